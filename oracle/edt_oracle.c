@@ -1,0 +1,340 @@
+/* oracle/edt_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded CPU restatement of the reference's multi-label anisotropic
+ * squared EDT (seung-lab/euclidean-distance-transform-3d, src/edt.hpp and
+ * src/edt_voxel_graph.hpp).  It is the *checker* the HIP path is compared against:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The shipped library (euclidean-distance-transform-3d_amd/csrc) never links, loads or
+ * falls back to anything in oracle/.
+ *
+ * Parity status: PINNED.  tests/test_oracle.py checks this file bit-for-bit against
+ *   (1) the real reference compiled from /root/reference/src (oracle/_ref, built by
+ *       oracle/Makefile), and
+ *   (2) the golden vectors under tests/golden/ (generated from the reference Python
+ *       module by tests/golden/make_golden.py) plus the hand-derivable known answers of
+ *       the reference's own test-suite (automated_test.py).
+ *
+ * Build: make -C oracle port   (gcc -O3 -ffp-contract=off, no fast-math)
+ *
+ * Every routine cites the reference lines it restates.  The arithmetic contract:
+ *   - pass 1 runs in fp32 (sequential adds of the voxel size, then an fp32 square);
+ *   - passes 2/3 evaluate the lower envelope in fp64 without FMA contraction and round
+ *     to fp32 once per pass;  w2 is the fp32 product w*w widened to fp64.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { DT_U8 = 0, DT_U16 = 1, DT_U32 = 2, DT_U64 = 3, DT_F32 = 4, DT_F64 = 5, DT_BOOL = 6 };
+
+/* ------------------------------------------------------------------------------------
+ * INF <-> FLT_MAX sentinels.  Reference: tofinite / toinfinite, src/edt.hpp:39-53.
+ * (FLT_MAX - 1 == FLT_MAX in fp32.)
+ * ---------------------------------------------------------------------------------- */
+static void inf_to_sentinel(float *f, int64_t count) {
+  for (int64_t i = 0; i < count; i++)
+    if (isinf(f[i])) f[i] = FLT_MAX;
+}
+static void sentinel_to_inf(float *f, int64_t count) {
+  for (int64_t i = 0; i < count; i++)
+    if (f[i] >= FLT_MAX) f[i] = INFINITY;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Scratch for the envelope scan, allocated once per volume instead of per run
+ * (the reference news three arrays per call, src/edt.hpp:184-192 / :261-269).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t cap;
+  int64_t *vertex;   /* v[]      : abscissa of each parabola on the envelope      */
+  double  *height;   /* ff[]     : fp64 copy of the row                           */
+  double  *start;    /* ranges[] : where each parabola starts to be the minimum   */
+} scratch_t;
+
+static int scratch_init(scratch_t *s, int64_t n) {
+  s->cap = n;
+  s->vertex = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+  s->height = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+  s->start  = (double *)malloc(sizeof(double) * (size_t)(n + 2));
+  return (s->vertex && s->height && s->start) ? 0 : -1;
+}
+static void scratch_free(scratch_t *s) {
+  free(s->vertex); free(s->height); free(s->start);
+}
+
+/* ------------------------------------------------------------------------------------
+ * One Felzenszwalb-Huttenlocher lower-envelope scan over f[0], f[stride], ...,
+ * f[(n-1)*stride], in place, with optional border parabolas of height 0 at -1 and n.
+ * Reference: squared_edt_1d_parabolic, src/edt.hpp:168-244 (0/1 border) and :247-313
+ * (both borders), dispatcher :315-330.
+ * ---------------------------------------------------------------------------------- */
+static void envelope_scan(float *f, int64_t n, int64_t stride, float w,
+                          int border_left, int border_right, scratch_t *s) {
+  if (n <= 0) return;
+  const double w2 = (double)(w * w);            /* fp32 product, then widened: :181, :258 */
+  int64_t *v = s->vertex;
+  double *ff = s->height;
+  double *z = s->start;
+
+  for (int64_t i = 0; i < n; i++) ff[i] = (double)f[i * stride];     /* :187-190 */
+
+  int64_t k = 0;
+  v[0] = 0;
+  z[0] = -INFINITY;
+  z[1] = +INFINITY;
+
+  for (int64_t i = 1; i < n; i++) {                                   /* :205-221 */
+    double s_x;
+    for (;;) {
+      const double f1 = (double)(i - v[k]) * w2;
+      const double f2 = (double)(i + v[k]);
+      s_x = (ff[i] - ff[v[k]] + f1 * f2) / (2.0 * f1);
+      if (k > 0 && s_x <= z[k]) { k--; continue; }
+      break;
+    }
+    k++;
+    v[k] = i;
+    z[k] = s_x;
+    z[k + 1] = +INFINITY;
+  }
+
+  k = 0;
+  for (int64_t i = 0; i < n; i++) {                                   /* :223-243, :300-312 */
+    while (z[k + 1] < (double)i) k++;
+    const double dx = (double)(i - v[k]);
+    float best = (float)(w2 * (dx * dx) + ff[v[k]]);
+    if (border_left && border_right) {
+      /* one fp64 min, one narrowing (:310-311) */
+      const double a = (double)(i + 1), b = (double)(n - i);
+      const float env = (float)fmin(w2 * (a * a), w2 * (b * b));
+      best = fminf(env, best);
+    } else if (border_left) {
+      const double a = (double)(i + 1);
+      best = fminf((float)(w2 * (a * a)), best);                       /* :238 */
+    } else if (border_right) {
+      const double b = (double)(n - i);
+      best = fminf((float)(w2 * (b * b)), best);                       /* :241 */
+    }
+    f[i * stride] = best;
+  }
+}
+
+/* ------------------------------------------------------------------------------------
+ * Typed kernels.  Only `== 0` and `==` between neighbours are ever applied to labels
+ * (src/edt.hpp:93-102, :356-358), with the C semantics of the label type (so for
+ * floating labels -0.0 is background and NaN never equals anything).
+ * ---------------------------------------------------------------------------------- */
+#define DEFINE_TYPED(T, SUF)                                                              \
+  /* Pass 1 along a contiguous row.  Reference: squared_edt_1d_multi_seg,               \
+   * src/edt.hpp:70-119 (stride fixed to 1: every caller passes 1). */                   \
+  static void row_pass_##SUF(const T *seg, float *d, int64_t n, float w, int bb) {        \
+    if (n <= 0) return;                                                                   \
+    T current = seg[0];                                                                   \
+    if (bb) d[0] = (float)(current != 0) * w;                                             \
+    else d[0] = (current == 0) ? 0.0f : INFINITY;                                         \
+    for (int64_t i = 1; i < n; i++) {                                                     \
+      if (seg[i] == 0) {                                                                  \
+        d[i] = 0.0f;                    /* background: does NOT change `current` */       \
+      } else if (seg[i] == current) {                                                     \
+        d[i] = d[i - 1] + w;                                                              \
+      } else {                                                                            \
+        d[i] = w;                                                                         \
+        d[i - 1] = (float)(seg[i - 1] != 0) * w;                                          \
+        current = seg[i];                                                                 \
+      }                                                                                   \
+    }                                                                                     \
+    int64_t lo = 0;                                                                       \
+    if (bb) { d[n - 1] = (float)(seg[n - 1] != 0) * w; lo = 1; }                          \
+    for (int64_t i = n - 2; i >= lo; i--) d[i] = fminf(d[i], d[i + 1] + w);               \
+    for (int64_t i = 0; i < n; i++) d[i] *= d[i];                                         \
+  }                                                                                       \
+                                                                                          \
+  /* Passes 2/3 along a strided column: split into maximal same-label runs and scan      \
+   * each non-background run.  Reference: squared_edt_1d_parabolic_multi_seg,            \
+   * src/edt.hpp:344-377. */                                                              \
+  static void column_pass_##SUF(const T *seg, float *f, int64_t n, int64_t stride,        \
+                                float w, int bb, scratch_t *s) {                          \
+    if (n <= 0) return;                                                                   \
+    T current = seg[0];                                                                   \
+    int64_t run_start = 0;                                                                \
+    for (int64_t i = 1; i < n; i++) {                                                     \
+      const T here = seg[i * stride];                                                     \
+      if (here != current) {                                                              \
+        if (current != 0)                                                                 \
+          envelope_scan(f + run_start * stride, i - run_start, stride, w,                 \
+                        bb || run_start > 0, 1, s);                                       \
+        current = here;                                                                   \
+        run_start = i;                                                                    \
+      }                                                                                   \
+    }                                                                                     \
+    if (current != 0)                                                                     \
+      envelope_scan(f + run_start * stride, n - run_start, stride, w,                     \
+                    bb || run_start > 0, bb, s);                                          \
+  }                                                                                       \
+                                                                                          \
+  /* 3-D driver.  Reference: _edt3dsq, src/edt.hpp:411-484 (thread pool dropped). */      \
+  static int volume_##SUF(const T *seg, int64_t sx, int64_t sy, int64_t sz, float wx,     \
+                          float wy, float wz, int bb, float *out, int ndim) {             \
+    const int64_t sxy = sx * sy, voxels = sxy * sz;                                       \
+    int64_t longest = sy > sz ? sy : sz;                                                  \
+    scratch_t s;                                                                          \
+    if (scratch_init(&s, longest) != 0) return -2;                                        \
+    for (int64_t r = 0; r < sy * sz; r++) row_pass_##SUF(seg + r * sx, out + r * sx, sx, wx, bb); \
+    if (ndim >= 2) {                                                                      \
+      if (!bb) inf_to_sentinel(out, voxels);                                              \
+      for (int64_t z = 0; z < sz; z++)                                                    \
+        for (int64_t x = 0; x < sx; x++)                                                  \
+          column_pass_##SUF(seg + x + sxy * z, out + x + sxy * z, sy, sx, wy, bb, &s);    \
+      if (ndim >= 3)                                                                      \
+        for (int64_t y = 0; y < sy; y++)                                                  \
+          for (int64_t x = 0; x < sx; x++)                                                \
+            column_pass_##SUF(seg + x + sx * y, out + x + sx * y, sz, sxy, wz, bb, &s);   \
+      if (!bb) sentinel_to_inf(out, voxels);                                              \
+    }                                                                                     \
+    scratch_free(&s);                                                                     \
+    return 0;                                                                             \
+  }
+
+DEFINE_TYPED(uint8_t, u8)
+DEFINE_TYPED(uint16_t, u16)
+DEFINE_TYPED(uint32_t, u32)
+DEFINE_TYPED(uint64_t, u64)
+DEFINE_TYPED(float, f32)
+DEFINE_TYPED(double, f64)
+
+/* ------------------------------------------------------------------------------------
+ * Boolean images take the reference's *binary* route: no run splitting; every column is
+ * scanned from its first non-zero pass-1 value to the end, background voxels taking part
+ * as height-0 parabolas.  Reference: _binary_edt3dsq src/edt.hpp:487-576,
+ * _binary_edt2dsq :681-732, bool overloads :580-587 / :758-772.
+ * ---------------------------------------------------------------------------------- */
+static void binary_column(float *f, int64_t n, int64_t stride, float w, int bb, scratch_t *s) {
+  int64_t first = 0;
+  while (first < n && f[first * stride] == 0.0f) first++;
+  envelope_scan(f + first * stride, n - first, stride, w, bb || first > 0, bb, s);
+}
+
+static int volume_bool(const uint8_t *img, int64_t sx, int64_t sy, int64_t sz, float wx,
+                       float wy, float wz, int bb, float *out, int ndim) {
+  const int64_t sxy = sx * sy, voxels = sxy * sz;
+  int64_t longest = sy > sz ? sy : sz;
+  scratch_t s;
+  if (scratch_init(&s, longest) != 0) return -2;
+  for (int64_t r = 0; r < sy * sz; r++) row_pass_u8(img + r * sx, out + r * sx, sx, wx, bb);
+  if (ndim >= 2) {
+    if (!bb) inf_to_sentinel(out, voxels);
+    for (int64_t z = 0; z < sz; z++)
+      for (int64_t x = 0; x < sx; x++) binary_column(out + x + sxy * z, sy, sx, wy, bb, &s);
+    if (ndim >= 3)
+      for (int64_t y = 0; y < sy; y++)
+        for (int64_t x = 0; x < sx; x++) binary_column(out + x + sx * y, sz, sxy, wz, bb, &s);
+    if (!bb) sentinel_to_inf(out, voxels);
+  }
+  scratch_free(&s);
+  return 0;
+}
+
+static int dispatch_volume(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz,
+                           float wx, float wy, float wz, int bb, float *out, int ndim) {
+  if (sx <= 0 || sy <= 0 || sz <= 0) return 0;
+  switch (dtype) {
+    case DT_U8:   return volume_u8((const uint8_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_U16:  return volume_u16((const uint16_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_U32:  return volume_u32((const uint32_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_U64:  return volume_u64((const uint64_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_F32:  return volume_f32((const float *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_F64:  return volume_f64((const double *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_BOOL: return volume_bool((const uint8_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    default: return -1;
+  }
+}
+
+/* ---------------------------------------------------------------------------------- */
+/* Public (test-only) entry points; x is the fastest axis: idx = x + sx*(y + sy*z).      */
+/* ---------------------------------------------------------------------------------- */
+int oracle_edt1dsq(const void *labels, int dtype, int64_t n, float w, int bb, float *out) {
+  return dispatch_volume(labels, dtype, n, 1, 1, w, 1.0f, 1.0f, bb, out, 1);
+}
+int oracle_edt2dsq(const void *labels, int dtype, int64_t sx, int64_t sy, float wx, float wy,
+                   int bb, float *out) {
+  return dispatch_volume(labels, dtype, sx, sy, 1, wx, wy, 1.0f, bb, out, 2);
+}
+int oracle_edt3dsq(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx,
+                   float wy, float wz, int bb, float *out) {
+  return dispatch_volume(labels, dtype, sx, sy, sz, wx, wy, wz, bb, out, 3);
+}
+
+/* In-place correctly rounded sqrt (numpy's np.sqrt in src/edt.pyx:242; std::sqrt in
+ * src/edt.hpp:599-601). */
+void oracle_sqrt_inplace(float *f, int64_t count) {
+  for (int64_t i = 0; i < count; i++) f[i] = sqrtf(f[i]);
+}
+
+/* ------------------------------------------------------------------------------------
+ * Voxel-connectivity-graph EDT: binarise, upsample 2x per axis into a uint8 volume
+ * where a blocked +x/+y/+z edge (graph bits 0x01 / 0x04 / 0x10 clear) becomes a
+ * background half-voxel, run the ordinary uint8 transform at half voxel size, then keep
+ * every other sample.  Reference: _edt3dsq_voxel_graph src/edt_voxel_graph.hpp:120-214,
+ * _edt2dsq_voxel_graph :54-117.
+ * ---------------------------------------------------------------------------------- */
+static int label_is_foreground(const void *labels, int dtype, int64_t i) {
+  switch (dtype) {
+    case DT_U8: case DT_BOOL: return ((const uint8_t *)labels)[i] > 0;
+    case DT_U16: return ((const uint16_t *)labels)[i] > 0;
+    case DT_U32: return ((const uint32_t *)labels)[i] > 0;
+    case DT_U64: return ((const uint64_t *)labels)[i] > 0;
+    case DT_F32: return ((const float *)labels)[i] > 0;
+    case DT_F64: return ((const double *)labels)[i] > 0;
+    default: return 0;
+  }
+}
+
+int oracle_edt3dsq_voxel_graph(const void *labels, int dtype, const uint8_t *graph, int64_t sx,
+                               int64_t sy, int64_t sz, float wx, float wy, float wz, int bb,
+                               float *out, int ndim) {
+  if (sx <= 0 || sy <= 0 || sz <= 0) return 0;
+  if (ndim == 2) sz = 1;
+  const int64_t X = 2 * sx, Y = 2 * sy, Z = (ndim == 3) ? 2 * sz : 1;
+  const int64_t big = X * Y * Z;
+  uint8_t *dbl = (uint8_t *)calloc((size_t)big, 1);
+  float *dt = (float *)malloc(sizeof(float) * (size_t)big);
+  if (!dbl || !dt) { free(dbl); free(dt); return -2; }
+
+  for (int64_t z = 0; z < sz; z++)
+    for (int64_t y = 0; y < sy; y++)
+      for (int64_t x = 0; x < sx; x++) {
+        const int64_t i = x + sx * (y + sy * z);
+        const int fg = label_is_foreground(labels, dtype, i);
+        const uint8_t g = graph[i];
+        for (int dz = 0; dz < (ndim == 3 ? 2 : 1); dz++)
+          for (int dy = 0; dy < 2; dy++)
+            for (int dx = 0; dx < 2; dx++) {
+              int v = fg;
+              /* only the three axis-aligned half-steps consult the graph (:145-154) */
+              if (dx == 1 && dy == 0 && dz == 0) v = fg && (g & 0x01);
+              if (dx == 0 && dy == 1 && dz == 0) v = fg && (g & 0x04);
+              if (dx == 0 && dy == 0 && dz == 1) v = fg && (g & 0x10);
+              /* black border trims the outermost upsampled faces (:156-187, :78-90) */
+              if (bb) {
+                if (dx == 1 && x == sx - 1) v = 0;
+                if (dy == 1 && y == sy - 1) v = 0;
+                if (dz == 1 && z == sz - 1) v = 0;
+              }
+              dbl[(2 * x + dx) + X * ((2 * y + dy) + Y * (2 * z + dz))] = (uint8_t)v;
+            }
+      }
+
+  int rc;
+  if (ndim == 3) rc = oracle_edt3dsq(dbl, DT_U8, X, Y, Z, wx / 2, wy / 2, wz / 2, bb, dt);
+  else           rc = oracle_edt2dsq(dbl, DT_U8, X, Y, wx / 2, wy / 2, bb, dt);
+
+  if (rc == 0)
+    for (int64_t z = 0; z < sz; z++)
+      for (int64_t y = 0; y < sy; y++)
+        for (int64_t x = 0; x < sx; x++)
+          out[x + sx * (y + sy * z)] = dt[2 * x + X * (2 * y + Y * (ndim == 3 ? 2 * z : 0))];
+  free(dbl); free(dt);
+  return rc;
+}

@@ -1,0 +1,479 @@
+// edt_api.hip -- the C ABI (include/edt_hip.h): orchestration of the passes, workspace
+// carving, host-buffer staging, per-pass event timing.  No compute happens on the host and
+// there is no CPU fallback: every entry point needs a HIP device.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "edt_common.h"
+#include "edt_kernels.h"
+
+namespace edt_amd {
+
+static thread_local std::string g_last_error = "";
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+// ---- per-pass event timing (bench.py reads this) -------------------------------------
+struct PassLog {
+  bool enabled = false;
+  std::vector<hipEvent_t> pool;          // reused events
+  std::vector<std::pair<int, int>> span;  // (start, stop) indices of the last call
+  std::vector<std::string> names;
+  int used = 0;
+};
+static PassLog g_log;
+static std::mutex g_log_mutex;
+
+static hipEvent_t log_event() {
+  if (g_log.used == (int)g_log.pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    g_log.pool.push_back(e);
+  }
+  return g_log.pool[g_log.used++];
+}
+
+struct ScopedPass {
+  hipStream_t stream;
+  int start = -1;
+  ScopedPass(const char *name, hipStream_t s) : stream(s) {
+    if (!g_log.enabled) return;
+    hipEvent_t e = log_event();
+    if (!e) return;
+    start = g_log.used - 1;
+    (void)hipEventRecord(e, stream);
+    g_log.names.push_back(name);
+  }
+  ~ScopedPass() {
+    if (start < 0) return;
+    hipEvent_t e = log_event();
+    if (!e) return;
+    (void)hipEventRecord(e, stream);
+    g_log.span.push_back({start, g_log.used - 1});
+  }
+};
+
+static void log_begin_call() {
+  g_log.used = 0;
+  g_log.span.clear();
+  g_log.names.clear();
+}
+
+// ---- workspace carving -----------------------------------------------------------------
+struct Carver {
+  char *base;
+  size_t off = 0;
+  explicit Carver(void *p) : base((char *)p) {}
+  template <typename T>
+  T *take(size_t count) {
+    off = align_up(off, 256);
+    T *p = base ? (T *)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+struct Plan {
+  int ndim;
+  int64_t sx, sy, sz, voxels;
+  AxisGeom gy, gz;
+  // carved pointers
+  float *bufB = nullptr;
+  int32_t *stack = nullptr;
+  uint32_t *nz_y = nullptr, *rs_y = nullptr, *nz_z = nullptr, *rs_z = nullptr;
+  size_t bytes = 0;
+};
+
+static AxisGeom make_geom_y(int64_t sx, int64_t sy, int64_t sz) {
+  AxisGeom g;
+  g.sx = sx; g.n = sy; g.stride = sx; g.nouter = sz; g.outer_stride = sx * sy;
+  g.nbands = ceil_div(sy, kBandRows);
+  return g;
+}
+static AxisGeom make_geom_z(int64_t sx, int64_t sy, int64_t sz) {
+  AxisGeom g;
+  g.sx = sx; g.n = sz; g.stride = sx * sy; g.nouter = sy; g.outer_stride = sx;
+  g.nbands = ceil_div(sz, kBandRows);
+  return g;
+}
+
+static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws) {
+  Plan p;
+  p.ndim = ndim; p.sx = sx; p.sy = sy; p.sz = sz; p.voxels = sx * sy * sz;
+  p.gy = make_geom_y(sx, sy, sz);
+  p.gz = make_geom_z(sx, sy, sz);
+  Carver c(ws);
+  if (ndim >= 2) {
+    p.bufB = c.take<float>((size_t)p.voxels);
+    p.stack = c.take<int32_t>((size_t)p.voxels);
+    const size_t wy = (size_t)(p.gy.sx * p.gy.nbands * p.gy.nouter);
+    p.nz_y = c.take<uint32_t>(wy);
+    p.rs_y = c.take<uint32_t>(wy);
+  }
+  if (ndim >= 3) {
+    const size_t wz = (size_t)(p.gz.sx * p.gz.nbands * p.gz.nouter);
+    p.nz_z = c.take<uint32_t>(wz);
+    p.rs_z = c.take<uint32_t>(wz);
+  }
+  p.bytes = align_up(c.off, 256) + 256;
+  return p;
+}
+
+static int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
+  if (dtype_size(dtype) == 0) { set_error("unknown dtype code"); return EDT_ERR_BAD_ARG; }
+  if (ndim < 1 || ndim > 3) { set_error("ndim must be 1, 2 or 3"); return EDT_ERR_BAD_ARG; }
+  if (sx < 0 || sy < 0 || sz < 0) { set_error("negative extent"); return EDT_ERR_BAD_ARG; }
+  if ((ndim < 3 && sz != 1) || (ndim < 2 && sy != 1)) {
+    set_error("unused extents must be 1");
+    return EDT_ERR_BAD_ARG;
+  }
+  if (sx > INT32_MAX || sy > INT32_MAX || sz > INT32_MAX) {
+    set_error("extent exceeds 2^31-1");
+    return EDT_ERR_UNSUPPORTED;
+  }
+  return EDT_OK;
+}
+
+static int require_device() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available (this library has no CPU fallback)");
+    return EDT_ERR_NO_DEVICE;
+  }
+  return EDT_OK;
+}
+
+// ---- the pass pipeline on device-resident data -----------------------------------------
+static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz,
+                      float wx, float wy, float wz, int flags, float *d_out, void *d_ws,
+                      size_t ws_bytes, hipStream_t stream) {
+  int rc = check_shape(dtype, ndim, sx, sy, sz);
+  if (rc != EDT_OK) return rc;
+  if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
+  if (!d_labels || !d_out) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
+  Plan p = make_plan(ndim, sx, sy, sz, d_ws);
+  if (ndim >= 2 && (!d_ws || ws_bytes < p.bytes)) {
+    set_error("workspace too small: need " + std::to_string(p.bytes) + " bytes");
+    return EDT_ERR_BAD_ARG;
+  }
+  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  const int want_sqrt = (flags & EDT_FLAG_SQRT) ? 1 : 0;
+  const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0);
+
+  std::lock_guard<std::mutex> lock(g_log_mutex);
+  log_begin_call();
+
+  if (ndim == 1) {
+    ScopedPass t("x_pass", stream);
+    return launch_row_pass_serial(dtype, d_labels, d_out, sx, 1, wx, bb, 0, want_sqrt, stream);
+  }
+
+  // pass 1 (x) -> A ; bits ; pass 2 (y): A -> B ; pass 3 (z): B -> A.  A must end up == d_out.
+  float *bufA = (ndim == 3) ? d_out : p.bufB;
+  float *bufB = (ndim == 3) ? p.bufB : d_out;
+  {
+    ScopedPass t("x_pass", stream);
+    rc = launch_row_pass_serial(dtype, d_labels, bufA, sx, sy * sz, wx, bb, bb ? 0 : 1, 0, stream);
+    if (rc != EDT_OK) return rc;
+  }
+  {
+    ScopedPass t("y_bits", stream);
+    rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_y, p.rs_y, p.gy, stream);
+    if (rc != EDT_OK) return rc;
+  }
+  {
+    ScopedPass t("y_pass", stream);
+    rc = launch_column_pass_serial(bufA, bufB, p.nz_y, p.rs_y, p.stack, p.gy, wy, bb,
+                                   ndim == 2 ? last_epi : 0, stream);
+    if (rc != EDT_OK) return rc;
+  }
+  if (ndim == 3) {
+    {
+      ScopedPass t("z_bits", stream);
+      rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
+      if (rc != EDT_OK) return rc;
+    }
+    ScopedPass t("z_pass", stream);
+    rc = launch_column_pass_serial(bufB, bufA, p.nz_z, p.rs_z, p.stack, p.gz, wz, bb, last_epi,
+                                   stream);
+    if (rc != EDT_OK) return rc;
+  }
+  return EDT_OK;
+}
+
+// ---- host-buffer staging -----------------------------------------------------------------
+struct DeviceBuf {
+  void *p = nullptr;
+  ~DeviceBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      p = nullptr;
+      set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+      return EDT_ERR_NOMEM;
+    }
+    return EDT_OK;
+  }
+};
+
+static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz,
+                    float wx, float wy, float wz, int flags, float *output) {
+  int rc = check_shape(dtype, ndim, sx, sy, sz);
+  if (rc != EDT_OK) return rc;
+  const int64_t voxels = sx * sy * sz;
+  if (voxels == 0) return EDT_OK;
+  if (!labels || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
+  rc = require_device();
+  if (rc != EDT_OK) return rc;
+
+  const size_t lbytes = (size_t)voxels * dtype_size(dtype);
+  const size_t obytes = (size_t)voxels * sizeof(float);
+  const size_t wbytes = edt_hip_workspace_bytes(dtype, ndim, sx, sy, sz);
+  DeviceBuf d_labels, d_out, d_ws;
+  if ((rc = d_labels.alloc(lbytes)) != EDT_OK) return rc;
+  if ((rc = d_out.alloc(obytes)) != EDT_OK) return rc;
+  if ((rc = d_ws.alloc(wbytes)) != EDT_OK) return rc;
+  EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
+  rc = run_device(d_labels.p, dtype, ndim, sx, sy, sz, wx, wy, wz, flags, (float *)d_out.p, d_ws.p,
+                  wbytes, nullptr);
+  if (rc != EDT_OK) return rc;
+  EDT_HIP_TRY(hipMemcpy(output, d_out.p, obytes, hipMemcpyDeviceToHost));
+  return EDT_OK;
+}
+
+
+static int voxel_graph_host(const void *labels, int dtype, const uint8_t *graph, int ndim, int64_t sx,
+                            int64_t sy, int64_t sz, float wx, float wy, float wz, int black_border,
+                            float *output) {
+  int rc = check_shape(dtype, ndim, sx, sy, sz);
+  if (rc != EDT_OK) return rc;
+  const int64_t voxels = sx * sy * sz;
+  if (voxels == 0) return EDT_OK;
+  if (!labels || !graph || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
+  if ((rc = require_device()) != EDT_OK) return rc;
+  const int64_t X = 2 * sx, Y = 2 * sy, Z = (ndim == 3) ? 2 * sz : 1;
+  const int64_t big = X * Y * Z;
+  const size_t lbytes = (size_t)voxels * dtype_size(dtype);
+  const size_t wbytes = edt_hip_workspace_bytes(EDT_U8, ndim, X, Y, Z);
+  DeviceBuf d_labels, d_graph, d_big, d_bigdt, d_ws, d_out;
+  if ((rc = d_labels.alloc(lbytes)) != EDT_OK) return rc;
+  if ((rc = d_graph.alloc((size_t)voxels)) != EDT_OK) return rc;
+  if ((rc = d_big.alloc((size_t)big)) != EDT_OK) return rc;
+  if ((rc = d_bigdt.alloc((size_t)big * sizeof(float))) != EDT_OK) return rc;
+  if ((rc = d_ws.alloc(wbytes)) != EDT_OK) return rc;
+  if ((rc = d_out.alloc((size_t)voxels * sizeof(float))) != EDT_OK) return rc;
+  EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
+  EDT_HIP_TRY(hipMemcpy(d_graph.p, graph, (size_t)voxels, hipMemcpyHostToDevice));
+  rc = launch_vg_expand(dtype, d_labels.p, (const uint8_t *)d_graph.p, (uint8_t *)d_big.p, sx, sy, sz,
+                        ndim, black_border ? 1 : 0, nullptr);
+  if (rc != EDT_OK) return rc;
+  // half voxel size on the 2x grid (src/edt_voxel_graph.hpp:96-101, :189-193)
+  rc = run_device(d_big.p, EDT_U8, ndim, X, Y, Z, wx / 2, wy / 2, wz / 2,
+                  black_border ? EDT_FLAG_BLACK_BORDER : 0, (float *)d_bigdt.p, d_ws.p, wbytes,
+                  nullptr);
+  if (rc != EDT_OK) return rc;
+  rc = launch_vg_gather((const float *)d_bigdt.p, (float *)d_out.p, sx, sy, sz, ndim, nullptr);
+  if (rc != EDT_OK) return rc;
+  EDT_HIP_TRY(hipMemcpy(output, d_out.p, (size_t)voxels * sizeof(float), hipMemcpyDeviceToHost));
+  return EDT_OK;
+}
+
+// ---- Z-sharded phases ------------------------------------------------------------------------
+struct ShardPlan {
+  float *bufB = nullptr;
+  int32_t *stack = nullptr;
+  uint32_t *nz = nullptr, *rs = nullptr;
+  size_t bytes = 0;
+};
+
+static ShardPlan make_shard_plan(int64_t sx, int64_t sy, int64_t sz, void *ws) {
+  // sized for the larger of the two phases run on an (sx, sy, sz) block
+  ShardPlan p;
+  Carver c(ws);
+  const int64_t voxels = sx * sy * sz;
+  p.bufB = c.take<float>((size_t)voxels);
+  p.stack = c.take<int32_t>((size_t)voxels);
+  const AxisGeom gy = make_geom_y(sx, sy, sz), gz = make_geom_z(sx, sy, sz);
+  const size_t words = (size_t)std::max(gy.sx * gy.nbands * gy.nouter, gz.sx * gz.nbands * gz.nouter);
+  p.nz = c.take<uint32_t>(words);
+  p.rs = c.take<uint32_t>(words);
+  p.bytes = align_up(c.off, 256) + 256;
+  return p;
+}
+
+}  // namespace edt_amd
+
+using namespace edt_amd;
+
+extern "C" {
+
+int edt_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+const char *edt_hip_last_error(void) { return g_last_error.c_str(); }
+
+const char *edt_hip_version(void) { return "edt_hip 0.1 (gfx950)"; }
+
+int edt_hip_squared_edt_1d_multi_seg(const void *labels, int dtype, float *dest, int64_t n,
+                                     int64_t stride, float anisotropy, int black_border) {
+  if (stride != 1) {
+    set_error("stride != 1 is not supported (no reference caller uses it)");
+    return EDT_ERR_UNSUPPORTED;
+  }
+  return run_host(labels, dtype, 1, n, 1, 1, anisotropy, 1.0f, 1.0f,
+                  black_border ? EDT_FLAG_BLACK_BORDER : 0, dest);
+}
+
+int edt_hip_edt2dsq(const void *labels, int dtype, int64_t sx, int64_t sy, float wx, float wy,
+                    int black_border, int /*parallel*/, float *output) {
+  return run_host(labels, dtype, 2, sx, sy, 1, wx, wy, 1.0f,
+                  black_border ? EDT_FLAG_BLACK_BORDER : 0, output);
+}
+
+int edt_hip_edt3dsq(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx,
+                    float wy, float wz, int black_border, int /*parallel*/, float *output) {
+  return run_host(labels, dtype, 3, sx, sy, sz, wx, wy, wz,
+                  black_border ? EDT_FLAG_BLACK_BORDER : 0, output);
+}
+
+int edt_hip_edt2d(const void *labels, int dtype, int64_t sx, int64_t sy, float wx, float wy,
+                  int black_border, int /*parallel*/, float *output) {
+  return run_host(labels, dtype, 2, sx, sy, 1, wx, wy, 1.0f,
+                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | EDT_FLAG_SQRT, output);
+}
+
+int edt_hip_edt3d(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx,
+                  float wy, float wz, int black_border, int /*parallel*/, float *output) {
+  return run_host(labels, dtype, 3, sx, sy, sz, wx, wy, wz,
+                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | EDT_FLAG_SQRT, output);
+}
+
+size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
+  if (check_shape(dtype, ndim, sx, sy, sz) != EDT_OK) return 0;
+  if (sx == 0 || sy == 0 || sz == 0) return 256;
+  return make_plan(ndim, sx, sy, sz, nullptr).bytes;
+}
+
+int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy,
+                         int64_t sz, float wx, float wy, float wz, int flags, float *d_output,
+                         void *d_workspace, size_t workspace_bytes, void *stream) {
+  return run_device(d_labels, dtype, ndim, sx, sy, sz, wx, wy, wz, flags, d_output, d_workspace,
+                    workspace_bytes, (hipStream_t)stream);
+}
+
+int edt_hip_set_profiling(int enabled) {
+  std::lock_guard<std::mutex> lock(g_log_mutex);
+  g_log.enabled = enabled != 0;
+  return EDT_OK;
+}
+
+int edt_hip_get_pass_times(float *ms, int capacity) {
+  std::lock_guard<std::mutex> lock(g_log_mutex);
+  int n = (int)g_log.span.size();
+  for (int i = 0; i < n && i < capacity; ++i) {
+    float t = 0.0f;
+    if (hipEventElapsedTime(&t, g_log.pool[g_log.span[i].first], g_log.pool[g_log.span[i].second]) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      t = -1.0f;
+    }
+    ms[i] = t;
+  }
+  return n;
+}
+
+const char *edt_hip_get_pass_name(int index) {
+  std::lock_guard<std::mutex> lock(g_log_mutex);
+  if (index < 0 || index >= (int)g_log.names.size()) return "";
+  return g_log.names[index].c_str();
+}
+
+int edt_hip_edt2dsq_voxel_graph(const void *labels, int dtype, const uint8_t *graph, int64_t sx,
+                                int64_t sy, float wx, float wy, int black_border,
+                                float *workspace) {
+  return voxel_graph_host(labels, dtype, graph, 2, sx, sy, 1, wx, wy, 2.0f, black_border, workspace);
+}
+
+int edt_hip_edt3dsq_voxel_graph(const void *labels, int dtype, const uint8_t *graph, int64_t sx,
+                                int64_t sy, int64_t sz, float wx, float wy, float wz,
+                                int black_border, float *workspace) {
+  return voxel_graph_host(labels, dtype, graph, 3, sx, sy, sz, wx, wy, wz, black_border, workspace);
+}
+
+size_t edt_hip_shard_workspace_bytes(int dtype, int64_t sx, int64_t sy, int64_t sz) {
+  if (check_shape(dtype, 3, sx, sy, sz) != EDT_OK) return 0;
+  if (sx == 0 || sy == 0 || sz == 0) return 256;
+  return make_shard_plan(sx, sy, sz, nullptr).bytes;
+}
+
+int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype, int64_t sx,
+                            int64_t sy, int64_t sz_local, float wx, float wy, int flags,
+                            float *d_partial, uint8_t *d_zflags, void *d_workspace,
+                            size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape(dtype, 3, sx, sy, sz_local);
+  if (rc != EDT_OK) return rc;
+  if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
+  if (!d_labels || !d_partial || !d_zflags) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
+  ShardPlan p = make_shard_plan(sx, sy, sz_local, d_workspace);
+  if (!d_workspace || workspace_bytes < p.bytes) {
+    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
+    return EDT_ERR_BAD_ARG;
+  }
+  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  const AxisGeom gy = make_geom_y(sx, sy, sz_local);
+  rc = launch_row_pass_serial(dtype, d_labels, p.bufB, sx, sy * sz_local, wx, bb, bb ? 0 : 1, 0, stream);
+  if (rc != EDT_OK) return rc;
+  rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz, p.rs, gy, stream);
+  if (rc != EDT_OK) return rc;
+  rc = launch_column_pass_serial(p.bufB, d_partial, p.nz, p.rs, p.stack, gy, wy, bb, 0, stream);
+  if (rc != EDT_OK) return rc;
+  return launch_zflags(dtype, d_labels, d_halo, d_zflags, sx * sy, sz_local, stream);
+}
+
+int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx, int64_t sy_local,
+                           int64_t sz, float wz, int flags, void *d_workspace,
+                           size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
+  if (rc != EDT_OK) return rc;
+  if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
+  if (!d_partial || !d_zflags) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
+  ShardPlan p = make_shard_plan(sx, sy_local, sz, d_workspace);
+  if (!d_workspace || workspace_bytes < p.bytes) {
+    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
+    return EDT_ERR_BAD_ARG;
+  }
+  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
+  const AxisGeom gz = make_geom_z(sx, sy_local, sz);
+  rc = launch_bits_from_flags(d_zflags, p.nz, p.rs, gz, stream);
+  if (rc != EDT_OK) return rc;
+  rc = launch_column_pass_serial(d_partial, p.bufB, p.nz, p.rs, p.stack, gz, wz, bb, epi, stream);
+  if (rc != EDT_OK) return rc;
+  EDT_HIP_TRY(hipMemcpyAsync(d_partial, p.bufB, (size_t)(sx * sy_local * sz) * sizeof(float),
+                             hipMemcpyDeviceToDevice, stream));
+  return EDT_OK;
+}
+
+int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, int64_t count,
+                            void *stream) {
+  return launch_subtract(d_a, d_b, d_out, count, (hipStream_t)stream);
+}
+
+int edt_hip_is_background_device(const void *d_labels, int dtype, uint8_t *d_mask, int64_t count,
+                                 void *stream) {
+  return launch_is_background(dtype, d_labels, d_mask, count, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// edt_common.h -- shared host/device helpers for the MI355X EDT library (internal).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "edt_hip.h"
+
+// All envelope arithmetic must be evaluated exactly as written: fp64 multiply and add as
+// separate IEEE operations (the reference CPU build has no FMA).  The build also passes
+// -ffp-contract=off; the pragma makes the intent local and robust.
+#pragma clang fp contract(off)
+
+namespace edt_amd {
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kBandRows = 32;    // rows of the scan axis covered by one bit-word
+
+// ---- error plumbing ---------------------------------------------------------------
+void set_error(const std::string &msg);
+
+#define EDT_HIP_TRY(expr)                                                              \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      ::edt_amd::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+      return EDT_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline int dtype_size(int dtype) {
+  switch (dtype) {
+    case EDT_U8: case EDT_BOOL: return 1;
+    case EDT_U16: return 2;
+    case EDT_U32: case EDT_F32: return 4;
+    case EDT_U64: case EDT_F64: return 8;
+    default: return 0;
+  }
+}
+
+// Geometry of one separable pass over a volume whose x axis is contiguous.
+//   column c = (x, o):  first voxel at  x + o * outer_stride,  rows `stride` apart.
+//   Y pass: n = sy, stride = sx,    outer = z (nouter = sz, outer_stride = sx*sy)
+//   Z pass: n = sz, stride = sx*sy, outer = y (nouter = sy, outer_stride = sx)
+struct AxisGeom {
+  int64_t sx;            // contiguous extent (columns per outer index)
+  int64_t n;             // length of the scan axis
+  int64_t stride;        // element stride between consecutive rows of a column
+  int64_t nouter;        // number of outer indices
+  int64_t outer_stride;  // element stride between outer indices
+  int64_t nbands;        // ceil(n / 32): bit-words per column
+};
+
+// epilogue of the last pass (fused tofinite/toinfinite/sqrt: src/edt.hpp:39-53, :599-601)
+enum : int { kEpiToInf = 1, kEpiSqrt = 2 };
+
+}  // namespace edt_amd

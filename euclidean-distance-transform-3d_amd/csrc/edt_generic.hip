@@ -1,0 +1,349 @@
+// edt_generic.hip -- size-agnostic fallback kernels.
+//
+// These kernels accept ANY extents (they keep their per-column state in global memory)
+// and are the path taken when a row/column is too long for the LDS-tiled kernels of
+// edt_tiled.hip, or when EDT_FLAG_FORCE_GENERIC is set (the tests use that to
+// cross-check the two implementations against each other).
+// They are written for clarity and exactness first; the tuned path lives in edt_tiled.hip.
+//
+// What is computed (algorithm-independent statement; reference: src/edt.hpp:70-119,
+// :168-377, :411-484):
+//   pass 1 (x):  per row, per maximal run of one non-zero label, distance to the nearer
+//                run end by sequential fp32 additions of wx, squared in fp32;
+//   pass 2/3  :  per column, per maximal run [a,b] of one non-zero label,
+//                  out[p] = fl32( min_j  w2*(p-j)^2 + F[j] ),  j in [a,b],  fp64, no FMA,
+//                then min'ed with the border parabolas fl32(w2*(p-a+1)^2) / fl32(w2*(b-p+1)^2)
+//                where a border (volume edge with black_border, or a label change) exists.
+// The lower envelope is built as the lower convex hull of the points (j, F[j] + w2*j^2)
+// with a division-free orientation test; only the value of the minimum reaches the
+// output, evaluated with the reference's own expression (src/edt.hpp:230, :307).
+#include "edt_common.h"
+#include "edt_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace edt_amd {
+
+// ------------------------------------------------------------------------------------
+// Pass 1, one thread per row (fallback for very long rows).  Same recurrences as the
+// reference's sweeps (src/edt.hpp:83-118) so that fp32 rounding is identical.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_row_pass_serial(const T *__restrict__ labels, float *__restrict__ out,
+                                  int64_t sx, int64_t nrows, float w, int bb, int to_finite,
+                                  int take_sqrt) {
+  const int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (row >= nrows) return;
+  const T *seg = labels + row * sx;
+  float *d = out + row * sx;
+
+  T current = seg[0];
+  T before = current;
+  float run = bb ? (float)(current != 0) * w : (current == 0 ? 0.0f : INFINITY);
+  d[0] = run;
+  for (int64_t i = 1; i < sx; ++i) {
+    const T here = seg[i];
+    if (here == 0) {
+      run = 0.0f;
+    } else if (here == current) {
+      run = run + w;
+    } else {
+      run = w;
+      d[i - 1] = (float)(before != 0) * w;
+      current = here;
+    }
+    d[i] = run;
+    before = here;
+  }
+  int64_t lo = 0;
+  if (bb) {
+    d[sx - 1] = (float)(seg[sx - 1] != 0) * w;
+    lo = 1;
+  }
+  float next = d[sx - 1];
+  for (int64_t i = sx - 2; i >= lo; --i) {
+    const float v = fminf(d[i], next + w);
+    d[i] = v;
+    next = v;
+  }
+  for (int64_t i = 0; i < sx; ++i) {
+    float v = d[i];
+    v = v * v;
+    if (to_finite && isinf(v)) v = FLT_MAX;
+    if (take_sqrt) v = sqrtf(v);
+    d[i] = v;
+  }
+}
+
+template <typename T>
+static int launch_row_serial_t(const void *labels, float *out, int64_t sx, int64_t nrows, float w,
+                               int bb, int to_finite, int take_sqrt, hipStream_t stream) {
+  const int threads = 64;
+  const int64_t blocks = ceil_div(nrows, threads);
+  hipLaunchKernelGGL(k_row_pass_serial<T>, dim3((unsigned)blocks), dim3(threads), 0, stream,
+                     (const T *)labels, out, sx, nrows, w, bb, to_finite, take_sqrt);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+int launch_row_pass_serial(int dtype, const void *labels, float *out, int64_t sx, int64_t nrows,
+                           float w, int bb, int to_finite, int take_sqrt, hipStream_t stream) {
+  switch (dtype) {
+    case EDT_U8: case EDT_BOOL:
+      return launch_row_serial_t<uint8_t>(labels, out, sx, nrows, w, bb, to_finite, take_sqrt, stream);
+    case EDT_U16: return launch_row_serial_t<uint16_t>(labels, out, sx, nrows, w, bb, to_finite, take_sqrt, stream);
+    case EDT_U32: return launch_row_serial_t<uint32_t>(labels, out, sx, nrows, w, bb, to_finite, take_sqrt, stream);
+    case EDT_U64: return launch_row_serial_t<uint64_t>(labels, out, sx, nrows, w, bb, to_finite, take_sqrt, stream);
+    case EDT_F32: return launch_row_serial_t<float>(labels, out, sx, nrows, w, bb, to_finite, take_sqrt, stream);
+    case EDT_F64: return launch_row_serial_t<double>(labels, out, sx, nrows, w, bb, to_finite, take_sqrt, stream);
+    default: set_error("unknown dtype"); return EDT_ERR_BAD_ARG;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Run structure of a scan axis as two bit-volumes (labels are compared exactly once, here):
+//   nz word (o, b, x): bit r set  <=>  label(x, row 32b+r, o) != 0
+//   rs word (o, b, x): bit r set  <=>  row 32b+r starts a run (row 0, or label differs
+//                                       from the previous row; src/edt.hpp:355-368)
+// Word layout [o][b][x] so that the column passes read them coalesced across x.
+// One thread per word.  `halo`, when given, supplies the row "-1" of every column
+// (used by the Z-sharded path where the previous slab lives on another GPU).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_axis_bits(const T *__restrict__ labels, const T *__restrict__ halo,
+                            uint32_t *__restrict__ nzbits, uint32_t *__restrict__ rsbits,
+                            AxisGeom g) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = g.sx * g.nbands * g.nouter;
+  if (idx >= total) return;
+  const int64_t x = idx % g.sx;
+  const int64_t b = (idx / g.sx) % g.nbands;
+  const int64_t o = idx / (g.sx * g.nbands);
+  const T *col = labels + x + o * g.outer_stride;
+  const int64_t r0 = b * kBandRows;
+  T prev = 0;
+  bool have_prev = false;
+  if (r0 > 0) { prev = col[(r0 - 1) * g.stride]; have_prev = true; }
+  else if (halo != nullptr) { prev = halo[x + o * g.outer_stride]; have_prev = true; }
+  uint32_t nz = 0, rs = 0;
+  for (int r = 0; r < kBandRows; ++r) {
+    const int64_t row = r0 + r;
+    if (row >= g.n) break;
+    const T here = col[row * g.stride];
+    if (here != 0) nz |= 1u << r;
+    if (!have_prev || here != prev) rs |= 1u << r;
+    prev = here;
+    have_prev = true;
+  }
+  nzbits[idx] = nz;
+  rsbits[idx] = rs;
+}
+
+template <typename T>
+static int launch_bits_t(const void *labels, const void *halo, uint32_t *nz, uint32_t *rs,
+                         const AxisGeom &g, hipStream_t stream) {
+  const int threads = 256;
+  const int64_t total = g.sx * g.nbands * g.nouter;
+  hipLaunchKernelGGL(k_axis_bits<T>, dim3((unsigned)ceil_div(total, threads)), dim3(threads), 0,
+                     stream, (const T *)labels, (const T *)halo, nz, rs, g);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+int launch_axis_bits(int dtype, const void *labels, const void *halo, uint32_t *nz, uint32_t *rs,
+                     const AxisGeom &g, hipStream_t stream) {
+  switch (dtype) {
+    case EDT_U8: case EDT_BOOL: return launch_bits_t<uint8_t>(labels, halo, nz, rs, g, stream);
+    case EDT_U16: return launch_bits_t<uint16_t>(labels, halo, nz, rs, g, stream);
+    case EDT_U32: return launch_bits_t<uint32_t>(labels, halo, nz, rs, g, stream);
+    case EDT_U64: return launch_bits_t<uint64_t>(labels, halo, nz, rs, g, stream);
+    case EDT_F32: return launch_bits_t<float>(labels, halo, nz, rs, g, stream);
+    case EDT_F64: return launch_bits_t<double>(labels, halo, nz, rs, g, stream);
+    default: set_error("unknown dtype"); return EDT_ERR_BAD_ARG;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Passes 2/3, one thread per column, hull vertices kept in a global-memory stack that
+// shares the volume's addressing (entry k of column c lives at stack[c + k*stride], so
+// lanes that agree on k access it coalesced).  Not in place: reads `fin`, writes `fout`.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t next_run_start(const uint32_t *rsw, int64_t word_stride,
+                                                  int64_t nbands, int64_t after, int64_t n) {
+  int64_t q = after + 1;
+  int64_t wi = q >> 5;
+  if (wi >= nbands) return n;
+  uint32_t wv = rsw[wi * word_stride] & (~0u << (q & 31));
+  while (true) {
+    if (wv) {
+      const int64_t pos = wi * 32 + __builtin_ctz(wv);
+      return pos < n ? pos : n;
+    }
+    if (++wi >= nbands) return n;
+    wv = rsw[wi * word_stride];
+  }
+}
+
+__global__ void k_column_pass_serial(const float *__restrict__ fin, float *__restrict__ fout,
+                                     const uint32_t *__restrict__ nzbits,
+                                     const uint32_t *__restrict__ rsbits,
+                                     int32_t *__restrict__ stack, AxisGeom g, float w, int bb,
+                                     int epi) {
+  const int64_t col = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (col >= g.sx * g.nouter) return;
+  const int64_t x = col % g.sx, o = col / g.sx;
+  const int64_t base = x + o * g.outer_stride;
+  const uint32_t *nzw = nzbits + o * g.nbands * g.sx + x;
+  const uint32_t *rsw = rsbits + o * g.nbands * g.sx + x;
+  const float *f = fin + base;
+  float *out = fout + base;
+  int32_t *stk = stack + base;
+  const int64_t n = g.n, st = g.stride;
+  const double w2 = (double)(w * w);  // fp32 product widened (src/edt.hpp:181, :258)
+
+  // ---- sweep 1: lower convex hull of every run -----------------------------------
+  int64_t k = 0, kb = 0;
+  int64_t ia = -1, ib = -1;
+  double Fa = 0.0, Fb = 0.0;
+  uint32_t nzword = 0, rsword = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int r = (int)(i & 31);
+    if (r == 0) {
+      nzword = nzw[(i >> 5) * g.sx];
+      rsword = rsw[(i >> 5) * g.sx];
+    }
+    if ((rsword >> r) & 1u) kb = k;
+    if (!((nzword >> r) & 1u)) continue;
+    const double Fi = (double)f[i * st];
+    while (k - kb >= 2) {
+      const double lhs = hull_num(Fb, Fi, ib, i, w2) * (double)(ib - ia);
+      const double rhs = hull_num(Fa, Fb, ia, ib, w2) * (double)(i - ib);
+      if (!(lhs <= rhs)) break;
+      --k;  // vertex ib is on or above the chord (ia, i): drop it
+      ib = ia;
+      Fb = Fa;
+      if (k - kb >= 2) {
+        ia = stk[(k - 2) * st];
+        Fa = (double)f[ia * st];
+      }
+    }
+    stk[k * st] = (int32_t)i;
+    ++k;
+    ia = ib; Fa = Fb;
+    ib = i;  Fb = Fi;
+  }
+
+  // ---- sweep 2: evaluate the envelope -----------------------------------------------
+  const int64_t ktot = k;
+  int64_t kk = 0;
+  int64_t run_lo = 0, run_hi = -1;
+  int64_t j = 0, jn = -1;
+  double Fj = 0.0, Fjn = 0.0;
+  for (int64_t p = 0; p < n; ++p) {
+    const int r = (int)(p & 31);
+    if (r == 0) {
+      nzword = nzw[(p >> 5) * g.sx];
+      rsword = rsw[(p >> 5) * g.sx];
+    }
+    const bool nz = (nzword >> r) & 1u;
+    if ((rsword >> r) & 1u) {
+      run_lo = p;
+      run_hi = next_run_start(rsw, g.sx, g.nbands, p, n) - 1;
+      if (nz) {
+        while (stk[kk * st] < p) ++kk;  // skip hull vertices of earlier runs
+        j = p;
+        Fj = (double)f[p * st];
+        jn = -1;
+        if (kk + 1 < ktot) {
+          jn = stk[(kk + 1) * st];
+          if (jn > run_hi) jn = -1; else Fjn = (double)f[jn * st];
+        }
+      }
+    }
+    if (!nz) {
+      out[p * st] = 0.0f;
+      continue;
+    }
+    double best = w2 * sqd(p - j) + Fj;
+    while (jn >= 0) {
+      const double cand = w2 * sqd(p - jn) + Fjn;
+      if (!(cand < best)) break;
+      best = cand;
+      ++kk;
+      j = jn; Fj = Fjn;
+      jn = -1;
+      if (kk + 1 < ktot) {
+        jn = stk[(kk + 1) * st];
+        if (jn > run_hi) jn = -1; else Fjn = (double)f[jn * st];
+      }
+    }
+    float m = (float)best;
+    if (bb || run_lo > 0) m = fminf((float)(w2 * sqd(p - run_lo + 1)), m);
+    if (bb || run_hi < n - 1) m = fminf((float)(w2 * sqd(run_hi - p + 1)), m);
+    out[p * st] = finish(m, epi);
+  }
+}
+
+int launch_column_pass_serial(const float *fin, float *fout, const uint32_t *nz, const uint32_t *rs,
+                              int32_t *stack, const AxisGeom &g, float w, int bb, int epi,
+                              hipStream_t stream) {
+  const int threads = 64;
+  const int64_t cols = g.sx * g.nouter;
+  hipLaunchKernelGGL(k_column_pass_serial, dim3((unsigned)ceil_div(cols, threads)), dim3(threads), 0,
+                     stream, fin, fout, nz, rs, stack, g, w, bb, epi);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Small elementwise helpers.
+// ------------------------------------------------------------------------------------
+__global__ void k_subtract(const float *__restrict__ a, const float *__restrict__ b,
+                           float *__restrict__ out, int64_t count) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += step) out[i] = a[i] - b[i];
+}
+
+int launch_subtract(const float *a, const float *b, float *out, int64_t count, hipStream_t stream) {
+  if (count <= 0) return EDT_OK;
+  const int threads = 256;
+  int64_t blocks = ceil_div(count, threads);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_subtract, dim3((unsigned)blocks), dim3(threads), 0, stream, a, b, out, count);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+template <typename T>
+__global__ void k_is_background(const T *__restrict__ labels, uint8_t *__restrict__ mask,
+                                int64_t count) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += step) mask[i] = (labels[i] == 0) ? 1 : 0;
+}
+
+int launch_is_background(int dtype, const void *labels, uint8_t *mask, int64_t count,
+                         hipStream_t stream) {
+  if (count <= 0) return EDT_OK;
+  const int threads = 256;
+  int64_t blocks = ceil_div(count, threads);
+  if (blocks > 8192) blocks = 8192;
+#define LAUNCH_BG(T)                                                                          \
+  hipLaunchKernelGGL(k_is_background<T>, dim3((unsigned)blocks), dim3(threads), 0, stream,    \
+                     (const T *)labels, mask, count)
+  switch (dtype) {
+    case EDT_U8: case EDT_BOOL: LAUNCH_BG(uint8_t); break;
+    case EDT_U16: LAUNCH_BG(uint16_t); break;
+    case EDT_U32: LAUNCH_BG(uint32_t); break;
+    case EDT_U64: LAUNCH_BG(uint64_t); break;
+    case EDT_F32: LAUNCH_BG(float); break;
+    case EDT_F64: LAUNCH_BG(double); break;
+    default: set_error("unknown dtype"); return EDT_ERR_BAD_ARG;
+  }
+#undef LAUNCH_BG
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+}  // namespace edt_amd

@@ -1,0 +1,60 @@
+// edt_kernels.h -- device helpers shared by the kernels + launcher declarations (internal).
+#pragma once
+
+#include "edt_common.h"
+
+#pragma clang fp contract(off)
+
+namespace edt_amd {
+
+// (double)d squared, exact for |d| < 2^26  (reference: pyedt::sq, src/edt.hpp:34-37)
+__device__ __forceinline__ double sqd(int64_t d) {
+  const double x = (double)d;
+  return x * x;
+}
+
+// Numerator of the abscissa where parabola q (height Fq) overtakes parabola p < q:
+//   s(p,q) = hull_num / (2 * (q - p) * w2)
+// Same operation order as the reference's `ff[i] - ff[v[k]] + factor1 * factor2`
+// (src/edt.hpp:206-208).  Comparing s(b,i) <= s(a,b) is done by cross-multiplication,
+// which needs no division:   hull_num(b,i) * (b-a)  <=  hull_num(a,b) * (i-b).
+__device__ __forceinline__ double hull_num(double Fp, double Fq, int64_t p, int64_t q, double w2) {
+  const double f1 = (double)(q - p) * w2;
+  const double f2 = (double)(q + p);
+  return (Fq - Fp) + f1 * f2;
+}
+
+// Last-pass epilogue: FLT_MAX sentinel back to +INF (toinfinite, src/edt.hpp:47-53) and the
+// optional correctly rounded sqrt (src/edt.hpp:599-601 / np.sqrt at src/edt.pyx:242).
+__device__ __forceinline__ float finish(float m, int epi) {
+  if ((epi & kEpiToInf) && m >= FLT_MAX) m = INFINITY;
+  if (epi & kEpiSqrt) m = sqrtf(m);
+  return m;
+}
+
+// ---- generic (any extent) kernels: edt_generic.hip ------------------------------------
+int launch_row_pass_serial(int dtype, const void *labels, float *out, int64_t sx, int64_t nrows,
+                           float w, int bb, int to_finite, int take_sqrt, hipStream_t stream);
+int launch_axis_bits(int dtype, const void *labels, const void *halo, uint32_t *nz, uint32_t *rs,
+                     const AxisGeom &g, hipStream_t stream);
+int launch_column_pass_serial(const float *fin, float *fout, const uint32_t *nz, const uint32_t *rs,
+                              int32_t *stack, const AxisGeom &g, float w, int bb, int epi,
+                              hipStream_t stream);
+int launch_subtract(const float *a, const float *b, float *out, int64_t count, hipStream_t stream);
+int launch_is_background(int dtype, const void *labels, uint8_t *mask, int64_t count,
+                         hipStream_t stream);
+
+}  // namespace edt_amd
+
+namespace edt_amd {
+// ---- voxel-graph helpers: edt_voxel_graph.hip -----------------------------------------
+int launch_vg_expand(int dtype, const void *labels, const uint8_t *graph, uint8_t *big, int64_t sx,
+                     int64_t sy, int64_t sz, int ndim, int bb, hipStream_t stream);
+int launch_vg_gather(const float *big, float *out, int64_t sx, int64_t sy, int64_t sz, int ndim,
+                     hipStream_t stream);
+// ---- Z-sharded helpers: edt_shard.hip ---------------------------------------------------
+int launch_zflags(int dtype, const void *labels, const void *halo, uint8_t *flags, int64_t sxy,
+                  int64_t szl, hipStream_t stream);
+int launch_bits_from_flags(const uint8_t *flags, uint32_t *nz, uint32_t *rs, const AxisGeom &g,
+                           hipStream_t stream);
+}  // namespace edt_amd

@@ -1,0 +1,117 @@
+"""ctypes binding of the C ABI declared in include/edt_hip.h.
+
+The shared library is built in-tree by ``euclidean-distance-transform-3d_amd/csrc/Makefile``
+(``python __graft_entry__.py`` does it).  There is deliberately no fallback: if the library
+is missing, or there is no HIP device, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libedt_hip.so")
+
+# dtype codes of include/edt_hip.h
+U8, U16, U32, U64, F32, F64, BOOL = range(7)
+
+FLAG_BLACK_BORDER = 1
+FLAG_SQRT = 2
+FLAG_FORCE_GENERIC = 4
+
+OK = 0
+ERR_NO_DEVICE = -1
+
+
+class EdtHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"edt_hip error {code}: {message}")
+        self.code = code
+
+
+_vp, _i, _i64, _f, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                          ctypes.c_size_t)
+
+# name -> (restype, argtypes); one entry per symbol declared in include/edt_hip.h
+SIGNATURES = {
+    "edt_hip_device_count": (_i, []),
+    "edt_hip_last_error": (ctypes.c_char_p, []),
+    "edt_hip_version": (ctypes.c_char_p, []),
+    "edt_hip_squared_edt_1d_multi_seg": (_i, [_vp, _i, _vp, _i64, _i64, _f, _i]),
+    "edt_hip_edt2dsq": (_i, [_vp, _i, _i64, _i64, _f, _f, _i, _i, _vp]),
+    "edt_hip_edt3dsq": (_i, [_vp, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp]),
+    "edt_hip_edt2d": (_i, [_vp, _i, _i64, _i64, _f, _f, _i, _i, _vp]),
+    "edt_hip_edt3d": (_i, [_vp, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp]),
+    "edt_hip_edt2dsq_voxel_graph": (_i, [_vp, _i, _vp, _i64, _i64, _f, _f, _i, _vp]),
+    "edt_hip_edt3dsq_voxel_graph": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _f, _f, _f, _i, _vp]),
+    "edt_hip_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i64]),
+    "edt_hip_edtsq_device": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _vp, _vp, _sz, _vp]),
+    "edt_hip_set_profiling": (_i, [_i]),
+    "edt_hip_get_pass_times": (_i, [_vp, _i]),
+    "edt_hip_get_pass_name": (ctypes.c_char_p, [_i]),
+    "edt_hip_shard_workspace_bytes": (_sz, [_i, _i64, _i64, _i64]),
+    "edt_hip_shard_xy_device": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _f, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    "edt_hip_shard_z_device": (_i, [_vp, _vp, _i64, _i64, _i64, _f, _i, _vp, _sz, _vp]),
+    "edt_hip_subtract_device": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "edt_hip_is_background_device": (_i, [_vp, _i, _vp, _i64, _vp]),
+}
+
+_lib = None
+
+
+def _preload_hip_runtime() -> None:
+    """Make this library and PyTorch-ROCm share ONE HIP runtime, whatever the import order.
+
+    The torch wheel bundles its own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``) and asks
+    for it by the unversioned file name; libedt_hip.so asks for the SONAME.  If torch is imported
+    first the loader resolves our request to torch's copy.  If WE are loaded first the system
+    runtime comes in, torch later loads its own copy next to it, and the two runtimes do not see
+    each other's devices, streams or allocations.  Loading torch's copy (when torch is installed;
+    torch itself is not imported) before our library removes the order dependence.
+    """
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libedt_hip.so once and attach the prototypes.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. "
+            "Run `python __graft_entry__.py` (or `make -C euclidean-distance-transform-3d_amd/csrc`). "
+            "There is no CPU fallback.")
+    _preload_hip_runtime()
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        msg = load().edt_hip_last_error()
+        raise EdtHipError(rc, msg.decode() if msg else "")
+
+
+def device_count() -> int:
+    return int(load().edt_hip_device_count())

@@ -1,0 +1,140 @@
+"""Device-resident entry points: torch tensors on an AMD GPU in, torch tensors out.
+
+torch is used only as plumbing (device memory, streams); all arithmetic happens in the HIP
+kernels behind ``edt_hip_edtsq_device`` (include/edt_hip.h).  Nothing is copied to the host
+and nothing is allocated per call once a :class:`Plan` exists, so a call only enqueues
+kernels on the current stream (graph-capturable, timeable with events).
+
+Tensor layout: a contiguous tensor of shape ``(a, b, c)`` has its LAST dimension fastest, so
+it is the same computation as a C-ordered numpy array: extents and anisotropy are reversed
+before they reach the kernels (reference: src/edt.pyx:651-656).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TORCH_CODE = {
+    torch.uint8: _lib.U8, torch.int8: _lib.U8,
+    torch.int16: _lib.U16, torch.int32: _lib.U32, torch.int64: _lib.U64,
+    torch.float32: _lib.F32, torch.float64: _lib.F64, torch.bool: _lib.BOOL,
+}
+for _name, _code in (("uint16", _lib.U16), ("uint32", _lib.U32), ("uint64", _lib.U64)):
+    if hasattr(torch, _name):
+        _TORCH_CODE[getattr(torch, _name)] = _code
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _TORCH_CODE[dtype]
+    except KeyError:
+        raise TypeError(f"Unsupported label dtype {dtype}") from None
+
+
+def _stream_ptr() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Plan:
+    """Pre-sized scratch for volumes of one shape/dtype (x-fastest extents ``(sx, sy, sz)``)."""
+
+    def __init__(self, extents_xyz, code: int, device=None):
+        self.lib = _lib.load()
+        ext = tuple(int(e) for e in extents_xyz)
+        self.ndim = len(ext)
+        self.ext = ext + (1,) * (3 - self.ndim)
+        self.code = code
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        nbytes = self.lib.edt_hip_workspace_bytes(code, self.ndim, *self.ext)
+        if nbytes == 0:
+            _lib.check(-2)
+        self.workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self.voxels = int(np.prod(self.ext))
+
+    def run(self, labels: torch.Tensor, weights_xyz, black_border=False, sqrt=False,
+            out: torch.Tensor | None = None, force_generic=False) -> torch.Tensor:
+        """Enqueue the transform of ``labels`` (device, contiguous, ``voxels`` elements)."""
+        if not labels.is_cuda or not labels.is_contiguous():
+            raise ValueError("labels must be a contiguous device tensor")
+        if labels.numel() != self.voxels:
+            raise ValueError("labels size does not match the plan")
+        if out is None:
+            out = torch.empty(labels.shape, dtype=torch.float32, device=labels.device)
+        w = tuple(float(np.float32(v)) for v in weights_xyz) + (1.0,) * (3 - self.ndim)
+        flags = ((_lib.FLAG_BLACK_BORDER if black_border else 0) | (_lib.FLAG_SQRT if sqrt else 0)
+                 | (_lib.FLAG_FORCE_GENERIC if force_generic else 0))
+        rc = self.lib.edt_hip_edtsq_device(
+            ctypes.c_void_p(labels.data_ptr()), self.code, self.ndim, *self.ext, w[0], w[1], w[2],
+            flags, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()),
+            self.workspace.numel(), _stream_ptr())
+        _lib.check(rc)
+        return out
+
+
+_plans: dict = {}
+
+
+def _plan_for(ext, code, device) -> Plan:
+    key = (tuple(ext), code, str(device))
+    if key not in _plans:
+        if len(_plans) > 8:
+            _plans.clear()
+        _plans[key] = Plan(ext, code, device)
+    return _plans[key]
+
+
+def _transform(labels: torch.Tensor, anisotropy, black_border, sqrt, force_generic=False):
+    if labels.numel() == 0:
+        return torch.zeros(labels.shape, dtype=torch.float32, device=labels.device)
+    if labels.dim() < 1 or labels.dim() > 3:
+        raise TypeError(
+            "Multi-Label EDT library only supports up to 3 dimensions got {}.".format(labels.dim()))
+    labels = labels.contiguous()
+    nd = labels.dim()
+    an = (1.0,) * nd if anisotropy is None else (
+        (float(anisotropy),) if np.ndim(anisotropy) == 0 else tuple(float(a) for a in anisotropy))
+    ext = tuple(labels.shape[::-1])
+    w = an[::-1]
+    plan = _plan_for(ext, dtype_code(labels.dtype), labels.device)
+    return plan.run(labels, w, black_border, sqrt, force_generic=force_generic)
+
+
+def edtsq(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
+    """Squared EDT of a device tensor (same semantics as :func:`edt.edtsq` on a C-ordered array)."""
+    return _transform(labels, anisotropy, black_border, sqrt=False)
+
+
+def edt(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
+    return _transform(labels, anisotropy, black_border, sqrt=True)
+
+
+def sdf(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
+    """``edt(x) - edt(x == 0)`` without leaving the device (reference: src/edt.pyx:148-158)."""
+    lib = _lib.load()
+    labels = labels.contiguous()
+    dt = _transform(labels, anisotropy, black_border, sqrt=True)
+    mask = torch.empty(labels.shape, dtype=torch.bool, device=labels.device)
+    _lib.check(lib.edt_hip_is_background_device(
+        ctypes.c_void_p(labels.data_ptr()), dtype_code(labels.dtype),
+        ctypes.c_void_p(mask.data_ptr()), labels.numel(), _stream_ptr()))
+    bg = _transform(mask, anisotropy, black_border, sqrt=True)
+    _lib.check(lib.edt_hip_subtract_device(
+        ctypes.c_void_p(dt.data_ptr()), ctypes.c_void_p(bg.data_ptr()),
+        ctypes.c_void_p(dt.data_ptr()), dt.numel(), _stream_ptr()))
+    return dt
+
+
+def pass_times():
+    """Durations (ms) of the kernels of the last profiled call, as ``[(name, ms), ...]``."""
+    lib = _lib.load()
+    buf = (ctypes.c_float * 16)()
+    n = lib.edt_hip_get_pass_times(ctypes.cast(buf, ctypes.c_void_p), 16)
+    return [(lib.edt_hip_get_pass_name(i).decode(), float(buf[i])) for i in range(min(n, 16))]
+
+
+def set_profiling(enabled: bool) -> None:
+    _lib.check(_lib.load().edt_hip_set_profiling(1 if enabled else 0))

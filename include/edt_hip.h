@@ -1,0 +1,155 @@
+/* include/edt_hip.h -- C ABI of the MI355X-native multi-label anisotropic EDT.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  The entry
+ * points below are exactly what the reference's FFI for this path binds
+ * (`cdef extern from "edt.hpp" namespace "pyedt"`, /root/reference/src/edt.pyx:62-113),
+ * with the template parameter T replaced by a run-time `dtype` code.  INTEGRATION.md shows
+ * the reference-side stubs (Cython / C++ header) a maintainer would add.
+ *
+ * Conventions (identical to the reference, src/edt.hpp:411-484):
+ *   - x is the fastest axis: idx = x + sx * (y + sy * z);
+ *   - label 0 is background; any change of label is a boundary;
+ *   - wx, wy, wz are the physical voxel sizes (anisotropy) as fp32;
+ *   - black_border != 0 treats the outside of the volume as background;
+ *   - output is fp32, squared distances unless the entry point says otherwise;
+ *     with black_border == 0 voxels that see no boundary are +INF.
+ *   - `parallel` is accepted for signature compatibility and ignored (the GPU grid
+ *     replaces the reference's ThreadPool, src/threadpool.h:46-140).
+ *
+ * Every function returns EDT_OK (0) or a negative error code and never throws;
+ * edt_hip_last_error() describes the last failure on the calling thread.  There is NO
+ * CPU fallback inside this library: without a usable gfx950 device every compute entry
+ * point fails with EDT_ERR_NO_DEVICE.
+ */
+#ifndef EDT_HIP_H
+#define EDT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* label element types (the seven instantiations of src/edt.pyx:670-732) */
+enum {
+  EDT_U8 = 0,
+  EDT_U16 = 1,
+  EDT_U32 = 2,
+  EDT_U64 = 3,
+  EDT_F32 = 4,
+  EDT_F64 = 5,
+  EDT_BOOL = 6 /* one byte per voxel, any non-zero byte is foreground */
+};
+
+enum {
+  EDT_OK = 0,
+  EDT_ERR_NO_DEVICE = -1,
+  EDT_ERR_BAD_ARG = -2,
+  EDT_ERR_HIP = -3,
+  EDT_ERR_UNSUPPORTED = -4,
+  EDT_ERR_NOMEM = -5
+};
+
+/* flags for the device-resident entry points */
+enum {
+  EDT_FLAG_BLACK_BORDER = 1, /* treat the outside of the volume as background          */
+  EDT_FLAG_SQRT = 2,         /* return distances instead of squared distances          */
+  EDT_FLAG_FORCE_GENERIC = 4 /* use the size-agnostic fallback kernels (test hook)      */
+};
+
+/* ---- introspection -------------------------------------------------------------- */
+int edt_hip_device_count(void);         /* number of visible HIP devices (0 if none)  */
+const char *edt_hip_last_error(void);   /* thread-local, never NULL                   */
+const char *edt_hip_version(void);
+
+/* ---- host-buffer entry points (numpy in / numpy out) ------------------------------
+ * Pointers are HOST pointers; the call stages through device memory (H2D, kernels, D2H)
+ * and is synchronous.  `output` must hold one float per voxel and is fully overwritten.
+ */
+
+/* replaces pyedt::squared_edt_1d_multi_seg<T>  (src/edt.hpp:70-119; bound at
+ * src/edt.pyx:63-70).  stride must be 1 (every reference caller passes 1). */
+int edt_hip_squared_edt_1d_multi_seg(const void *labels, int dtype, float *dest, int64_t n,
+                                     int64_t stride, float anisotropy, int black_border);
+
+/* replaces pyedt::_edt2dsq<T>  (src/edt.hpp:632-678, bool: :758-772; bound at
+ * src/edt.pyx:72-78) */
+int edt_hip_edt2dsq(const void *labels, int dtype, int64_t sx, int64_t sy, float wx, float wy,
+                    int black_border, int parallel, float *output);
+
+/* replaces pyedt::_edt3dsq<T>  (src/edt.hpp:411-484, bool: :580-587; bound at
+ * src/edt.pyx:80-86) -- THE hot path. */
+int edt_hip_edt3dsq(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx,
+                    float wy, float wz, int black_border, int parallel, float *output);
+
+/* replace pyedt::_edt2d<T> / _edt3d<T>  (src/edt.hpp:776-797, :591-604): the same plus a
+ * correctly rounded sqrt fused into the last pass. */
+int edt_hip_edt2d(const void *labels, int dtype, int64_t sx, int64_t sy, float wx, float wy,
+                  int black_border, int parallel, float *output);
+int edt_hip_edt3d(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx,
+                  float wy, float wz, int black_border, int parallel, float *output);
+
+/* replace pyedt::_edt2dsq_voxel_graph<T,uint8_t> / _edt3dsq_voxel_graph<T,uint8_t>
+ * (src/edt_voxel_graph.hpp:54-117, :120-214; bound at src/edt.pyx:89-100).  `graph` holds
+ * one byte per voxel; only bits 0x01 (+x), 0x04 (+y), 0x10 (+z) are read. */
+int edt_hip_edt2dsq_voxel_graph(const void *labels, int dtype, const uint8_t *graph, int64_t sx,
+                                int64_t sy, float wx, float wy, int black_border,
+                                float *workspace);
+int edt_hip_edt3dsq_voxel_graph(const void *labels, int dtype, const uint8_t *graph, int64_t sx,
+                                int64_t sy, int64_t sz, float wx, float wy, float wz,
+                                int black_border, float *workspace);
+
+/* ---- device-resident entry points --------------------------------------------------
+ * All pointers are DEVICE pointers on the current HIP device; `stream` is a hipStream_t
+ * (NULL = the null stream).  Calls only enqueue work (no host synchronisation, no
+ * allocation), so they can be timed with events and captured into a hipGraph.
+ */
+
+/* bytes of scratch edt_hip_edtsq_device needs for a volume of this shape */
+size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz);
+
+/* ndim in {1,2,3}; unused extents must be 1.  flags: EDT_FLAG_*.  d_output may not alias
+ * d_labels.  Implements _edt3dsq / _edt2dsq / squared_edt_1d_multi_seg (+ optional sqrt). */
+int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy,
+                         int64_t sz, float wx, float wy, float wz, int flags, float *d_output,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Per-pass timing hook for bench.py: when enabled, edt_hip_edtsq_device brackets every
+ * kernel it launches with hipEvents on `stream`.  After synchronising the stream,
+ * edt_hip_get_pass_times copies the durations (ms) of the last call, in launch order,
+ * into `ms` and returns how many there were (names via edt_hip_get_pass_name). */
+int edt_hip_set_profiling(int enabled);
+int edt_hip_get_pass_times(float *ms, int capacity);
+const char *edt_hip_get_pass_name(int index);
+
+/* ---- Z-sharded (multi-GPU) building blocks ------------------------------------------
+ * One process per GPU holds a contiguous Z-slab.  Phase 1 runs the X and Y passes on the
+ * slab (no data dependence across z) and emits, per voxel, the fp32 partial result plus
+ * one flag byte (bit0 = foreground, bit1 = label differs from the voxel below in z).
+ * The host layer then re-partitions both arrays from Z-slabs to Y-slabs with ONE
+ * all-to-all (RCCL over xGMI) and phase 2 runs the Z pass on whole z-columns.
+ *   d_halo: the last xy-slice of the previous rank's labels (NULL on the first rank) --
+ *           the one-slab halo that decides run continuity across the cut.
+ */
+size_t edt_hip_shard_workspace_bytes(int dtype, int64_t sx, int64_t sy, int64_t sz);
+int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype, int64_t sx,
+                            int64_t sy, int64_t sz_local, float wx, float wy, int flags,
+                            float *d_partial, uint8_t *d_zflags, void *d_workspace,
+                            size_t workspace_bytes, void *stream);
+int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx,
+                           int64_t sy_local, int64_t sz, float wz, int flags,
+                           void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- fused helpers on device-resident data ------------------------------------------ */
+/* out[i] = a[i] - b[i]  (src/edt.pyx:156-158, sdf = edt(x) - edt(x == 0)) */
+int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, int64_t count,
+                            void *stream);
+/* mask[i] = (labels[i] == 0) as one byte per voxel (the `data == 0` of src/edt.pyx:157) */
+int edt_hip_is_background_device(const void *d_labels, int dtype, uint8_t *d_mask, int64_t count,
+                                 void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDT_HIP_H */

@@ -1,0 +1,100 @@
+"""Seeded synthetic label volumes for tests, golden fixtures and bench.py.
+
+All generators return arrays whose shape is (sx, sy, sz) in Fortran order when asked for
+`order="F"`, i.e. x is the fastest axis, matching the reference's native layout
+(reference: src/edt.hpp:434, src/edt.pyx:659-664).  Only numpy is used so that the same
+inputs can be rebuilt on the GPU box.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def blocky_labels(shape, nlabels=5, zero_frac=0.2, block=4, rng=None):
+    """Piecewise-constant random labels in 1..nlabels with a fraction of background blocks."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    small = tuple(max(1, -(-s // block)) for s in shape)
+    a = rng.integers(1, nlabels + 1, size=small)
+    a[rng.random(small) < zero_frac] = 0
+    for ax in range(len(shape)):
+        a = a.repeat(block, axis=ax)
+    return np.ascontiguousarray(a[tuple(slice(0, s) for s in shape)])
+
+
+def blob_mask(shape, rng=None, p=0.6, block=4):
+    """Binary blobs: a coarse random field up-sampled by `block`."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    small = tuple(max(1, -(-s // block)) for s in shape)
+    a = (rng.random(small) < p).astype(np.uint8)
+    for ax in range(len(shape)):
+        a = a.repeat(block, axis=ax)
+    return np.ascontiguousarray(a[tuple(slice(0, s) for s in shape)])
+
+
+def voronoi_labels(shape, nseeds, seed=0, upsample=4, membrane=0.0, dtype=np.uint32):
+    """SNEMI3D-like dense segmentation: nearest-seed labels on a coarse grid, up-sampled.
+
+    Brute-force nearest seed in chunks (no scipy dependency); `membrane` > 0 zeroes that
+    fraction of coarse cells to create thin background sheets between segments.
+    """
+    rng = np.random.default_rng(seed)
+    small = tuple(max(1, -(-s // upsample)) for s in shape)
+    pts = rng.random((nseeds, len(shape))) * np.array(small)
+    grids = np.meshgrid(*[np.arange(s) + 0.5 for s in small], indexing="ij")
+    g = np.stack(grids, -1).reshape(-1, len(shape))
+    idx = np.empty(len(g), dtype=np.int64)
+    # order seeds once so that chunks can prune by a KD-free brute force in float32
+    pts32 = pts.astype(np.float32)
+    chunk = max(1, (1 << 24) // max(1, nseeds))
+    for s in range(0, len(g), chunk):
+        d = ((g[s:s + chunk, None, :].astype(np.float32) - pts32[None, :, :]) ** 2).sum(-1)
+        idx[s:s + chunk] = d.argmin(1)
+    lab = (idx + 1).reshape(small)
+    if membrane > 0:
+        lab[rng.random(small) < membrane] = 0
+    for ax in range(len(shape)):
+        lab = lab.repeat(upsample, axis=ax)
+    lab = lab[tuple(slice(0, s) for s in shape)]
+    return np.asfortranarray(lab.astype(dtype))
+
+
+def config_volume(name: str, n: int = 512):
+    """The BASELINE.json configurations at edge length `n` (Fortran order, x fastest).
+
+    Returns (labels, anisotropy, black_border).
+      cfg1: all-ones uint32, (1,1,1), black_border=True
+      cfg2: all-ones uint32 single label, (6,6,30), black_border=True      <- headline metric
+      cfg3: ~2000 (scaled with volume) random multi-labels, black_border=False
+      cfg5: uint8 binary blobs, black_border=True
+    """
+    if name == "cfg1":
+        return np.ones((n, n, n), dtype=np.uint32, order="F"), (1.0, 1.0, 1.0), True
+    if name == "cfg2":
+        return np.ones((n, n, n), dtype=np.uint32, order="F"), (6.0, 6.0, 30.0), True
+    if name == "cfg3":
+        nseeds = max(8, int(round(2000 * (n / 512.0) ** 3)))
+        return voronoi_labels((n, n, n), nseeds, seed=0, upsample=4), (1.0, 1.0, 1.0), False
+    if name == "cfg3m":  # same with thin zero membranes
+        nseeds = max(8, int(round(2000 * (n / 512.0) ** 3)))
+        return voronoi_labels((n, n, n), nseeds, seed=0, upsample=4, membrane=0.05), (6.0, 6.0, 30.0), False
+    if name == "cfg5":
+        rng = np.random.default_rng(5)
+        up = 16 if n >= 64 else 4
+        m = blob_mask((n, n, n), rng=rng, p=0.6, block=up)
+        return np.asfortranarray(m.astype(np.uint8)), (1.0, 1.0, 1.0), True
+    raise KeyError(name)
+
+
+def box_edtsq_closed_form(shape, anisotropy):
+    """Exact squared EDT of an all-foreground box with black border (integer anisotropy):
+    the nearest background voxel lies straight across the nearest face."""
+    out = None
+    for ax, (s, w) in enumerate(zip(shape, anisotropy)):
+        i = np.arange(s, dtype=np.int64)
+        d = np.minimum(i + 1, s - i).astype(np.float64) * float(w)
+        d2 = (d * d).astype(np.float32)
+        shp = [1] * len(shape)
+        shp[ax] = s
+        d2 = d2.reshape(shp)
+        out = d2 if out is None else np.minimum(out, d2)
+    return np.asfortranarray(np.broadcast_to(out, shape))

@@ -1,0 +1,91 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds/loads, exports every
+symbol include/edt_hip.h declares, validates arguments, and fails LOUDLY (no CPU fallback)
+when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "edt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(edt_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from edt import _lib
+    return _lib.load()
+
+
+def test_header_symbols_are_all_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/edt_hip.h but not exported"
+
+
+def test_python_binding_covers_the_header():
+    from edt import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_version_and_error_strings(lib):
+    assert b"gfx950" in lib.edt_hip_version()
+    assert isinstance(lib.edt_hip_last_error(), bytes)
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    from edt import _lib
+    # unknown dtype, bad ndim, unused extent != 1
+    assert lib.edt_hip_workspace_bytes(99, 3, 4, 4, 4) == 0
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 4, 4, 4, 4) == 0
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 2, 4, 4, 4) == 0
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 64, 64, 64) >= 64 * 64 * 64 * 4
+    buf = np.zeros(8, dtype=np.uint32)
+    out = np.zeros(8, dtype=np.float32)
+    rc = lib.edt_hip_squared_edt_1d_multi_seg(buf.ctypes.data, _lib.U32, out.ctypes.data, 8, 2, 1.0, 0)
+    assert rc == -4  # EDT_ERR_UNSUPPORTED: stride != 1
+    assert b"stride" in lib.edt_hip_last_error()
+
+
+def test_empty_and_bad_shapes_python_level():
+    import edt
+    assert edt.edtsq(np.zeros((0,), dtype=np.uint8)).shape == (0,)
+    assert edt.edt(np.zeros((4, 0, 3), dtype=np.uint32)).shape == (4, 0, 3)
+    with pytest.raises(TypeError):
+        edt.edtsq(np.zeros((2, 2, 2, 2), dtype=np.uint8))
+    with pytest.raises(TypeError):
+        edt.edtsq(np.zeros((5,), dtype=np.uint8), voxel_graph=np.zeros((5,), dtype=np.uint8))
+    with pytest.raises(TypeError):
+        edt.edtsq(np.zeros((5,), dtype=np.complex64))
+
+
+def test_no_silent_cpu_fallback(lib):
+    """Without a device every compute entry point must return EDT_ERR_NO_DEVICE."""
+    from edt import _lib
+    import edt
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present; the no-device path is exercised on the CPU runner")
+    lab = np.ones((4, 4, 4), dtype=np.uint32)
+    with pytest.raises(_lib.EdtHipError) as e:
+        edt.edtsq(lab)
+    assert e.value.code == _lib.ERR_NO_DEVICE
+    with pytest.raises(_lib.EdtHipError):
+        edt.sdf(lab)
+
+
+def test_product_never_imports_the_oracle():
+    """The shipped package must not import, link, load or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "euclidean-distance-transform-3d_amd")
+    banned = re.compile(r"import\s+oracle|from\s+oracle|oracle/|libedt_oracle|libedt_ref|edt_oracle\.c|harness")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not banned.search(text), f"{os.path.join(dirpath, f)} references the oracle"

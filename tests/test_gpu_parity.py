@@ -1,0 +1,205 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI
+via the drop-in Python module, against the CPU oracle on the same seeded inputs.
+
+Bar: squared distances bit-identical (`np.array_equal`); `edt` (with the fused correctly
+rounded sqrt) bit-identical as well, i.e. 0 ULP (the north-star allows 1 ULP)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from synth import blocky_labels, blob_mask, box_edtsq_closed_form, config_volume, voronoi_labels
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int32, np.int64, np.float32,
+          np.float64, bool]
+ANISO = [(1, 1, 1), (6, 6, 30), (4, 4, 40), (0.5, 0.7, 1.3), (3, 1, 2), (1e-3, 2.5, 7)]
+
+
+def same(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True)
+
+
+def explain(got, want):
+    bad = np.argwhere(~((got == want) | (np.isnan(got) & np.isnan(want))))
+    if len(bad) == 0:
+        return "shape/dtype mismatch"
+    i = tuple(bad[0])
+    return f"{len(bad)} mismatches; first at {i}: got {got[i]!r} want {want[i]!r}"
+
+
+# ---- golden vectors recorded from the reference ---------------------------------------------
+def test_golden_random(edt_gpu):
+    for n, c in enumerate(load_golden("edt_random.npz")):
+        lab = c["labels"]
+        lab = np.asfortranarray(lab) if str(c["order"]) == "F" else np.ascontiguousarray(lab)
+        an = tuple(c["anisotropy"])
+        an = an[0] if lab.ndim == 1 else an
+        bb = bool(c["black_border"])
+        got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+        assert same(got, c["edtsq"]), (n, lab.shape, lab.dtype, explain(got, c["edtsq"]))
+        got = edt_gpu.edt(lab, anisotropy=an, black_border=bb)
+        assert same(got, c["edt"]), (n, lab.shape, lab.dtype, explain(got, c["edt"]))
+
+
+def test_golden_configs(edt_gpu):
+    for c in load_golden("edt_configs.npz"):
+        lab = np.asfortranarray(c["labels"])
+        got = edt_gpu.edtsq(lab, anisotropy=tuple(c["anisotropy"]), black_border=bool(c["black_border"]))
+        assert same(got, c["edtsq"]), explain(got, c["edtsq"])
+
+
+def test_golden_sdf_voxel_graph(edt_gpu):
+    for c in load_golden("edt_sdf_voxel_graph.npz"):
+        lab, an, bb = c["labels"], tuple(c["anisotropy"]), bool(c["black_border"])
+        if str(c["kind"]) == "sdf":
+            got = edt_gpu.sdf(lab, anisotropy=an, black_border=bb)
+        else:
+            got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb, voxel_graph=c["graph"])
+        assert same(got, c["out"]), explain(got, c["out"])
+
+
+# ---- randomized parity against the oracle -----------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_random_small_vs_oracle(edt_gpu, oracle_port, seed):
+    rng = np.random.default_rng(100 + seed)
+    for t in range(40):
+        dims = int(rng.integers(1, 4))
+        shape = tuple(int(rng.integers(1, 70)) for _ in range(dims))
+        dtype = DTYPES[int(rng.integers(0, len(DTYPES)))]
+        lab = blocky_labels(shape, nlabels=int(rng.integers(1, 9)), zero_frac=float(rng.random() * 0.5),
+                            block=int(rng.integers(1, 9)), rng=rng).astype(dtype)
+        if rng.random() < 0.5:
+            lab = np.asfortranarray(lab)
+        an = ANISO[int(rng.integers(0, len(ANISO)))][:dims]
+        an = an[0] if dims == 1 else an
+        bb = bool(rng.integers(0, 2))
+        want = oracle_port.edtsq(lab, an, bb)
+        got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+        assert same(got, want), (seed, t, shape, dtype, an, bb, explain(got, want))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 1, 3), (1, 70, 1), (65, 33, 31), (64, 64, 64),
+                                   (96, 80, 72), (130, 67, 35), (257, 5, 3), (3, 300, 2), (2, 3, 513)])
+@pytest.mark.parametrize("bb", [False, True])
+def test_odd_extents(edt_gpu, oracle_port, shape, bb):
+    rng = np.random.default_rng(hash(shape) % 1000)
+    lab = np.asfortranarray(blocky_labels(shape, 6, 0.15, 5, rng).astype(np.uint32))
+    for an in ((1, 1, 1), (6, 6, 30)):
+        want = oracle_port.edtsq(lab, an, bb)
+        got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+        assert same(got, want), (shape, an, explain(got, want))
+    want = oracle_port.edt(lab, (4, 4, 40), bb)
+    got = edt_gpu.edt(lab, anisotropy=(4, 4, 40), black_border=bb)
+    assert same(got, want), explain(got, want)  # 0 ULP
+
+
+def test_long_axes_take_the_generic_path(edt_gpu, oracle_port):
+    # rows / columns far longer than any LDS tile (cf. automated_test.py:819-823)
+    rng = np.random.default_rng(5)
+    for shape in ((5000, 3), (3, 5000), (46342, 1), (1, 46342)):
+        lab = blocky_labels(shape, 4, 0.1, 37, rng).astype(np.float64)
+        for bb in (False, True):
+            want = oracle_port.edtsq(lab, (1.0, 2.0), bb)
+            got = edt_gpu.edtsq(lab, anisotropy=(1.0, 2.0), black_border=bb)
+            assert same(got, want), (shape, bb, explain(got, want))
+            assert not np.any(np.isnan(got))
+
+
+def test_extreme_anisotropy(edt_gpu, oracle_port):
+    # automated_test.py:702-721, :791-817
+    rng = np.random.default_rng(6)
+    lab = blob_mask((40, 40, 40), rng=rng, p=0.7, block=5).astype(np.uint8)
+    for an in ((1e6, 1.2e6, 40.0), (1e-7, 1e-7, 1e-7), (1e8, 1e8, 1e8), (1e-5, 1.0, 1e5), (0.001, 0.001, 0.001)):
+        for bb in (False, True):
+            want = oracle_port.edtsq(lab, an, bb)
+            got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+            assert same(got, want), (an, bb, explain(got, want))
+
+
+def test_float_label_semantics(edt_gpu, oracle_port):
+    lab = np.array([[1.5, 1.5, -0.0, 2.0, np.nan, np.nan, 2.0, 2.0]] * 5, dtype=np.float32)
+    for bb in (False, True):
+        assert same(edt_gpu.edtsq(lab, black_border=bb), oracle_port.edtsq(lab, None, bb))
+    lab64 = lab.astype(np.float64)
+    assert same(edt_gpu.edtsq(lab64, black_border=True), oracle_port.edtsq(lab64, None, True))
+
+
+def test_bool_equals_uint8_path(edt_gpu, oracle_port):
+    rng = np.random.default_rng(7)
+    m = blob_mask((33, 47, 29), rng=rng, p=0.5, block=4)
+    for bb in (False, True):
+        a = edt_gpu.edtsq(m.astype(bool), anisotropy=(2, 3, 5), black_border=bb)
+        b = edt_gpu.edtsq(m.astype(np.uint8), anisotropy=(2, 3, 5), black_border=bb)
+        assert same(a, b)
+        assert same(a, oracle_port.edtsq(m.astype(bool), (2, 3, 5), bb))  # reference's binary route
+
+
+def test_input_not_mutated_and_noncontiguous(edt_gpu, oracle_port):
+    rng = np.random.default_rng(8)
+    lab = blocky_labels((30, 40, 20), 5, 0.2, 4, rng).astype(np.uint16)
+    keep = lab.copy()
+    view = lab[::2, 1::3, :]
+    got = edt_gpu.edtsq(view, anisotropy=(1, 2, 3))
+    assert np.array_equal(lab, keep)
+    assert same(got, oracle_port.edtsq(np.ascontiguousarray(view), (1, 2, 3), False))
+
+
+def test_sdf_and_each(edt_gpu, oracle_port):
+    rng = np.random.default_rng(9)
+    lab = blocky_labels((24, 28, 20), 4, 0.4, 4, rng).astype(np.uint32)
+    for bb in (False, True):
+        assert same(edt_gpu.sdf(lab, anisotropy=(1, 1, 2), black_border=bb),
+                    oracle_port.sdf(lab, (1, 1, 2), bb))
+        assert same(edt_gpu.sdfsq(lab, anisotropy=(1, 1, 2), black_border=bb),
+                    oracle_port.sdfsq(lab, (1, 1, 2), bb))
+    dt = edt_gpu.edt(lab)
+    seen = dict(edt_gpu.each(lab, dt))
+    assert sorted(seen) == [k for k in np.unique(lab) if k]
+    for k, img in seen.items():
+        assert np.array_equal(img, dt * (lab == k))
+
+
+def test_voxel_graph_3d(edt_gpu, oracle_port):
+    rng = np.random.default_rng(10)
+    m = blob_mask((20, 18, 22), rng=rng, p=0.8, block=3).astype(np.uint8)
+    g = np.full(m.shape, 0b00111111, dtype=np.uint8)
+    g[rng.random(m.shape) < 0.05] &= 0b11111110
+    g[rng.random(m.shape) < 0.05] &= 0b11111011
+    g[rng.random(m.shape) < 0.05] &= 0b11101111
+    for bb in (False, True):
+        for arr, gg in ((m, g), (np.asfortranarray(m), np.asfortranarray(g))):
+            got = edt_gpu.edtsq(arr, anisotropy=(2, 2, 3), black_border=bb, voxel_graph=gg)
+            want = oracle_port.edtsq(arr, (2, 2, 3), bb, voxel_graph=gg)
+            assert same(got, want), explain(got, want)
+
+
+# ---- BASELINE.json configurations at reduced size, bit-exact against the oracle ---------------
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg3m", "cfg5"])
+def test_baseline_configs_reduced(edt_gpu, oracle_port, cfg):
+    lab, an, bb = config_volume(cfg, 96)
+    want = oracle_port.edtsq(lab, an, bb)
+    got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+    assert same(got, want), explain(got, want)
+    if cfg == "cfg5":
+        assert same(edt_gpu.sdf(lab, anisotropy=an, black_border=bb), oracle_port.sdf(lab, an, bb))
+
+
+# ---- full BASELINE sizes: size-independent properties ---------------------------------------
+def test_cfg2_full_size_closed_form(edt_gpu):
+    lab, an, bb = config_volume("cfg2", 512)
+    got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+    assert got.max() == 2359296.0  # (6 * 256)^2, SURVEY 8(d)
+    assert same(got, box_edtsq_closed_form(lab.shape, an))
+
+
+def test_cfg3_full_size_vs_oracle_and_flip(edt_gpu, oracle_port):
+    lab, an, bb = config_volume("cfg3", 512)
+    got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+    assert len(np.unique(lab)) >= 1900
+    # mirror symmetry: the transform commutes with flipping every axis
+    flipped = np.asfortranarray(lab[::-1, ::-1, ::-1])
+    got_f = edt_gpu.edtsq(flipped, anisotropy=an, black_border=bb)
+    assert np.array_equal(got_f[::-1, ::-1, ::-1], got)
+    want = oracle_port.edtsq(lab, an, bb)  # ~10 s single thread
+    assert same(got, want), explain(got, want)

@@ -2,6 +2,7 @@
 // carving, host-buffer staging, per-pass event timing.  No compute happens on the host and
 // there is no CPU fallback: every entry point needs a HIP device.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -171,12 +172,17 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     return launch_row_pass_serial(dtype, d_labels, d_out, sx, 1, wx, bb, 0, want_sqrt, stream);
   }
 
-  // pass 1 (x) -> A ; bits ; pass 2 (y): A -> B ; pass 3 (z): B -> A.  A must end up == d_out.
-  float *bufA = (ndim == 3) ? d_out : p.bufB;
-  float *bufB = (ndim == 3) ? p.bufB : d_out;
+  // Column passes are in place when the LDS-tiled kernel applies, otherwise they ping-pong
+  // between two volumes.  Start in the buffer that makes the last pass land in d_out.
+  const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0;
+  const bool tiled_y = !force_generic && column_pass_tiled_supported(p.gy);
+  const bool tiled_z = !force_generic && column_pass_tiled_supported(p.gz);
+  const int swaps = (tiled_y ? 0 : 1) + ((ndim == 3 && !tiled_z) ? 1 : 0);
+  float *cur = (swaps % 2 == 0) ? d_out : p.bufB;
+  float *other = (cur == d_out) ? p.bufB : d_out;
   {
     ScopedPass t("x_pass", stream);
-    rc = launch_row_pass_serial(dtype, d_labels, bufA, sx, sy * sz, wx, bb, bb ? 0 : 1, 0, stream);
+    rc = launch_row_pass_serial(dtype, d_labels, cur, sx, sy * sz, wx, bb, bb ? 0 : 1, 0, stream);
     if (rc != EDT_OK) return rc;
   }
   {
@@ -186,8 +192,13 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   }
   {
     ScopedPass t("y_pass", stream);
-    rc = launch_column_pass_serial(bufA, bufB, p.nz_y, p.rs_y, p.stack, p.gy, wy, bb,
-                                   ndim == 2 ? last_epi : 0, stream);
+    const int epi = ndim == 2 ? last_epi : 0;
+    if (tiled_y) {
+      rc = launch_column_pass_tiled(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, stream);
+    } else {
+      rc = launch_column_pass_serial(cur, other, p.nz_y, p.rs_y, p.stack, p.gy, wy, bb, epi, stream);
+      std::swap(cur, other);
+    }
     if (rc != EDT_OK) return rc;
   }
   if (ndim == 3) {
@@ -197,10 +208,16 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
       if (rc != EDT_OK) return rc;
     }
     ScopedPass t("z_pass", stream);
-    rc = launch_column_pass_serial(bufB, bufA, p.nz_z, p.rs_z, p.stack, p.gz, wz, bb, last_epi,
-                                   stream);
+    if (tiled_z) {
+      rc = launch_column_pass_tiled(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream);
+    } else {
+      rc = launch_column_pass_serial(cur, other, p.nz_z, p.rs_z, p.stack, p.gz, wz, bb, last_epi,
+                                     stream);
+      std::swap(cur, other);
+    }
     if (rc != EDT_OK) return rc;
   }
+  if (cur != d_out) { set_error("internal: result buffer mismatch"); return EDT_ERR_HIP; }
   return EDT_OK;
 }
 
@@ -229,6 +246,10 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
   if (!labels || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
   rc = require_device();
   if (rc != EDT_OK) return rc;
+  // test hook: EDT_HIP_FORCE_GENERIC=1 routes host-buffer calls through the fallback kernels
+  if (const char *e = std::getenv("EDT_HIP_FORCE_GENERIC")) {
+    if (e[0] == '1') flags |= EDT_FLAG_FORCE_GENERIC;
+  }
 
   const size_t lbytes = (size_t)voxels * dtype_size(dtype);
   const size_t obytes = (size_t)voxels * sizeof(float);

@@ -57,4 +57,8 @@ int launch_zflags(int dtype, const void *labels, const void *halo, uint8_t *flag
                   int64_t szl, hipStream_t stream);
 int launch_bits_from_flags(const uint8_t *flags, uint32_t *nz, uint32_t *rs, const AxisGeom &g,
                            hipStream_t stream);
+// ---- LDS-tiled column pass: edt_tiled.hip ---------------------------------------------------
+bool column_pass_tiled_supported(const AxisGeom &g);
+int launch_column_pass_tiled(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                             float w, int bb, int epi, hipStream_t stream);
 }  // namespace edt_amd

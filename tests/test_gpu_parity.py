@@ -203,3 +203,42 @@ def test_cfg3_full_size_vs_oracle_and_flip(edt_gpu, oracle_port):
     assert np.array_equal(got_f[::-1, ::-1, ::-1], got)
     want = oracle_port.edtsq(lab, an, bb)  # ~10 s single thread
     assert same(got, want), explain(got, want)
+
+
+# ---- the two kernel families (LDS-tiled vs size-agnostic fallback) agree -----------------------
+@pytest.mark.parametrize("seed", range(3))
+def test_generic_path_matches_oracle(edt_gpu, oracle_port, seed, monkeypatch):
+    monkeypatch.setenv("EDT_HIP_FORCE_GENERIC", "1")
+    rng = np.random.default_rng(500 + seed)
+    for t in range(30):
+        dims = int(rng.integers(1, 4))
+        shape = tuple(int(rng.integers(1, 80)) for _ in range(dims))
+        lab = blocky_labels(shape, nlabels=int(rng.integers(1, 7)), zero_frac=float(rng.random() * 0.4),
+                            block=int(rng.integers(1, 9)), rng=rng).astype(DTYPES[t % len(DTYPES)])
+        an = ANISO[t % len(ANISO)][:dims]
+        an = an[0] if dims == 1 else an
+        bb = bool(t % 2)
+        want = oracle_port.edtsq(lab, an, bb)
+        got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+        assert same(got, want), (seed, t, shape, an, bb, explain(got, want))
+
+
+def test_long_runs_deep_hulls(edt_gpu, oracle_port):
+    """Wedges and cones: hulls hundreds of vertices deep and bridges far from the band seams."""
+    n = 200
+    x, y = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    shapes = {
+        "wedge": (x + 2 * y < 3 * n // 2),
+        "cone": ((x - n / 2) ** 2 + (y - n / 2) ** 2 < (n / 2.2) ** 2),
+        "comb": ((x % 7 != 0) | (y > n // 2)),
+        "stairs": ((x // 16) * 16 + 8 > y),
+    }
+    for name, m in shapes.items():
+        vol = np.repeat(m[:, :, None], 40, axis=2).astype(np.uint8)
+        if name in ("comb", "stairs"):
+            vol[:, :, ::13] = 0  # cut the z columns into short runs
+        for an in ((1, 1, 1), (3, 1, 2), (0.37, 1.9, 1.1)):
+            for bb in (False, True):
+                want = oracle_port.edtsq(vol, an, bb)
+                got = edt_gpu.edtsq(vol, anisotropy=an, black_border=bb)
+                assert same(got, want), (name, an, bb, explain(got, want))

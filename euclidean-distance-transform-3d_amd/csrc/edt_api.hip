@@ -83,7 +83,7 @@ struct Plan {
   // carved pointers
   float *bufB = nullptr;
   int32_t *stack = nullptr;
-  uint32_t *nz_y = nullptr, *rs_y = nullptr, *nz_z = nullptr, *rs_z = nullptr;
+  uint32_t *nz_y = nullptr, *rs_y = nullptr, *zs_y = nullptr, *nz_z = nullptr, *rs_z = nullptr;
   size_t bytes = 0;
 };
 
@@ -117,6 +117,7 @@ static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws) {
     const size_t wz = (size_t)(p.gz.sx * p.gz.nbands * p.gz.nouter);
     p.nz_z = c.take<uint32_t>(wz);
     p.rs_z = c.take<uint32_t>(wz);
+    p.zs_y = c.take<uint32_t>((size_t)(p.gy.sx * p.gy.nbands * p.gy.nouter));
   }
   p.bytes = align_up(c.off, 256) + 256;
   return p;
@@ -180,15 +181,36 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   const int swaps = (tiled_y ? 0 : 1) + ((ndim == 3 && !tiled_z) ? 1 : 0);
   float *cur = (swaps % 2 == 0) ? d_out : p.bufB;
   float *other = (cur == d_out) ? p.bufB : d_out;
-  {
-    ScopedPass t("x_pass", stream);
-    rc = launch_row_pass_serial(dtype, d_labels, cur, sx, sy * sz, wx, bb, bb ? 0 : 1, 0, stream);
-    if (rc != EDT_OK) return rc;
-  }
-  {
-    ScopedPass t("y_bits", stream);
-    rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_y, p.rs_y, p.gy, stream);
-    if (rc != EDT_OK) return rc;
+  const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
+  if (tiled_x) {
+    // labels are read once: pass 1 also emits the run bit-planes of the y and z axes
+    {
+      ScopedPass t("x_pass", stream);
+      rc = launch_row_pass_tiled(dtype, d_labels, cur, p.nz_y, p.rs_y, ndim == 3 ? p.zs_y : nullptr, sx,
+                                 sy, sz, wx, bb, bb ? 0 : 1, stream);
+      if (rc != EDT_OK) return rc;
+    }
+    if (ndim == 3) {
+      ScopedPass t("z_bits", stream);
+      rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
+      if (rc != EDT_OK) return rc;
+    }
+  } else {
+    {
+      ScopedPass t("x_pass", stream);
+      rc = launch_row_pass_serial(dtype, d_labels, cur, sx, sy * sz, wx, bb, bb ? 0 : 1, 0, stream);
+      if (rc != EDT_OK) return rc;
+    }
+    {
+      ScopedPass t("y_bits", stream);
+      rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_y, p.rs_y, p.gy, stream);
+      if (rc != EDT_OK) return rc;
+    }
+    if (ndim == 3) {
+      ScopedPass t("z_bits", stream);
+      rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
+      if (rc != EDT_OK) return rc;
+    }
   }
   {
     ScopedPass t("y_pass", stream);
@@ -202,11 +224,6 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     if (rc != EDT_OK) return rc;
   }
   if (ndim == 3) {
-    {
-      ScopedPass t("z_bits", stream);
-      rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
-      if (rc != EDT_OK) return rc;
-    }
     ScopedPass t("z_pass", stream);
     if (tiled_z) {
       rc = launch_column_pass_tiled(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream);

@@ -61,4 +61,11 @@ int launch_bits_from_flags(const uint8_t *flags, uint32_t *nz, uint32_t *rs, con
 bool column_pass_tiled_supported(const AxisGeom &g);
 int launch_column_pass_tiled(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                              float w, int bb, int epi, hipStream_t stream);
+// ---- wave-per-row-group pass 1 + bit-plane transposer: edt_rows.hip ---------------------------
+bool row_pass_tiled_supported(int64_t sx);
+int launch_row_pass_tiled(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
+                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
+                          int to_finite, hipStream_t stream);
+int launch_bits_transpose_yz(const uint32_t *nz_y, const uint32_t *zs_y, uint32_t *nz_z,
+                             uint32_t *rs_z, int64_t sx, int64_t sy, int64_t sz, hipStream_t stream);
 }  // namespace edt_amd

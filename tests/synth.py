@@ -34,21 +34,24 @@ def blob_mask(shape, rng=None, p=0.6, block=4):
 def voronoi_labels(shape, nseeds, seed=0, upsample=4, membrane=0.0, dtype=np.uint32):
     """SNEMI3D-like dense segmentation: nearest-seed labels on a coarse grid, up-sampled.
 
-    Brute-force nearest seed in chunks (no scipy dependency); `membrane` > 0 zeroes that
-    fraction of coarse cells to create thin background sheets between segments.
+    `membrane` > 0 zeroes that fraction of coarse cells to create thin background sheets
+    between segments.
     """
     rng = np.random.default_rng(seed)
     small = tuple(max(1, -(-s // upsample)) for s in shape)
     pts = rng.random((nseeds, len(shape))) * np.array(small)
     grids = np.meshgrid(*[np.arange(s) + 0.5 for s in small], indexing="ij")
     g = np.stack(grids, -1).reshape(-1, len(shape))
-    idx = np.empty(len(g), dtype=np.int64)
-    # order seeds once so that chunks can prune by a KD-free brute force in float32
-    pts32 = pts.astype(np.float32)
-    chunk = max(1, (1 << 24) // max(1, nseeds))
-    for s in range(0, len(g), chunk):
-        d = ((g[s:s + chunk, None, :].astype(np.float32) - pts32[None, :, :]) ** 2).sum(-1)
-        idx[s:s + chunk] = d.argmin(1)
+    try:  # same image here and on the GPU box; brute force only as a fallback
+        from scipy.spatial import cKDTree
+        idx = cKDTree(pts).query(g)[1]
+    except ImportError:  # pragma: no cover
+        idx = np.empty(len(g), dtype=np.int64)
+        pts32 = pts.astype(np.float32)
+        chunk = max(1, (1 << 24) // max(1, nseeds))
+        for s in range(0, len(g), chunk):
+            d = ((g[s:s + chunk, None, :].astype(np.float32) - pts32[None, :, :]) ** 2).sum(-1)
+            idx[s:s + chunk] = d.argmin(1)
     lab = (idx + 1).reshape(small)
     if membrane > 0:
         lab[rng.random(small) < membrane] = 0

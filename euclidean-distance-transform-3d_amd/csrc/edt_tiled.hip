@@ -27,8 +27,11 @@
 //                      and stores in place.
 // Background voxels are neither loaded nor stored (they hold 0 since pass 1 and stay 0).
 //
-// All fp64 arithmetic is evaluated without contraction, so results are bit-identical to
-// the CPU reference (see edt_kernels.h: hull_num).
+// Arithmetic: rows are < 2^15, so differences and their squares are formed in int32 (one
+// full-rate 24-bit multiply), converted once to fp64, and combined with separate fp64
+// multiply/add (no contraction) -- value-identical to the reference's
+// `w2 * sq(i - v[k]) + ff[v[k]]` and `ff[i] - ff[v[k]] + factor1 * factor2`
+// (every product involved is exact in fp64: w2 carries 24 significant bits).
 #include "edt_common.h"
 #include "edt_kernels.h"
 
@@ -38,13 +41,18 @@ namespace edt_amd {
 
 namespace {
 
-// b (height Fb) lies on or above the chord from a to c  <=>  s(b,c) <= s(a,b): parabola b is
-// never the strict minimum and can be dropped (reference pop rule, src/edt.hpp:210, :287).
-__device__ __forceinline__ bool dominated(int a, double Fa, int b, double Fb, int c, double Fc,
-                                          double w2) {
-  const double lhs = hull_num(Fb, Fc, b, c, w2) * (double)(b - a);
-  const double rhs = hull_num(Fa, Fb, a, b, w2) * (double)(c - b);
-  return lhs <= rhs;
+// exact (double)(d*d) for |d| < 4096
+__device__ __forceinline__ double sq_i(int d) { return (double)__mul24(d, d); }
+
+// value of parabola j (height Fj) at row p -- the reference's output expression
+__device__ __forceinline__ double para(int p, int j, double Fj, double w2) {
+  return w2 * sq_i(p - j) + Fj;
+}
+
+// numerator of the crossing abscissa of parabolas p < q:  (Fq - Fp) + w2*(q-p)*(q+p)
+// (== hull_num of edt_kernels.h: (q-p)*w2*(q+p) is exact in either association)
+__device__ __forceinline__ double edge_num(int p, double Fp, int q, double Fq, double w2) {
+  return (Fq - Fp) + w2 * (double)__mul24(q - p, q + p);
 }
 
 // Highest set bit p with lo <= p < from in a bit-plane column (`words` already points at the
@@ -88,21 +96,20 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NB = (int)blockDim.y;
   const int n = (int)g.n;
-  float *tile = reinterpret_cast<float *>(smem);                  // [NB*32][C]
+  float *tile = reinterpret_cast<float *>(smem);                       // [NB*32][C]
   uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NB * 32 * C);  // [NB][C]
-  uint32_t *rsp = alive + NB * C;                                  // [NB][C]
-  uint32_t *nzp = rsp + NB * C;                                    // [NB][C]
+  uint32_t *rsp = alive + NB * C;                                      // [NB][C]
 
   const int c = (int)threadIdx.x, b = (int)threadIdx.y;
   const int64_t xt = blockIdx.x % tiles_x, o = blockIdx.x / tiles_x;
   const int64_t x = xt * C + c;
   const bool active = x < g.sx;
-  const int64_t base = x + o * g.outer_stride;
   const int64_t st = g.stride;
-  const double w2 = (double)(w * w);  // fp32 product widened (src/edt.hpp:181, :258)
+  float *Fcol = F + x + o * g.outer_stride;  // global column
+  const double w2 = (double)(w * w);         // fp32 product widened (src/edt.hpp:181, :258)
 
-  float *tcol = tile + c;             // element of row r: tcol[r * C]
-  uint32_t *acol = alive + c;         // word of band k: acol[k * C]
+  float *tcol = tile + c;      // row r of this column: tcol[r * C]
+  uint32_t *acol = alive + c;  // word of band k: acol[k * C]
   const uint32_t *rcol = rsp + c;
   const int row0 = b * 32;
 
@@ -115,48 +122,57 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   }
   {
     float v[32];
+    const float *src = Fcol + (int64_t)row0 * st;
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
       v[r] = 0.0f;
-      if ((nzword >> r) & 1u) v[r] = F[base + (int64_t)(row0 + r) * st];
+      if ((nzword >> r) & 1u) v[r] = src[(int64_t)r * st];
     }
 #pragma unroll
     for (int r = 0; r < 32; ++r) tcol[(row0 + r) * C] = v[r];
   }
   rsp[b * C + c] = rsword;
-  nzp[b * C + c] = nzword;
 
   // ---- phase 1: hull of this band (monotone chain; the stack is the set bits of `aw`) ----
+  uint32_t aw = 0;
   {
-    uint32_t aw = 0;
-    uint32_t seg = 0xFFFFFFFFu;  // bits of the current run segment (from its first row upward)
-    int ia = -1, ib = -1;
+    uint32_t seg = 0xFFFFFFFFu;  // rows of the current run segment (from its first row upward)
+    int ia = -1, ib = -1;        // second / top vertex of the stack (ia < 0: fewer than two)
     double Fa = 0.0, Fb = 0.0;
-    uint32_t todo = nzword;
-    while (todo) {
-      const int r = __builtin_ctz(todo);
-      todo &= todo - 1;
-      // a run starts at r, or a background gap lies between the previous vertex and r
-      if (((rsword >> r) & 1u) || ib != row0 + r - 1) {
+    double nab = 0.0;            // edge_num(ia, ib) of the top edge
+    double dab = 0.0;            // (double)(ib - ia)
+#pragma unroll 1
+    for (int r = 0; r < 32; ++r) {
+      if (!((nzword >> r) & 1u)) continue;
+      if ((rsword >> r) & 1u) {  // a run starts here: fresh stack
         ia = ib = -1;
         seg = 0xFFFFFFFFu << r;
       }
       const int row = row0 + r;
       const double Fi = (double)tcol[row * C];
-      while (ia >= 0 && dominated(ia, Fa, ib, Fb, row, Fi, w2)) {
-        aw &= ~(1u << (ib & 31));
+      double nbi = 0.0;
+      if (ib >= 0) nbi = edge_num(ib, Fb, row, Fi, w2);
+      // pop while the top vertex lies on or above the chord (second, new):
+      //   s(ib,row) <= s(ia,ib)  <=>  nbi * (ib-ia) <= nab * (row-ib)   (src/edt.hpp:210, :287)
+      while (ia >= 0 && nbi * dab <= nab * (double)(row - ib)) {
+        aw &= ~(1u << (ib - row0));
         ib = ia;
         Fb = Fa;
-        const uint32_t below = aw & seg & ((1u << (ib & 31)) - 1u);
+        nbi = edge_num(ib, Fb, row, Fi, w2);
+        const uint32_t below = aw & seg & ((1u << (ib - row0)) - 1u);
         if (below) {
           ia = row0 + 31 - __builtin_clz(below);
           Fa = (double)tcol[ia * C];
+          nab = edge_num(ia, Fa, ib, Fb, w2);
+          dab = (double)(ib - ia);
         } else {
           ia = -1;
         }
       }
       aw |= 1u << r;
       ia = ib; Fa = Fb;
+      nab = nbi;
+      dab = (double)(row - ib);
       ib = row; Fb = Fi;
     }
     acol[b * C] = aw;
@@ -178,8 +194,8 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         const int nxt = next_set(rcol, C, R, ghi);
         const int Rhi = nxt < 0 ? ghi : nxt - 1;
 
-        int u = prev_set(acol, C, R, Llo);  // == R-1 (last vertex of the left hull)
-        int v = R;                           // first vertex of the right hull
+        int u = R - 1;  // last vertex of the left hull (always alive)
+        int v = R;      // first vertex of the right hull (always alive)
         double Fu = (double)tcol[u * C], Fv = (double)tcol[v * C];
         int up = prev_set(acol, C, u, Llo);
         int vn = next_set(acol, C, v, Rhi);
@@ -187,14 +203,16 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         double Fvn = vn >= 0 ? (double)tcol[vn * C] : 0.0;
         while (true) {
           bool moved = false;
-          if (up >= 0 && dominated(up, Fup, u, Fu, v, Fv, w2)) {
+          const double nuv = edge_num(u, Fu, v, Fv, w2);
+          if (up >= 0 &&
+              nuv * (double)(u - up) <= edge_num(up, Fup, u, Fu, w2) * (double)(v - u)) {
             acol[(u >> 5) * C] &= ~(1u << (u & 31));
             u = up; Fu = Fup;
             up = prev_set(acol, C, u, Llo);
             Fup = up >= 0 ? (double)tcol[up * C] : 0.0;
             moved = true;
-          }
-          if (vn >= 0 && dominated(u, Fu, v, Fv, vn, Fvn, w2)) {
+          } else if (vn >= 0 &&
+                     edge_num(v, Fv, vn, Fvn, w2) * (double)(v - u) <= nuv * (double)(vn - v)) {
             acol[(v >> 5) * C] &= ~(1u << (v & 31));
             v = vn; Fv = Fvn;
             vn = next_set(acol, C, v, Rhi);
@@ -209,54 +227,89 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   }
 
   // ---- phase 3: evaluate the envelope on this band's rows, in place -------------------------
-  if (!active) return;
-  int r = 0;
-  while (r < 32) {
-    const uint32_t rest = nzword >> r;
-    if (rest == 0) break;
-    r += __builtin_ctz(rest);  // next foreground row of this band
-    const int p0 = row0 + r;
-    const int run_lo = ((rsword >> r) & 1u) ? p0 : prev_set(rcol, C, p0, 0);
-    const int nxt = next_set(rcol, C, p0, n - 1);
-    const int run_hi = nxt < 0 ? n - 1 : nxt - 1;
-    const int seg_end = run_hi < row0 + 31 ? run_hi : row0 + 31;
-    const bool left = bb || run_lo > 0;
-    const bool right = bb || run_hi < n - 1;
+  if (!active || nzword == 0) return;
+  aw = acol[b * C];  // this band's vertices after the merges
 
-    // hull vertex owning p0: start from the last vertex at or before p0, walk down the
-    // (unimodal) values
-    int j = prev_set(acol, C, p0 + 1, run_lo);
-    double Fj = (double)tcol[j * C];
-    {
-      double vj = w2 * sqd(p0 - j) + Fj;
-      while (true) {
-        const int jp = prev_set(acol, C, j, run_lo);
-        if (jp < 0) break;
-        const double Fjp = (double)tcol[jp * C];
-        const double vp = w2 * sqd(p0 - jp) + Fjp;
-        if (!(vp < vj)) break;
-        j = jp; Fj = Fjp; vj = vp;
-      }
+  // run boundaries outside the band (needed only when a run crosses the band's ends)
+  int lo_carry = row0, hi_carry = row0 + 31;
+  if ((nzword & 1u) && !(rsword & 1u)) lo_carry = prev_set(rcol, C, row0, 0);
+  {
+    const int last = row0 + 31;
+    if (last < n - 1 && (nzword >> 31)) {
+      const int nx = next_set(rcol, C, last, n - 1);
+      hi_carry = nx < 0 ? n - 1 : nx - 1;
     }
-    int jn = next_set(acol, C, j, run_hi);
-    double Fjn = jn >= 0 ? (double)tcol[jn * C] : 0.0;
+    if (hi_carry > n - 1) hi_carry = n - 1;
+  }
 
-    for (int p = p0; p <= seg_end; ++p) {
-      double best = w2 * sqd(p - j) + Fj;
-      while (jn >= 0) {
-        const double cand = w2 * sqd(p - jn) + Fjn;
-        if (!(cand < best)) break;
-        best = cand;
-        j = jn; Fj = Fjn;
+  int j = 0, jn = -1, run_lo = 0, run_hi = 0;
+  double Fj = 0.0, Fjn = 0.0;
+  bool left = false, right = false;
+#pragma unroll 1
+  for (int r = 0; r < 32; ++r) {
+    if (!((nzword >> r) & 1u)) continue;
+    const int p = row0 + r;
+    const bool starts = (rsword >> r) & 1u;
+    if (starts || r == 0) {
+      // bounds of the run containing p
+      const uint32_t below = rsword & (0xFFFFFFFFu >> (31 - r));
+      run_lo = below ? row0 + 31 - __builtin_clz(below) : lo_carry;
+      const uint32_t above = (r < 31) ? (rsword & (0xFFFFFFFEu << r)) : 0u;
+      run_hi = above ? row0 + __builtin_ctz(above) - 1 : hi_carry;
+      left = bb || run_lo > 0;
+      right = bb || run_hi < n - 1;
+      if (starts) {
+        j = p;  // first vertex of the run
+        Fj = (double)tcol[p * C];
+      } else {
+        // the run began in an earlier band: start from the last vertex at or before p and walk
+        // down the (unimodal) values towards earlier vertices
+        j = prev_set(acol, C, p + 1, run_lo);
+        Fj = (double)tcol[j * C];
+        double vj = para(p, j, Fj, w2);
+        while (true) {
+          const int jp = prev_set(acol, C, j, run_lo);
+          if (jp < 0) break;
+          const double Fjp = (double)tcol[jp * C];
+          const double vp = para(p, jp, Fjp, w2);
+          if (!(vp < vj)) break;
+          j = jp; Fj = Fjp; vj = vp;
+        }
+      }
+      jn = -1;
+      if (j >= row0) {
+        const uint32_t m = aw & (0xFFFFFFFEu << (j - row0));
+        if (j - row0 < 31 && m) jn = row0 + __builtin_ctz(m);
+        else if (run_hi > row0 + 31) jn = next_set(acol, C, row0 + 31, run_hi);
+      } else {
         jn = next_set(acol, C, j, run_hi);
-        Fjn = jn >= 0 ? (double)tcol[jn * C] : 0.0;
       }
-      float m = (float)best;
-      if (left) m = fminf((float)(w2 * sqd(p - run_lo + 1)), m);
-      if (right) m = fminf((float)(w2 * sqd(run_hi - p + 1)), m);
-      F[base + (int64_t)p * st] = finish(m, epi);
+      if (jn > run_hi) jn = -1;
+      if (jn >= 0) Fjn = (double)tcol[jn * C];
     }
-    r = seg_end - row0 + 1;
+    double best = para(p, j, Fj, w2);
+    while (jn >= 0) {
+      const double cand = para(p, jn, Fjn, w2);
+      if (!(cand < best)) break;
+      best = cand;
+      j = jn; Fj = Fjn;
+      // next vertex after j inside the run
+      jn = -1;
+      if (j >= row0 && j - row0 < 31) {
+        const uint32_t m = aw & (0xFFFFFFFEu << (j - row0));
+        if (m) jn = row0 + __builtin_ctz(m);
+        else if (run_hi > row0 + 31) jn = next_set(acol, C, row0 + 31, run_hi);
+      } else {
+        jn = next_set(acol, C, j, run_hi);
+      }
+      if (jn > run_hi) jn = -1;
+      if (jn >= 0) Fjn = (double)tcol[jn * C];
+    }
+    // border parabolas of height 0 at run_lo-1 and run_hi+1; fp32 rounding is monotone, so
+    // one narrowing of the fp64 minimum equals the reference's separate narrowings
+    if (left) best = fmin(best, w2 * sq_i(p - run_lo + 1));
+    if (right) best = fmin(best, w2 * sq_i(run_hi - p + 1));
+    Fcol[(int64_t)p * st] = finish((float)best, epi);
   }
 }
 
@@ -264,14 +317,14 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 // launcher
 // ---------------------------------------------------------------------------------------
 bool column_pass_tiled_supported(const AxisGeom &g) {
-  return g.nbands >= 1 && g.nbands * 8 <= 1024;  // C = 8 is the narrowest tile
+  return g.nbands >= 1 && g.nbands * 8 <= 1024;  // C = 8 is the narrowest tile; rows < 4096
 }
 
 template <int C>
 static int launch_tiled_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                           float w, int bb, int epi, hipStream_t stream) {
   const int NB = (int)g.nbands;
-  const size_t lds = (size_t)NB * C * (32 * sizeof(float) + 3 * sizeof(uint32_t));
+  const size_t lds = (size_t)NB * C * (32 * sizeof(float) + 2 * sizeof(uint32_t));
   static bool attr_done = false;  // per C instantiation
   if (!attr_done) {
     EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_tiled<C>),

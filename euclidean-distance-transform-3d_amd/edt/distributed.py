@@ -1,5 +1,255 @@
-"""Z-sharded multi-GPU driver (filled in below in this round)."""
+"""Z-sharded multi-GPU EDT: one process per GPU, torch.distributed (RCCL over xGMI).
+
+Why this shape ("Multi-GPU"): the X and Y passes of the reference touch one
+z-slice at a time (reference: src/edt.hpp:430-460), so a volume cut into contiguous Z-slabs
+needs no communication for them.  The Z pass (src/edt.hpp:465-475) walks whole z-columns, which
+a fixed-width halo cannot provide exactly, so the fp32 partial result is re-partitioned ONCE
+from Z-slabs to Y-slabs with an all-to-all; every rank then owns complete z-columns for its
+y-range.  The all-to-all is issued as one group of point-to-point sends/receives -- on a
+fully connected xGMI node every peer pair has its own link, so the 7 transfers of a rank run
+concurrently.  Labels do not travel: one flag byte per voxel (foreground, run-start-along-z)
+does, and run continuity across the slab cut is decided from a ONE-SLICE label halo received
+from the previous rank.
+
+    rank r:  labels[z in Z_r, :, :] --X,Y passes--> partial, zflags        (local, HIP)
+             halo: last slice of rank r-1's labels                          (1 send/recv)
+             all-to-all: block (Z_r, Y_h) -> rank h                         (P2P group)
+             Z pass on [all z, y in Y_r, :]                                 (local, HIP)
+
+The numerical work is done by `ops` (default: the HIP kernels through the C ABI); the
+partition / exchange logic here is backend agnostic, which is how the CPU test-suite drives
+it over gloo with a CPU implementation of the two phases.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
 
 
-def bench_main(args, rank, world, dev):  # pragma: no cover - replaced by the real driver
-    raise NotImplementedError("multi-GPU bench driver not wired yet")
+def balanced_partition(n: int, parts: int):
+    """`parts` contiguous ranges covering [0, n), sizes differing by at most one."""
+    base, extra = divmod(n, parts)
+    out, start = [], 0
+    for i in range(parts):
+        size = base + (1 if i < extra else 0)
+        out.append((start, start + size))
+        start += size
+    return out
+
+
+class HipOps:
+    """The two local phases on the GPU (edt_hip_shard_xy_device / edt_hip_shard_z_device)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self._ws = None
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self._ws
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def xy(self, labels, halo, code, weights, flags):
+        szl, sy, sx = labels.shape
+        partial = torch.empty((szl, sy, sx), dtype=torch.float32, device=labels.device)
+        zflags = torch.empty((szl, sy, sx), dtype=torch.uint8, device=labels.device)
+        ws = self._workspace(self.lib.edt_hip_shard_workspace_bytes(code, sx, sy, szl), labels.device)
+        _lib.check(self.lib.edt_hip_shard_xy_device(
+            ctypes.c_void_p(labels.data_ptr()),
+            ctypes.c_void_p(halo.data_ptr()) if halo is not None else None, code, sx, sy, szl,
+            weights[0], weights[1], flags, ctypes.c_void_p(partial.data_ptr()),
+            ctypes.c_void_p(zflags.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+            self._stream()))
+        return partial, zflags
+
+    def z(self, partial, zflags, wz, flags):
+        sz, syl, sx = partial.shape
+        ws = self._workspace(self.lib.edt_hip_shard_workspace_bytes(_lib.U8, sx, syl, sz), partial.device)
+        _lib.check(self.lib.edt_hip_shard_z_device(
+            ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(zflags.data_ptr()), sx, syl, sz, wz,
+            flags, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
+        return partial
+
+
+class ShardedEDT:
+    """Distributed squared EDT of one volume of x-fastest extents ``(sx, sy, sz)``.
+
+    Every rank passes its Z-slab as a contiguous tensor of shape ``(sz_local, sy, sx)`` and
+    receives its Y-slab of the result, shape ``(sz, sy_local, sx)`` (all z, its y-range), or --
+    with ``gather_back=True`` -- its original Z-slab of the result.
+    """
+
+    def __init__(self, extents_xyz, code: int, group=None, ops=None):
+        self.sx, self.sy, self.sz = (int(e) for e in extents_xyz)
+        self.code = code
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if self.sz < self.world or self.sy < self.world:
+            raise ValueError("need at least one z-slice and one y-row per rank")
+        self.zparts = balanced_partition(self.sz, self.world)
+        self.yparts = balanced_partition(self.sy, self.world)
+        self.ops = HipOps() if ops is None else ops
+
+    # -- helpers ----------------------------------------------------------------------------
+    def local_z(self):
+        return self.zparts[self.rank]
+
+    def local_y(self):
+        return self.yparts[self.rank]
+
+    def _global_rank(self, r):
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def _halo(self, labels):
+        """One-slice label halo: receive the previous rank's last slice, send ours onward."""
+        ops, halo = [], None
+        if self.rank + 1 < self.world:
+            ops.append(dist.P2POp(dist.isend, labels[-1].contiguous(), self._global_rank(self.rank + 1),
+                                  self.group))
+        if self.rank > 0:
+            halo = torch.empty_like(labels[0])
+            ops.append(dist.P2POp(dist.irecv, halo, self._global_rank(self.rank - 1), self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return halo
+
+    def _reshard(self, slab_list, to_y: bool):
+        """All-to-all between the Z-slab and the Y-slab layouts, as one group of P2P transfers.
+
+        to_y=True : [(szl, sy, sx)]  -> [(sz, syl, sx)]     block (Z_me, Y_h) goes to rank h
+        to_y=False: [(sz, syl, sx)]  -> [(szl, sy, sx)]     the inverse
+        """
+        ys, ye = self.yparts[self.rank]
+        zs, ze = self.zparts[self.rank]
+        outs, ops, keep = [], [], []
+        for src in slab_list:
+            if to_y:
+                dst = torch.empty((self.sz, ye - ys, self.sx), dtype=src.dtype, device=src.device)
+            else:
+                dst = torch.empty((ze - zs, self.sy, self.sx), dtype=src.dtype, device=src.device)
+            outs.append(dst)
+            for h in range(self.world):
+                hys, hye = self.yparts[h]
+                hzs, hze = self.zparts[h]
+                if to_y:
+                    send = src[:, hys:hye, :]
+                    recv = dst[hzs:hze]                      # contiguous: z is the slowest axis
+                else:
+                    send = src[hzs:hze]
+                    recv = None                              # strided target: stage then copy
+                if h == self.rank:
+                    if to_y:
+                        recv.copy_(send)
+                    else:
+                        dst[:, hys:hye, :].copy_(send)
+                    continue
+                send = send.contiguous()
+                keep.append(send)
+                ops.append(dist.P2POp(dist.isend, send, self._global_rank(h), self.group))
+                if to_y:
+                    ops.append(dist.P2POp(dist.irecv, recv, self._global_rank(h), self.group))
+                else:
+                    stage = torch.empty((ze - zs, hye - hys, self.sx), dtype=src.dtype, device=src.device)
+                    keep.append((stage, dst, hys, hye))
+                    ops.append(dist.P2POp(dist.irecv, stage, self._global_rank(h), self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for item in keep:
+            if isinstance(item, tuple):
+                stage, dst, hys, hye = item
+                dst[:, hys:hye, :].copy_(stage)
+        return outs
+
+    # -- the pipeline -----------------------------------------------------------------------
+    def run(self, labels, weights_xyz, black_border=False, sqrt=False, gather_back=False):
+        zs, ze = self.local_z()
+        if tuple(labels.shape) != (ze - zs, self.sy, self.sx) or not labels.is_contiguous():
+            raise ValueError(f"rank {self.rank}: expected a contiguous ({ze - zs}, {self.sy}, {self.sx}) slab")
+        w = tuple(float(np.float32(v)) for v in weights_xyz)
+        flags = (_lib.FLAG_BLACK_BORDER if black_border else 0)
+        halo = self._halo(labels)
+        partial, zflags = self.ops.xy(labels, halo, self.code, w, flags)
+        partial_y, zflags_y = self._reshard([partial, zflags], to_y=True)
+        out = self.ops.z(partial_y, zflags_y, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0))
+        if gather_back:
+            out = self._reshard([out], to_y=False)[0]
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+# bench.py's N > 1 leg
+# ------------------------------------------------------------------------------------------
+def global_extents(world: int, edge: int = 512):
+    """One volume with edge^3 voxels per GPU (8 GPUs -> (2*edge)^3, BASELINE configs[3])."""
+    ext = [edge, edge, edge]
+    k, axis = world, 2
+    while k > 1 and k % 2 == 0:
+        ext[axis] *= 2
+        axis = (axis - 1) % 3
+        k //= 2
+    ext[2] *= k  # odd remainder: stack along z
+    return tuple(ext)
+
+
+def bench_main(args, rank, world, dev):
+    ext = global_extents(world, args.size)
+    an, bb = (6.0, 6.0, 30.0), True
+    plan = ShardedEDT(ext, _lib.U32)
+    zs, ze = plan.local_z()
+    labels = torch.ones((ze - zs, ext[1], ext[0]), dtype=torch.int32, device=dev)
+
+    def step():
+        return plan.run(labels, an, black_border=bb)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # correctness of the timed output: closed form of the all-ones box on this rank's y-slab
+    ys, ye = plan.local_y()
+    idx = [torch.arange(e, device=dev, dtype=torch.float64) for e in ext]
+    d = [torch.minimum(i + 1, e - i) * w for i, e, w in zip(idx, ext, an)]
+    want = torch.minimum(torch.minimum((d[2] ** 2)[:, None, None], (d[1][ys:ye] ** 2)[None, :, None]),
+                         (d[0] ** 2)[None, None, :]).to(torch.float32)
+    ok = torch.tensor([1 if torch.equal(out, want) else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+
+    if rank == 0:
+        vox = ext[0] * ext[1] * ext[2]
+        print(json.dumps({
+            "metric": "Mvox/s edt3dsq 512^3 uint32", "value": round(vox / (elapsed / args.steps) / 1e6, 1),
+            "unit": "Mvox/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 envelope / f32 storage / u32 labels", "data": "synthetic",
+            "config": {"workload": f"one {ext[0]}x{ext[1]}x{ext[2]} uint32 volume ({args.size}^3 voxels per GPU), "
+                                   f"anisotropy {an}, black_border={bb}, Z-sharded over {world} GPUs, "
+                                   "one all-to-all (Z-slabs -> Y-slabs) before the z pass",
+                       "output_verified": bool(ok.item())},
+        }))
+    dist.destroy_process_group()

@@ -1,0 +1,121 @@
+"""Multi-process CPU tests (gloo, world_size 2 and 3) of the Z-sharded driver
+(euclidean-distance-transform-3d_amd/edt/distributed.py): partitioning, the one-slice label halo
+and the Z-slab -> Y-slab all-to-all.  The two local phases are supplied by a CPU implementation
+(oracle/edt_oracle.c: oracle_shard_xy / oracle_shard_z) injected through the driver's `ops`
+hook, so what is under test is exactly the code that runs unchanged over RCCL on the GPUs."""
+import ctypes
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "euclidean-distance-transform-3d_amd"))
+
+
+class OracleOps:
+    """CPU stand-in for HipOps with the same interface."""
+
+    def __init__(self):
+        from oracle import harness
+        if not harness.have_port():
+            harness.build("port")
+        self.lib = harness.port().lib
+
+    def xy(self, labels, halo, code, weights, flags):
+        szl, sy, sx = labels.shape
+        lab = labels.numpy()
+        partial = np.zeros((szl, sy, sx), dtype=np.float32)
+        zflags = np.zeros((szl, sy, sx), dtype=np.uint8)
+        hp = ctypes.c_void_p(halo.numpy().ctypes.data) if halo is not None else None
+        rc = self.lib.oracle_shard_xy(ctypes.c_void_p(lab.ctypes.data), hp, ctypes.c_int(code),
+                                      ctypes.c_int64(sx), ctypes.c_int64(sy), ctypes.c_int64(szl),
+                                      ctypes.c_float(weights[0]), ctypes.c_float(weights[1]),
+                                      ctypes.c_int(flags & 1), ctypes.c_void_p(partial.ctypes.data),
+                                      ctypes.c_void_p(zflags.ctypes.data))
+        assert rc == 0
+        return torch.from_numpy(partial), torch.from_numpy(zflags)
+
+    def z(self, partial, zflags, wz, flags):
+        sz, syl, sx = partial.shape
+        p = partial.numpy()
+        rc = self.lib.oracle_shard_z(ctypes.c_void_p(p.ctypes.data),
+                                     ctypes.c_void_p(zflags.numpy().ctypes.data), ctypes.c_int64(sx),
+                                     ctypes.c_int64(syl), ctypes.c_int64(sz), ctypes.c_float(wz),
+                                     ctypes.c_int(flags & 1), ctypes.c_int(1 if flags & 2 else 0))
+        assert rc == 0
+        return partial
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from edt import distributed as edist
+        from oracle import harness
+        from synth import blocky_labels
+
+        rng = np.random.default_rng(77)
+        vol = blocky_labels(shape, nlabels=5, zero_frac=0.15, block=5, rng=rng).astype(np.uint32)
+        vol = np.asfortranarray(vol)                      # (sx, sy, sz), x fastest
+        zyx = np.ascontiguousarray(vol.T)                  # (sz, sy, sx)
+        plan = edist.ShardedEDT(shape, 2, ops=OracleOps())
+        zs, ze = plan.local_z()
+        slab = torch.from_numpy(zyx[zs:ze].copy().view(np.int32))
+        out = plan.run(slab, an, black_border=bb, sqrt=sqrt, gather_back=gather_back).numpy()
+
+        want = harness.port().edtsq(vol, an, bb)
+        if sqrt:
+            want = np.sqrt(want)
+        want = np.ascontiguousarray(want.T)                # (sz, sy, sx)
+        if gather_back:
+            ok = np.array_equal(out, want[zs:ze], equal_nan=True)
+        else:
+            ys, ye = plan.local_y()
+            ok = np.array_equal(out, want[:, ys:ye, :], equal_nan=True)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,an,bb,sqrt,gather_back", [
+    (2, (24, 20, 18), (6.0, 6.0, 30.0), True, False, False),
+    (2, (17, 13, 11), (1.0, 1.0, 1.0), False, True, True),
+    (3, (16, 19, 22), (0.5, 0.7, 1.3), False, False, False),
+    (3, (9, 7, 8), (4.0, 4.0, 40.0), True, False, True),
+])
+def test_z_sharded_equals_single_process(world, shape, an, bb, sqrt, gather_back):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, an, bb, sqrt, gather_back, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, "worker crashed"
+    results = dict(q.get(timeout=5) for _ in range(world))
+    assert results == {r: True for r in range(world)}
+
+
+def test_partition_helpers():
+    from edt.distributed import balanced_partition, global_extents
+    assert balanced_partition(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert balanced_partition(8, 8) == [(i, i + 1) for i in range(8)]
+    for world in (1, 2, 4, 8):
+        e = global_extents(world, 512)
+        assert e[0] * e[1] * e[2] == world * 512 ** 3
+    assert global_extents(8, 512) == (1024, 1024, 1024)

@@ -16,6 +16,9 @@ static thread_local std::string g_last_error = "";
 
 void set_error(const std::string &msg) { g_last_error = msg; }
 
+static int g_debug_mode = 0;
+int debug_mode() { return g_debug_mode; }
+
 // ---- per-pass event timing (bench.py reads this) -------------------------------------
 struct PassLog {
   bool enabled = false;
@@ -409,6 +412,11 @@ int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, 
                     workspace_bytes, (hipStream_t)stream);
 }
 
+int edt_hip_set_debug_mode(int mode) {
+  g_debug_mode = mode;
+  return EDT_OK;
+}
+
 int edt_hip_set_profiling(int enabled) {
   std::lock_guard<std::mutex> lock(g_log_mutex);
   g_log.enabled = enabled != 0;
@@ -469,12 +477,23 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
     return EDT_ERR_BAD_ARG;
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0;
   const AxisGeom gy = make_geom_y(sx, sy, sz_local);
-  rc = launch_row_pass_serial(dtype, d_labels, p.bufB, sx, sy * sz_local, wx, bb, bb ? 0 : 1, 0, stream);
-  if (rc != EDT_OK) return rc;
-  rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz, p.rs, gy, stream);
-  if (rc != EDT_OK) return rc;
-  rc = launch_column_pass_serial(p.bufB, d_partial, p.nz, p.rs, p.stack, gy, wy, bb, 0, stream);
+  const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
+  const bool tiled_y = !force_generic && column_pass_tiled_supported(gy);
+  float *xout = tiled_y ? d_partial : p.bufB;  // the tiled y pass runs in place
+  if (tiled_x) {
+    rc = launch_row_pass_tiled(dtype, d_labels, xout, p.nz, p.rs, nullptr, sx, sy, sz_local, wx, bb,
+                               bb ? 0 : 1, stream);
+    if (rc != EDT_OK) return rc;
+  } else {
+    rc = launch_row_pass_serial(dtype, d_labels, xout, sx, sy * sz_local, wx, bb, bb ? 0 : 1, 0, stream);
+    if (rc != EDT_OK) return rc;
+    rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz, p.rs, gy, stream);
+    if (rc != EDT_OK) return rc;
+  }
+  if (tiled_y) rc = launch_column_pass_tiled(d_partial, p.nz, p.rs, gy, wy, bb, 0, stream);
+  else rc = launch_column_pass_serial(p.bufB, d_partial, p.nz, p.rs, p.stack, gy, wy, bb, 0, stream);
   if (rc != EDT_OK) return rc;
   return launch_zflags(dtype, d_labels, d_halo, d_zflags, sx * sy, sz_local, stream);
 }
@@ -497,6 +516,8 @@ int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx
   const AxisGeom gz = make_geom_z(sx, sy_local, sz);
   rc = launch_bits_from_flags(d_zflags, p.nz, p.rs, gz, stream);
   if (rc != EDT_OK) return rc;
+  if (!(flags & EDT_FLAG_FORCE_GENERIC) && column_pass_tiled_supported(gz))
+    return launch_column_pass_tiled(d_partial, p.nz, p.rs, gz, wz, bb, epi, stream);
   rc = launch_column_pass_serial(d_partial, p.bufB, p.nz, p.rs, p.stack, gz, wz, bb, epi, stream);
   if (rc != EDT_OK) return rc;
   EDT_HIP_TRY(hipMemcpyAsync(d_partial, p.bufB, (size_t)(sx * sy_local * sz) * sizeof(float),

@@ -21,6 +21,7 @@ constexpr int kBandRows = 32;    // rows of the scan axis covered by one bit-wor
 
 // ---- error plumbing ---------------------------------------------------------------
 void set_error(const std::string &msg);
+int debug_mode();  // edt_hip_set_debug_mode(): bit0 = column pass moves data only (diagnostics)
 
 #define EDT_HIP_TRY(expr)                                                              \
   do {                                                                                 \

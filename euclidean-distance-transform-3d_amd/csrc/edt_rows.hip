@@ -31,7 +31,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kMaxChunks = 32;  // rows up to 2048 voxels
 }  // namespace
 
-template <typename T>
+template <typename T, bool HAS_Z>
 __global__ void __launch_bounds__(kWavesPerBlock * 64, 4)
 k_row_pass_tiled(const T *__restrict__ labels, float *__restrict__ out,
                  uint32_t *__restrict__ nz_y, uint32_t *__restrict__ ys_y,
@@ -41,7 +41,8 @@ k_row_pass_tiled(const T *__restrict__ labels, float *__restrict__ out,
   // LDS carve: T table [sx+2] | per wave: st[32][NC] u64, fg[32][NC] u64, pre[32][NC], suf[32][NC]
   const int tbl = (int)((sx + 2 + 3) & ~3);
   float *Ttab = reinterpret_cast<float *>(smem);
-  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform
+  const int lane = (int)(threadIdx.x & 63);
   unsigned char *wbase = smem + (size_t)tbl * sizeof(float) + (size_t)wave * (32 * NC * 24);
   unsigned long long *st = reinterpret_cast<unsigned long long *>(wbase);          // [32][NC]
   unsigned long long *fg = st + 32 * NC;                                           // [32][NC]
@@ -76,44 +77,46 @@ k_row_pass_tiled(const T *__restrict__ labels, float *__restrict__ out,
     for (int c = 0; c < NC; ++c) {
       const int64_t x = (int64_t)c * 64 + lane;
       const bool inb = x < sx;
+      // Every load below is unconditional (clamped to a voxel that exists): the left and lower
+      // neighbours are plain shifted loads that hit L1/L2, not exchanged through lanes.
+      const int64_t xs = inb ? x : sx - 1;
+      const int64_t xl = xs > 0 ? xs - 1 : 0;
+      const T *base = labels + (z * sy + y0) * sx;       // row y0 of this slice
+      const T *lower = (HAS_Z && z > 0) ? base - sxy : base;
       uint32_t nzw = 0, ysw = 0, zsw = 0;
       T above = 0;  // label at (x, y-1, z)
       bool have_above = false;
-      if (inb && nrows > 0 && y0 > 0) {
-        above = labels[(z * sy + (y0 - 1)) * sx + x];
+      if (nrows > 0 && y0 > 0) {
+        above = base[xs - sx];
         have_above = true;
       }
-      constexpr int kBatch = 8;  // rows loaded back-to-back before any cross-lane work
+      constexpr int kBatch = 16;  // rows loaded back-to-back before any cross-lane work
 #pragma unroll 1
       for (int r0 = 0; r0 < nrows; r0 += kBatch) {
-        T labv[kBatch], belv[kBatch], edgev[kBatch];
+        T labv[kBatch], leftv[kBatch], belv[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
-          labv[k] = 0; belv[k] = 0; edgev[k] = 0;
-          if (inb && r0 + k < nrows) {
-            const int64_t idx = (z * sy + (y0 + r0 + k)) * sx + x;
-            labv[k] = labels[idx];
-            if (z > 0 && zs_y != nullptr) belv[k] = labels[idx - sxy];
-            if (lane == 0 && x > 0) edgev[k] = labels[idx - 1];
-          }
+          const int rr = r0 + k < nrows ? r0 + k : nrows - 1;
+          const int64_t off = (int64_t)rr * sx;
+          labv[k] = base[off + xs];
+          leftv[k] = base[off + xl];
+          belv[k] = HAS_Z ? lower[off + xs] : labv[k];
         }
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
           const int r = r0 + k;
           if (r < nrows) {  // wave-uniform
             const T lab = labv[k];
-            T left = __shfl_up(lab, 1);
-            if (lane == 0) left = edgev[k];
-            const bool startx = inb && (x == 0 || lab != left);
+            const bool startx = inb && (x == 0 || lab != leftv[k]);
             const unsigned long long stm = __ballot(startx);
             const unsigned long long fgm = __ballot(inb && lab != 0);
             if (lane == 0) {
               st[r * NC + c] = stm;
               fg[r * NC + c] = fgm;
             }
-            if (lab != 0) nzw |= 1u << r;
-            if (!have_above || lab != above) ysw |= 1u << r;
-            if (z == 0 || lab != belv[k]) zsw |= 1u << r;
+            nzw |= (lab != 0 ? 1u : 0u) << r;
+            ysw |= ((!have_above || lab != above) ? 1u : 0u) << r;
+            if (HAS_Z) zsw |= ((z == 0 || lab != belv[k]) ? 1u : 0u) << r;
             above = lab;
             have_above = true;
           }
@@ -123,7 +126,7 @@ k_row_pass_tiled(const T *__restrict__ labels, float *__restrict__ out,
         const int64_t widx = (z * nby + yb) * sx + x;
         nz_y[widx] = nzw;
         ys_y[widx] = ysw;
-        if (zs_y != nullptr) zs_y[widx] = zsw;
+        if (HAS_Z) zs_y[widx] = zsw;
       }
     }
     __syncthreads();
@@ -195,16 +198,23 @@ static int launch_row_tiled_t(const void *labels, float *out, uint32_t *nz_y, ui
                      (size_t)kWavesPerBlock * 32 * NC * 24;
   static bool attr_done = false;
   if (!attr_done) {
-    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_pass_tiled<T>),
+    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_pass_tiled<T, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_pass_tiled<T, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   int64_t blocks = ceil_div(ngroups, kWavesPerBlock);
   const int64_t resident = 256 * 6;  // persistent grid: the T table is built once per block
   if (blocks > resident) blocks = resident;
-  hipLaunchKernelGGL(k_row_pass_tiled<T>, dim3((unsigned)blocks), dim3(kWavesPerBlock * 64), lds,
-                     stream, (const T *)labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite,
-                     NC, nby, ngroups);
+  if (zs_y != nullptr)
+    hipLaunchKernelGGL((k_row_pass_tiled<T, true>), dim3((unsigned)blocks), dim3(kWavesPerBlock * 64),
+                       lds, stream, (const T *)labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb,
+                       to_finite, NC, nby, ngroups);
+  else
+    hipLaunchKernelGGL((k_row_pass_tiled<T, false>), dim3((unsigned)blocks), dim3(kWavesPerBlock * 64),
+                       lds, stream, (const T *)labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb,
+                       to_finite, NC, nby, ngroups);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }

@@ -86,13 +86,31 @@ __device__ __forceinline__ int next_set(const uint32_t *words, int pitch, int af
   }
 }
 
+// Next hull vertex after j inside the run ending at run_hi, or -1.  `aw` is the calling
+// thread's own (post-merge) alive word for rows [row0, row0+32): the common case needs no LDS.
+__device__ __forceinline__ int next_vertex(int j, int row0, uint32_t aw, int run_hi,
+                                           const uint32_t *acol, int C) {
+  const int rj = j - row0;
+  int q = -1;
+  if (rj >= 0 && rj < 32) {
+    const uint32_t m = (rj < 31) ? (aw & (0xFFFFFFFEu << rj)) : 0u;
+    if (m) q = row0 + __builtin_ctz(m);
+    else if (run_hi > row0 + 31) q = next_set(acol, C, row0 + 31, run_hi);
+  } else {
+    q = next_set(acol, C, j, run_hi);
+  }
+  return q > run_hi ? -1 : q;
+}
+
 }  // namespace
 
-template <int C>
+template <int C, int EPI, bool BB>
 __global__ void __launch_bounds__(1024)
 k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
-                    const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int bb, int epi,
-                    int tiles_x) {
+                    const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x,
+                    int debug_mode) {
+  constexpr int epi = EPI;
+  constexpr bool bb = BB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NB = (int)blockDim.y;
   const int n = (int)g.n;
@@ -107,73 +125,94 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   const int64_t st = g.stride;
   float *Fcol = F + x + o * g.outer_stride;  // global column
   const double w2 = (double)(w * w);         // fp32 product widened (src/edt.hpp:181, :258)
-
-  float *tcol = tile + c;      // row r of this column: tcol[r * C]
-  uint32_t *acol = alive + c;  // word of band k: acol[k * C]
+  float *tcol = tile + c;                    // row r of this column: tcol[r * C]
+  uint32_t *acol = alive + c;                // word of band k: acol[k * C]
   const uint32_t *rcol = rsp + c;
   const int row0 = b * 32;
 
-  // ---- phase 0: load ------------------------------------------------------------------
-  uint32_t nzword = 0, rsword = 0;
-  if (active) {
-    const int64_t widx = (o * g.nbands + b) * g.sx + x;
-    nzword = nzbits[widx];
-    rsword = rsbits[widx];
-  }
   {
-    float v[32];
-    const float *src = Fcol + (int64_t)row0 * st;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      v[r] = 0.0f;
-      if ((nzword >> r) & 1u) v[r] = src[(int64_t)r * st];
+    // ---- phase 0: load ------------------------------------------------------------------
+    uint32_t nzword = 0, rsword = 0;
+    if (active) {
+      const int64_t widx = (o * g.nbands + b) * g.sx + x;
+      nzword = nzbits[widx];
+      rsword = rsbits[widx];
     }
+    {
+      float v[32];
+      const float *src = Fcol + (int64_t)row0 * st;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) tcol[(row0 + r) * C] = v[r];
-  }
-  rsp[b * C + c] = rsword;
+      for (int r = 0; r < 32; ++r) {
+        v[r] = 0.0f;
+        if ((nzword >> r) & 1u) v[r] = src[(int64_t)r * st];
+      }
+#pragma unroll
+      for (int r = 0; r < 32; ++r) tcol[(row0 + r) * C] = v[r];
+    }
+    rsp[b * C + c] = rsword;
+
+    if (debug_mode & 1) {
+      // diagnostics: memory-only variant (tile -> LDS -> store back), the access-pattern floor
+      // that the roofline analysis in DESIGN.md compares the full kernel against
+      __syncthreads();
+      float *dstp = Fcol + (int64_t)row0 * st;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        if ((nzword >> r) & 1u) dstp[(int64_t)r * st] = tcol[(row0 + r) * C];
+      }
+      return;
+    }
 
   // ---- phase 1: hull of this band (monotone chain; the stack is the set bits of `aw`) ----
+  // Written in "predicated, wave-uniform loop" style: every lane steps through the same row
+  // index, data-dependent repetition (pops) is a loop on __any(), and per-lane decisions are
+  // selects.  This keeps the scalar unit out of the way (no exec-mask bookkeeping per branch).
   uint32_t aw = 0;
-  {
+  if (debug_mode & 2) {  // diagnostics: pretend every foreground row is a hull vertex
+    aw = nzword;
+    acol[b * C] = aw;
+  } else {
     uint32_t seg = 0xFFFFFFFFu;  // rows of the current run segment (from its first row upward)
     int ia = -1, ib = -1;        // second / top vertex of the stack (ia < 0: fewer than two)
     double Fa = 0.0, Fb = 0.0;
     double nab = 0.0;            // edge_num(ia, ib) of the top edge
-    double dab = 0.0;            // (double)(ib - ia)
+    double dab = 1.0;            // (double)(ib - ia)
 #pragma unroll 1
     for (int r = 0; r < 32; ++r) {
-      if (!((nzword >> r) & 1u)) continue;
-      if ((rsword >> r) & 1u) {  // a run starts here: fresh stack
-        ia = ib = -1;
-        seg = 0xFFFFFFFFu << r;
-      }
+      const bool nz = (nzword >> r) & 1u;
+      if (!__any(nz)) continue;
       const int row = row0 + r;
       const double Fi = (double)tcol[row * C];
-      double nbi = 0.0;
-      if (ib >= 0) nbi = edge_num(ib, Fb, row, Fi, w2);
+      if ((rsword >> r) & 1u) {  // a run starts here: fresh stack
+        ia = -1; ib = -1;
+        seg = 0xFFFFFFFFu << r;
+      }
+      double nbi = edge_num(ib, Fb, row, Fi, w2);
       // pop while the top vertex lies on or above the chord (second, new):
       //   s(ib,row) <= s(ia,ib)  <=>  nbi * (ib-ia) <= nab * (row-ib)   (src/edt.hpp:210, :287)
-      while (ia >= 0 && nbi * dab <= nab * (double)(row - ib)) {
-        aw &= ~(1u << (ib - row0));
-        ib = ia;
-        Fb = Fa;
-        nbi = edge_num(ib, Fb, row, Fi, w2);
-        const uint32_t below = aw & seg & ((1u << (ib - row0)) - 1u);
-        if (below) {
-          ia = row0 + 31 - __builtin_clz(below);
-          Fa = (double)tcol[ia * C];
+      bool pop = nz && ia >= 0 && (nbi * dab <= nab * (double)(row - ib));
+      while (__any(pop)) {
+        if (pop) {
+          aw &= ~(1u << (ib - row0));
+          ib = ia;
+          Fb = Fa;
+          nbi = edge_num(ib, Fb, row, Fi, w2);
+          const uint32_t below = aw & seg & ((1u << (ib - row0)) - 1u);
+          const int top = row0 + 31 - __builtin_clz(below | 1u);
+          ia = below ? top : -1;
+          Fa = (double)tcol[(below ? top : row) * C];
           nab = edge_num(ia, Fa, ib, Fb, w2);
           dab = (double)(ib - ia);
-        } else {
-          ia = -1;
         }
+        pop = nz && ia >= 0 && (nbi * dab <= nab * (double)(row - ib));
       }
-      aw |= 1u << r;
-      ia = ib; Fa = Fb;
-      nab = nbi;
-      dab = (double)(row - ib);
-      ib = row; Fb = Fi;
+      if (nz) {
+        aw |= 1u << r;
+        ia = ib; Fa = Fb;
+        nab = nbi;
+        dab = (double)(row - ib);
+        ib = row; Fb = Fi;
+      }
     }
     acol[b * C] = aw;
   }
@@ -181,6 +220,7 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 
   // ---- phase 2: merge hulls across band-group boundaries ------------------------------------
   for (int half = 1; half < NB; half <<= 1) {
+    if (debug_mode & 4) break;  // diagnostics: no merges
     if (active && (b & (2 * half - 1)) == half) {
       const int R = row0;  // first row of the right group
       // a non-background run crosses the boundary iff row R is foreground and not a run start
@@ -227,89 +267,112 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   }
 
   // ---- phase 3: evaluate the envelope on this band's rows, in place -------------------------
-  if (!active || nzword == 0) return;
   aw = acol[b * C];  // this band's vertices after the merges
+  if (!active) { nzword = 0; }
+  if (debug_mode & 8) {  // diagnostics: skip the evaluation, store the tile back
+    float *dstp = Fcol + (int64_t)row0 * st;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      if ((nzword >> r) & 1u) dstp[(int64_t)r * st] = tcol[(row0 + r) * C];
+    }
+    nzword = 0;  // nothing left to do for this tile
+  }
 
   // run boundaries outside the band (needed only when a run crosses the band's ends)
   int lo_carry = row0, hi_carry = row0 + 31;
   if ((nzword & 1u) && !(rsword & 1u)) lo_carry = prev_set(rcol, C, row0, 0);
-  {
-    const int last = row0 + 31;
-    if (last < n - 1 && (nzword >> 31)) {
-      const int nx = next_set(rcol, C, last, n - 1);
-      hi_carry = nx < 0 ? n - 1 : nx - 1;
+  if (row0 + 31 < n - 1 && (nzword >> 31)) {
+    const int nx = next_set(rcol, C, row0 + 31, n - 1);
+    hi_carry = nx < 0 ? n - 1 : nx - 1;
+  }
+  if (hi_carry > n - 1) hi_carry = n - 1;
+
+  int j = row0, jn = -1, run_lo = row0, run_hi = row0;
+  double Fj = 0.0, Fjn = 0.0;
+  if ((nzword & 1u) && !(rsword & 1u)) {
+    // The band begins inside a run that started in an earlier band: find the hull vertex that
+    // owns row0 -- start from the last vertex at or before it and walk down the (unimodal)
+    // values towards earlier vertices.
+    run_lo = lo_carry;
+    const uint32_t above = rsword & 0xFFFFFFFEu;
+    run_hi = above ? row0 + __builtin_ctz(above) - 1 : hi_carry;
+    j = prev_set(acol, C, row0 + 1, run_lo);
+    Fj = (double)tcol[j * C];
+    double vj = para(row0, j, Fj, w2);
+    while (true) {
+      const int jp = prev_set(acol, C, j, run_lo);
+      if (jp < 0) break;
+      const double Fjp = (double)tcol[jp * C];
+      const double vp = para(row0, jp, Fjp, w2);
+      if (!(vp < vj)) break;
+      j = jp; Fj = Fjp; vj = vp;
     }
-    if (hi_carry > n - 1) hi_carry = n - 1;
+    jn = next_vertex(j, row0, aw, run_hi, acol, C);
+    Fjn = (double)tcol[(jn >= 0 ? jn : row0) * C];
   }
 
-  int j = 0, jn = -1, run_lo = 0, run_hi = 0;
-  double Fj = 0.0, Fjn = 0.0;
-  bool left = false, right = false;
+  // Row sweep, wave-uniform control flow only: per-lane decisions are selects, repetition is a
+  // loop on __any(), and the one rare case (the next vertex lies in another band) sits behind
+  // a single __any() test.  `need` marks lanes whose next-vertex register must be (re)loaded.
+  bool need = false;
+  float *dst = Fcol + (int64_t)row0 * st;
 #pragma unroll 1
-  for (int r = 0; r < 32; ++r) {
-    if (!((nzword >> r) & 1u)) continue;
+  for (int r = 0; r < 32; ++r, dst += st) {
+    const bool nz = (nzword >> r) & 1u;
+    if (!__any(nz)) continue;
     const int p = row0 + r;
-    const bool starts = (rsword >> r) & 1u;
-    if (starts || r == 0) {
-      // bounds of the run containing p
-      const uint32_t below = rsword & (0xFFFFFFFFu >> (31 - r));
-      run_lo = below ? row0 + 31 - __builtin_clz(below) : lo_carry;
-      const uint32_t above = (r < 31) ? (rsword & (0xFFFFFFFEu << r)) : 0u;
-      run_hi = above ? row0 + __builtin_ctz(above) - 1 : hi_carry;
-      left = bb || run_lo > 0;
-      right = bb || run_hi < n - 1;
-      if (starts) {
-        j = p;  // first vertex of the run
-        Fj = (double)tcol[p * C];
-      } else {
-        // the run began in an earlier band: start from the last vertex at or before p and walk
-        // down the (unimodal) values towards earlier vertices
-        j = prev_set(acol, C, p + 1, run_lo);
-        Fj = (double)tcol[j * C];
-        double vj = para(p, j, Fj, w2);
-        while (true) {
-          const int jp = prev_set(acol, C, j, run_lo);
-          if (jp < 0) break;
-          const double Fjp = (double)tcol[jp * C];
-          const double vp = para(p, jp, Fjp, w2);
-          if (!(vp < vj)) break;
-          j = jp; Fj = Fjp; vj = vp;
-        }
-      }
-      jn = -1;
-      if (j >= row0) {
-        const uint32_t m = aw & (0xFFFFFFFEu << (j - row0));
-        if (j - row0 < 31 && m) jn = row0 + __builtin_ctz(m);
-        else if (run_hi > row0 + 31) jn = next_set(acol, C, row0 + 31, run_hi);
-      } else {
-        jn = next_set(acol, C, j, run_hi);
-      }
-      if (jn > run_hi) jn = -1;
-      if (jn >= 0) Fjn = (double)tcol[jn * C];
+    const bool start = nz && ((rsword >> r) & 1u);  // a run starts at p: first vertex is p
+    if (__any(start)) {
+      const double Fp = (double)tcol[p * C];
+      const uint32_t above = rsword & (0xFFFFFFFEu << r);
+      const int hi_here = above ? row0 + __builtin_ctz(above | 0x80000000u) - 1 : hi_carry;
+      run_lo = start ? p : run_lo;
+      run_hi = start ? hi_here : run_hi;
+      j = start ? p : j;
+      Fj = start ? Fp : Fj;
+      need = need || start;
     }
     double best = para(p, j, Fj, w2);
-    while (jn >= 0) {
-      const double cand = para(p, jn, Fjn, w2);
-      if (!(cand < best)) break;
-      best = cand;
-      j = jn; Fj = Fjn;
-      // next vertex after j inside the run
-      jn = -1;
-      if (j >= row0 && j - row0 < 31) {
-        const uint32_t m = aw & (0xFFFFFFFEu << (j - row0));
-        if (m) jn = row0 + __builtin_ctz(m);
-        else if (run_hi > row0 + 31) jn = next_set(acol, C, row0 + 31, run_hi);
-      } else {
-        jn = next_set(acol, C, j, run_hi);
+    while (true) {
+      if (__any(need)) {
+        // next hull vertex after j: a bit scan of this thread's own alive word ...
+        const unsigned rj = (unsigned)(j - row0);
+        const uint32_t m = rj < 32u ? (aw & (0xFFFFFFFEu << (rj & 31u))) : 0u;
+        const int q = row0 + __builtin_ctz(m | 0x80000000u);
+        const bool found = m != 0u && q <= run_hi;
+        // ... unless the run continues past this band (or j sits in another band)
+        const bool slow = need && !found && (rj < 32u ? (m == 0u && run_hi > row0 + 31) : true);
+        int jq = found ? q : -1;
+        if (__any(slow)) {
+          if (slow) {
+            jq = next_set(acol, C, rj < 32u ? row0 + 31 : j, run_hi);
+          }
+        }
+        jn = need ? jq : jn;
+        const double Fq = (double)tcol[(jq >= 0 ? jq : p) * C];
+        Fjn = need ? Fq : Fjn;
       }
-      if (jn > run_hi) jn = -1;
-      if (jn >= 0) Fjn = (double)tcol[jn * C];
+      const double cand = para(p, jn, Fjn, w2);
+      const bool adv = nz && jn >= 0 && cand < best;
+      if (!__any(adv)) break;
+      best = adv ? cand : best;
+      j = adv ? jn : j;
+      Fj = adv ? Fjn : Fj;
+      need = adv;
     }
-    // border parabolas of height 0 at run_lo-1 and run_hi+1; fp32 rounding is monotone, so
+    need = false;
+    // border parabolas of height 0 at run_lo-1 and run_hi+1.  fp32 rounding is monotone, so
     // one narrowing of the fp64 minimum equals the reference's separate narrowings
-    if (left) best = fmin(best, w2 * sq_i(p - run_lo + 1));
-    if (right) best = fmin(best, w2 * sq_i(run_hi - p + 1));
-    Fcol[(int64_t)p * st] = finish((float)best, epi);
+    // (src/edt.hpp:233-242, :310-311); the nearer border dominates the farther one.
+    const bool left = bb || run_lo > 0;
+    const bool right = bb || run_hi < n - 1;
+    const int dl = left ? p - run_lo + 1 : 0x7FFF;
+    const int dr = right ? run_hi - p + 1 : 0x7FFF;
+    const int dm = dl < dr ? dl : dr;
+    const double border = w2 * sq_i(dm);
+    best = (left || right) ? fmin(best, border) : best;
+    if (nz) *dst = finish((float)best, epi);
+  }
   }
 }
 
@@ -320,14 +383,14 @@ bool column_pass_tiled_supported(const AxisGeom &g) {
   return g.nbands >= 1 && g.nbands * 8 <= 1024;  // C = 8 is the narrowest tile; rows < 4096
 }
 
-template <int C>
-static int launch_tiled_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                          float w, int bb, int epi, hipStream_t stream) {
+template <int C, int EPI, bool BB>
+static int launch_tiled_ceb(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                            float w, hipStream_t stream) {
   const int NB = (int)g.nbands;
   const size_t lds = (size_t)NB * C * (32 * sizeof(float) + 2 * sizeof(uint32_t));
-  static bool attr_done = false;  // per C instantiation
+  static bool attr_done = false;  // per instantiation
   if (!attr_done) {
-    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_tiled<C>),
+    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_tiled<C, EPI, BB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -335,10 +398,26 @@ static int launch_tiled_c(float *F, const uint32_t *nz, const uint32_t *rs, cons
   const int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL(k_column_pass_tiled<C>, dim3((unsigned)tiles), dim3(C, NB), lds, stream, F, nz,
-                     rs, g, w, bb, epi, (int)tiles_x);
+  hipLaunchKernelGGL((k_column_pass_tiled<C, EPI, BB>), dim3((unsigned)tiles), dim3(C, NB), lds, stream,
+                     F, nz, rs, g, w, (int)tiles_x, debug_mode());
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
+}
+
+template <int C>
+static int launch_tiled_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                          float w, int bb, int epi, hipStream_t stream) {
+  // the fused epilogue and the border rule are compile-time variants of the kernel
+  switch ((epi & 3) * 2 + (bb ? 1 : 0)) {
+    case 0: return launch_tiled_ceb<C, 0, false>(F, nz, rs, g, w, stream);
+    case 1: return launch_tiled_ceb<C, 0, true>(F, nz, rs, g, w, stream);
+    case 2: return launch_tiled_ceb<C, 1, false>(F, nz, rs, g, w, stream);
+    case 3: return launch_tiled_ceb<C, 1, true>(F, nz, rs, g, w, stream);
+    case 4: return launch_tiled_ceb<C, 2, false>(F, nz, rs, g, w, stream);
+    case 5: return launch_tiled_ceb<C, 2, true>(F, nz, rs, g, w, stream);
+    case 6: return launch_tiled_ceb<C, 3, false>(F, nz, rs, g, w, stream);
+    default: return launch_tiled_ceb<C, 3, true>(F, nz, rs, g, w, stream);
+  }
 }
 
 int launch_column_pass_tiled(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,

@@ -120,6 +120,9 @@ int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, 
  * edt_hip_get_pass_times copies the durations (ms) of the last call, in launch order,
  * into `ms` and returns how many there were (names via edt_hip_get_pass_name). */
 int edt_hip_set_profiling(int enabled);
+/* Diagnostics only (never set in production): bit0 makes the column passes move their tile
+ * HBM -> LDS -> HBM without computing, which measures the access-pattern floor of that kernel. */
+int edt_hip_set_debug_mode(int mode);
 int edt_hip_get_pass_times(float *ms, int capacity);
 const char *edt_hip_get_pass_name(int index);
 

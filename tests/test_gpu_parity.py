@@ -242,3 +242,10 @@ def test_long_runs_deep_hulls(edt_gpu, oracle_port):
                 want = oracle_port.edtsq(vol, an, bb)
                 got = edt_gpu.edtsq(vol, anisotropy=an, black_border=bb)
                 assert same(got, want), (name, an, bb, explain(got, want))
+
+
+def test_cpp_drop_in_header_on_gpu(edt_gpu, tmp_path):
+    import subprocess
+    from test_abi import build_cpp_dropin
+    res = subprocess.run([build_cpp_dropin(tmp_path)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr

@@ -126,6 +126,18 @@ static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws) {
   return p;
 }
 
+// In-place LDS-tiled column pass: the wave-autonomous kernel where the axis fits its register
+// budget, the workgroup-phased kernel for longer axes.  (debug bit 16 forces the latter.)
+static bool column_inplace_supported(const AxisGeom &g) {
+  return column_pass_wave_supported(g) || column_pass_tiled_supported(g);
+}
+static int launch_column_inplace(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                                 float w, int bb, int epi, hipStream_t stream) {
+  if (column_pass_wave_supported(g) && !(g_debug_mode & 16))
+    return launch_column_pass_wave(F, nz, rs, g, w, bb, epi, stream);
+  return launch_column_pass_tiled(F, nz, rs, g, w, bb, epi, stream);
+}
+
 static int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
   if (dtype_size(dtype) == 0) { set_error("unknown dtype code"); return EDT_ERR_BAD_ARG; }
   if (ndim < 1 || ndim > 3) { set_error("ndim must be 1, 2 or 3"); return EDT_ERR_BAD_ARG; }
@@ -179,8 +191,8 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   // Column passes are in place when the LDS-tiled kernel applies, otherwise they ping-pong
   // between two volumes.  Start in the buffer that makes the last pass land in d_out.
   const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0;
-  const bool tiled_y = !force_generic && column_pass_tiled_supported(p.gy);
-  const bool tiled_z = !force_generic && column_pass_tiled_supported(p.gz);
+  const bool tiled_y = !force_generic && column_inplace_supported(p.gy);
+  const bool tiled_z = !force_generic && column_inplace_supported(p.gz);
   const int swaps = (tiled_y ? 0 : 1) + ((ndim == 3 && !tiled_z) ? 1 : 0);
   float *cur = (swaps % 2 == 0) ? d_out : p.bufB;
   float *other = (cur == d_out) ? p.bufB : d_out;
@@ -219,7 +231,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     ScopedPass t("y_pass", stream);
     const int epi = ndim == 2 ? last_epi : 0;
     if (tiled_y) {
-      rc = launch_column_pass_tiled(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, stream);
+      rc = launch_column_inplace(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, stream);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_y, p.rs_y, p.stack, p.gy, wy, bb, epi, stream);
       std::swap(cur, other);
@@ -229,7 +241,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   if (ndim == 3) {
     ScopedPass t("z_pass", stream);
     if (tiled_z) {
-      rc = launch_column_pass_tiled(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream);
+      rc = launch_column_inplace(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_z, p.rs_z, p.stack, p.gz, wz, bb, last_epi,
                                      stream);
@@ -480,7 +492,7 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
   const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0;
   const AxisGeom gy = make_geom_y(sx, sy, sz_local);
   const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
-  const bool tiled_y = !force_generic && column_pass_tiled_supported(gy);
+  const bool tiled_y = !force_generic && column_inplace_supported(gy);
   float *xout = tiled_y ? d_partial : p.bufB;  // the tiled y pass runs in place
   if (tiled_x) {
     rc = launch_row_pass_tiled(dtype, d_labels, xout, p.nz, p.rs, nullptr, sx, sy, sz_local, wx, bb,
@@ -492,7 +504,7 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
     rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz, p.rs, gy, stream);
     if (rc != EDT_OK) return rc;
   }
-  if (tiled_y) rc = launch_column_pass_tiled(d_partial, p.nz, p.rs, gy, wy, bb, 0, stream);
+  if (tiled_y) rc = launch_column_inplace(d_partial, p.nz, p.rs, gy, wy, bb, 0, stream);
   else rc = launch_column_pass_serial(p.bufB, d_partial, p.nz, p.rs, p.stack, gy, wy, bb, 0, stream);
   if (rc != EDT_OK) return rc;
   return launch_zflags(dtype, d_labels, d_halo, d_zflags, sx * sy, sz_local, stream);
@@ -516,8 +528,8 @@ int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx
   const AxisGeom gz = make_geom_z(sx, sy_local, sz);
   rc = launch_bits_from_flags(d_zflags, p.nz, p.rs, gz, stream);
   if (rc != EDT_OK) return rc;
-  if (!(flags & EDT_FLAG_FORCE_GENERIC) && column_pass_tiled_supported(gz))
-    return launch_column_pass_tiled(d_partial, p.nz, p.rs, gz, wz, bb, epi, stream);
+  if (!(flags & EDT_FLAG_FORCE_GENERIC) && column_inplace_supported(gz))
+    return launch_column_inplace(d_partial, p.nz, p.rs, gz, wz, bb, epi, stream);
   rc = launch_column_pass_serial(d_partial, p.bufB, p.nz, p.rs, p.stack, gz, wz, bb, epi, stream);
   if (rc != EDT_OK) return rc;
   EDT_HIP_TRY(hipMemcpyAsync(d_partial, p.bufB, (size_t)(sx * sy_local * sz) * sizeof(float),

@@ -1,0 +1,195 @@
+// edt_colwave.hip -- wave-autonomous LDS-tiled column pass (passes 2 and 3) for gfx950.
+//
+// Work decomposition
+//   workgroup = one tile of 32 adjacent columns (128 contiguous bytes per row, so every global
+//               access is a full cache line) x the WHOLE scan axis, staged once in LDS by
+//               direct global->LDS loads (global_load_lds_dwordx4: no VGPR round trip);
+//   wave      = CW = 64/NBP of those columns x all NBP bands (a band = 32 rows): the hull
+//               build, the hull merges and the evaluation of a column only involve lanes of
+//               ONE wave, so after the tile has landed the waves run without any workgroup
+//               barrier and hide each other's LDS/fp64 latencies (the previous design,
+//               edt_tiled.hip, synchronised 1024 threads four times per tile while most of
+//               them idled in the merge rounds);
+//   lane      = (column c, band b): its 32 rows live in VGPRs for the whole kernel.
+// The tile is read from HBM exactly once and written exactly once (8 B/voxel of traffic
+// against 12 B/voxel in the reference's data-movement model, which re-reads the labels).
+//
+// LDS image: fp32 tile [rows][32], the 16-byte granule of a column XOR-rotated by its band
+// (edt_colwave_lane.h: addr_tile) so that "every lane reads its own row" is bank-conflict free;
+// because global_load_lds writes LDS linearly (lane i -> base + 16*i), the rotation is applied
+// to the per-lane SOURCE address, and again when the results are streamed back.
+#include "edt_common.h"
+#include "edt_kernels.h"
+
+#pragma clang fp contract(off)
+
+#define EDT_LANE __device__ __forceinline__
+#include "edt_colwave_lane.h"
+
+namespace edt_amd {
+
+namespace {
+
+__device__ __forceinline__ void wave_sync() {
+  // lanes of one wave exchange data through LDS: the hardware executes a wave's LDS
+  // instructions in order, the fence keeps the compiler from reordering them
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace
+
+template <int CW, int EPI, bool BB>
+__global__ void __launch_bounds__(2048 / CW)
+k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
+                   const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x) {
+  using namespace edt_lane;
+  constexpr int NBP = 64 / CW;  // bands per column handled by a wave (power of two)
+  constexpr int W = 32 / CW;    // waves per workgroup
+  constexpr int K = (CW / 4) & 7;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *tile = reinterpret_cast<float *>(smem);                           // [NBP*32][32]
+  uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * 32 * 32);    // [NBP][32]
+  uint32_t *rsp = alive + NBP * 32;                                        // [NBP][32]
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int n = (int)g.n;
+  const int NB = (int)g.nbands;
+  const int64_t xt = blockIdx.x % tiles_x, o = blockIdx.x / tiles_x;
+  const int64_t x0 = xt * 32;
+  const int64_t st = g.stride;
+  float *Ftile = F + x0 + o * g.outer_stride;
+  const int cols_left = (int)(g.sx - x0);  // columns of this tile that exist (multiple of 4)
+
+  // ---- phase 0: the whole tile, HBM -> LDS --------------------------------------------
+  // one instruction = 64 granules = 8 rows of 128 B; all 8 rows belong to one band
+  for (int i = wave; i < NBP * 4; i += W) {
+    const int row = 8 * i + (lane >> 3);
+    const int slot = lane & 7;
+    const int gg = slot ^ (((i >> 2) * K) & 7);  // global granule that lands in this slot
+    if (row < n && 4 * gg < cols_left) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + 4 * gg),
+          (__attribute__((address_space(3))) void *)(tile + i * 256), 16, 0, 0);
+    }
+  }
+
+  Lane L;
+  L.tile = tile;
+  L.alive = alive;
+  L.rsp = rsp;
+  L.colc = wave * CW + (lane % CW);
+  L.band = lane / CW;
+  L.row0 = L.band * 32;
+  L.n = n;
+  L.w2 = (double)(w * w);  // fp32 product widened (src/edt.hpp:181, :258)
+  L.nzw = 0;
+  L.rsw = 0;
+  const bool active = L.colc < cols_left && L.band < NB;
+  if (active) {
+    const int64_t widx = (o * g.nbands + L.band) * g.sx + x0 + L.colc;
+    L.nzw = nzbits[widx];
+    L.rsw = rsbits[widx];
+  }
+  rsp[addr_word<CW>(L.colc, L.band)] = L.rsw;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- own rows -> registers ---------------------------------------------------------------
+  float f[32];
+  {
+    const float *own = tile + addr_tile<CW>(L.colc, L.row0);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) f[r] = own[r * 32];
+  }
+
+  // ---- phase 1 / 2 / 3 (wave-local) ----------------------------------------------------------
+  uint32_t aw = phase1_hull<CW>(L, f);
+  alive[addr_word<CW>(L.colc, L.band)] = aw;
+  wave_sync();
+#pragma unroll
+  for (int half = 1; half < NBP; half <<= 1) {
+    phase2_merge<CW>(L, half);
+    wave_sync();
+  }
+  aw = alive[addr_word<CW>(L.colc, L.band)];
+  phase3_eval<CW, EPI, BB>(L, aw, f);
+  wave_sync();  // every lane of the wave is done reading the tile
+
+  // ---- results -> LDS (in place) -> HBM ------------------------------------------------------
+  {
+    float *own = tile + addr_tile<CW>(L.colc, L.row0);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) own[r * 32] = f[r];
+  }
+  __syncthreads();
+  for (int i = wave; i < NBP * 4; i += W) {
+    const int row = 8 * i + (lane >> 3);
+    const int slot = lane & 7;
+    const int gg = slot ^ (((i >> 2) * K) & 7);
+    if (row < n && 4 * gg < cols_left) {
+      const float4 v = *reinterpret_cast<const float4 *>(tile + i * 256 + lane * 4);
+      *reinterpret_cast<float4 *>(Ftile + (int64_t)row * st + 4 * gg) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------
+bool column_pass_wave_supported(const AxisGeom &g) {
+  // rows in VGPRs: one band per lane, at most 16 bands per column (n <= 512); 16-byte granules
+  return g.nbands >= 1 && g.nbands <= 16 && (g.sx % 4) == 0 && (g.stride % 4) == 0 &&
+         (g.outer_stride % 4) == 0;
+}
+
+template <int CW, int EPI, bool BB>
+static int launch_wave_ceb(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                           float w, hipStream_t stream) {
+  constexpr int NBP = 64 / CW;
+  const size_t lds = (size_t)NBP * 32 * 32 * sizeof(float) + 2 * (size_t)NBP * 32 * sizeof(uint32_t);
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, EPI, BB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const int64_t tiles_x = ceil_div(g.sx, 32);
+  const int64_t tiles = tiles_x * g.nouter;
+  if (tiles <= 0) return EDT_OK;
+  if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL((k_column_pass_wave<CW, EPI, BB>), dim3((unsigned)tiles), dim3(2048 / CW), lds,
+                     stream, F, nz, rs, g, w, (int)tiles_x);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+template <int CW>
+static int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
+                         int bb, int epi, hipStream_t stream) {
+  switch ((epi & 3) * 2 + (bb ? 1 : 0)) {
+    case 0: return launch_wave_ceb<CW, 0, false>(F, nz, rs, g, w, stream);
+    case 1: return launch_wave_ceb<CW, 0, true>(F, nz, rs, g, w, stream);
+    case 2: return launch_wave_ceb<CW, 1, false>(F, nz, rs, g, w, stream);
+    case 3: return launch_wave_ceb<CW, 1, true>(F, nz, rs, g, w, stream);
+    case 4: return launch_wave_ceb<CW, 2, false>(F, nz, rs, g, w, stream);
+    case 5: return launch_wave_ceb<CW, 2, true>(F, nz, rs, g, w, stream);
+    case 6: return launch_wave_ceb<CW, 3, false>(F, nz, rs, g, w, stream);
+    default: return launch_wave_ceb<CW, 3, true>(F, nz, rs, g, w, stream);
+  }
+}
+
+int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                            float w, int bb, int epi, hipStream_t stream) {
+  const int64_t NB = g.nbands;
+  if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, stream);
+  if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, stream);
+  if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, stream);
+  if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, stream);
+  set_error("axis too long for the wave column pass");
+  return EDT_ERR_UNSUPPORTED;
+}
+
+}  // namespace edt_amd

@@ -69,3 +69,10 @@ int launch_row_pass_tiled(int dtype, const void *labels, float *out, uint32_t *n
 int launch_bits_transpose_yz(const uint32_t *nz_y, const uint32_t *zs_y, uint32_t *nz_z,
                              uint32_t *rs_z, int64_t sx, int64_t sy, int64_t sz, hipStream_t stream);
 }  // namespace edt_amd
+
+namespace edt_amd {
+// ---- wave-autonomous LDS-tiled column pass: edt_colwave.hip -----------------------------------
+bool column_pass_wave_supported(const AxisGeom &g);
+int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                            float w, int bb, int epi, hipStream_t stream);
+}  // namespace edt_amd

@@ -1,0 +1,126 @@
+// tests/lane_emul.cpp -- TEST FIXTURE: lane-by-lane host emulation of the wave-autonomous
+// column pass (euclidean-distance-transform-3d_amd/csrc/edt_colwave_lane.h).
+//
+// The per-lane phases of the HIP kernel are plain functions; this file compiles the SAME header
+// with g++ and plays every lane of every workgroup tile in sequence (phase by phase, which is
+// what the wave-synchronous kernel does), with ordinary arrays standing in for LDS.  It lets
+// the CPU-only test tier check the hull / merge / evaluation logic and the LDS address swizzle
+// against the oracle.  It is never linked into the product library.
+//
+//   g++ -O2 -ffp-contract=off -shared -fPIC -I<csrc> tests/lane_emul.cpp -o liblane_emul.so
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#define EDT_LANE static inline
+#include "edt_colwave_lane.h"
+
+using namespace edt_lane;
+
+namespace {
+
+template <int CW, int EPI, bool BB>
+void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t sx, int n, int NB,
+               int64_t stride, int64_t x0, float w) {
+  constexpr int NBP = 64 / CW;
+  constexpr int W = 32 / CW;
+  constexpr int K = (CW / 4) & 7;
+  std::vector<float> tile((size_t)NBP * 32 * 32, -12345.0f);
+  std::vector<uint32_t> alive((size_t)NBP * 32, 0), rsp((size_t)NBP * 32, 0);
+  const int cols_left = (int)(sx - x0);
+  // phase 0: the swizzled fill, exactly as the kernel addresses it
+  for (int i = 0; i < NBP * 4; ++i)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int row = 8 * i + (lane >> 3), slot = lane & 7;
+      const int gg = slot ^ (((i >> 2) * K) & 7);
+      if (row < n && 4 * gg < cols_left)
+        std::memcpy(&tile[(size_t)i * 256 + lane * 4], F + x0 + (int64_t)row * stride + 4 * gg, 16);
+    }
+  struct PerLane { Lane L; float f[32]; uint32_t aw; };
+  std::vector<PerLane> lanes((size_t)W * 64);
+  for (int wave = 0; wave < W; ++wave)
+    for (int lane = 0; lane < 64; ++lane) {
+      PerLane &P = lanes[(size_t)wave * 64 + lane];
+      Lane &L = P.L;
+      L.tile = tile.data(); L.alive = alive.data(); L.rsp = rsp.data();
+      L.colc = wave * CW + (lane % CW);
+      L.band = lane / CW;
+      L.row0 = L.band * 32;
+      L.n = n;
+      L.w2 = (double)(w * w);
+      L.nzw = 0; L.rsw = 0;
+      if (L.colc < cols_left && L.band < NB) {
+        const int64_t widx = (int64_t)L.band * sx + x0 + L.colc;
+        L.nzw = nzbits[widx];
+        L.rsw = rsbits[widx];
+      }
+      rsp[addr_word<CW>(L.colc, L.band)] = L.rsw;
+    }
+  for (auto &P : lanes) {
+    const float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
+    for (int r = 0; r < 32; ++r) P.f[r] = own[r * 32];
+  }
+  for (auto &P : lanes) {
+    P.aw = phase1_hull<CW>(P.L, P.f);
+    alive[addr_word<CW>(P.L.colc, P.L.band)] = P.aw;
+  }
+  for (int half = 1; half < NBP; half <<= 1)
+    for (auto &P : lanes) phase2_merge<CW>(P.L, half);
+  for (auto &P : lanes) {
+    P.aw = alive[addr_word<CW>(P.L.colc, P.L.band)];
+    phase3_eval<CW, EPI, BB>(P.L, P.aw, P.f);
+  }
+  for (auto &P : lanes) {
+    float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
+    for (int r = 0; r < 32; ++r) own[r * 32] = P.f[r];
+  }
+  for (int i = 0; i < NBP * 4; ++i)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int row = 8 * i + (lane >> 3), slot = lane & 7;
+      const int gg = slot ^ (((i >> 2) * K) & 7);
+      if (row < n && 4 * gg < cols_left)
+        std::memcpy(F + x0 + (int64_t)row * stride + 4 * gg, &tile[(size_t)i * 256 + lane * 4], 16);
+    }
+}
+
+template <int CW>
+void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n, int NB, int64_t stride,
+             float w, int bb, int epi) {
+  for (int64_t x0 = 0; x0 < sx; x0 += 32) {
+#define GO(E, B) tile_pass<CW, E, B>(F, nz, rs, sx, n, NB, stride, x0, w)
+    switch ((epi & 3) * 2 + (bb ? 1 : 0)) {
+      case 0: GO(0, false); break;
+      case 1: GO(0, true); break;
+      case 2: GO(1, false); break;
+      case 3: GO(1, true); break;
+      case 4: GO(2, false); break;
+      case 5: GO(2, true); break;
+      case 6: GO(3, false); break;
+      default: GO(3, true); break;
+    }
+#undef GO
+  }
+}
+
+}  // namespace
+
+// F: [n][sx] fp32 (row stride = sx), in place.  labels: [n][sx] uint32.  Returns 0, or -1 if the
+// shape is outside what the wave kernel supports.
+extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t sx, int64_t n, float w,
+                                     int bb, int epi) {
+  const int NB = (int)((n + 31) / 32);
+  if (NB < 1 || NB > 16 || sx % 4 != 0) return -1;
+  std::vector<uint32_t> nz((size_t)NB * sx, 0), rs((size_t)NB * sx, 0);
+  for (int64_t x = 0; x < sx; ++x)
+    for (int64_t y = 0; y < n; ++y) {
+      const uint32_t lab = labels[y * sx + x];
+      const bool start = (y == 0) || lab != labels[(y - 1) * sx + x];
+      if (lab != 0) nz[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
+      if (start) rs[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
+    }
+  if (NB <= 2) pass_cw<32>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  else if (NB <= 4) pass_cw<16>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  else if (NB <= 8) pass_cw<8>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  else pass_cw<4>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  return 0;
+}

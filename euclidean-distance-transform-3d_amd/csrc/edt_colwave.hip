@@ -37,12 +37,33 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Run structure across the bands of a column: lane = c + CW*band, so "the bands below / above"
+// are the lanes CW, 2*CW, ... away.  Exclusive prefix max of the last run start, exclusive
+// suffix min of the first run start (Hillis-Steele over lane shuffles, log2(NBP) steps each).
+template <int CW>
+__device__ __forceinline__ void scan_runs(edt_lane::Lane &L, int lane) {
+  int x = __shfl_up(edt_lane::band_last_start(L.rsw, L.row0), CW);
+  if (lane < CW) x = -1;
+  int y = __shfl_down(edt_lane::band_first_start(L.rsw, L.row0, L.n) - 1, CW);
+  if (lane >= 64 - CW) y = L.n - 1;
+#pragma unroll
+  for (int d = CW; d < 64; d <<= 1) {
+    const int tx = __shfl_up(x, d);
+    const int ty = __shfl_down(y, d);
+    if (lane >= d) x = tx > x ? tx : x;
+    if (lane + d < 64) y = ty < y ? ty : y;
+  }
+  L.lo_in = x;
+  L.hi_out = y;
+}
+
 }  // namespace
 
-template <int CW, int EPI, bool BB>
+template <int CW, bool BB>
 __global__ void __launch_bounds__(2048 / CW)
 k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
-                   const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x) {
+                   const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x,
+                   int epi, int dbg) {
   using namespace edt_lane;
   constexpr int NBP = 64 / CW;  // bands per column handled by a wave (power of two)
   constexpr int W = 32 / CW;    // waves per workgroup
@@ -93,6 +114,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     L.rsw = rsbits[widx];
   }
   rsp[addr_word<CW>(L.colc, L.band)] = L.rsw;
+  scan_runs<CW>(L, lane);
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -106,16 +128,19 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   }
 
   // ---- phase 1 / 2 / 3 (wave-local) ----------------------------------------------------------
-  uint32_t aw = phase1_hull<CW>(L, f);
+  // (dbg: diagnostics only -- bit1 skips the hull build, bit2 the merges, bit3 the evaluation)
+  uint32_t aw = (dbg & 2) ? L.nzw : phase1_hull<CW>(L, f);
   alive[addr_word<CW>(L.colc, L.band)] = aw;
   wave_sync();
+  if (!(dbg & 4)) {
 #pragma unroll
-  for (int half = 1; half < NBP; half <<= 1) {
-    phase2_merge<CW>(L, half);
-    wave_sync();
+    for (int half = 1; half < NBP; half <<= 1) {
+      phase2_merge<CW>(L, half);
+      wave_sync();
+    }
   }
   aw = alive[addr_word<CW>(L.colc, L.band)];
-  phase3_eval<CW, EPI, BB>(L, aw, f);
+  if (!(dbg & 8)) phase3_eval<CW, BB>(L, aw, f, epi);
   wave_sync();  // every lane of the wave is done reading the tile
 
   // ---- results -> LDS (in place) -> HBM ------------------------------------------------------
@@ -145,14 +170,14 @@ bool column_pass_wave_supported(const AxisGeom &g) {
          (g.outer_stride % 4) == 0;
 }
 
-template <int CW, int EPI, bool BB>
-static int launch_wave_ceb(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                           float w, hipStream_t stream) {
+template <int CW, bool BB>
+static int launch_wave_cb(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
+                          int epi, hipStream_t stream) {
   constexpr int NBP = 64 / CW;
   const size_t lds = (size_t)NBP * 32 * 32 * sizeof(float) + 2 * (size_t)NBP * 32 * sizeof(uint32_t);
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
-    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, EPI, BB>),
+    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -160,8 +185,8 @@ static int launch_wave_ceb(float *F, const uint32_t *nz, const uint32_t *rs, con
   const int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL((k_column_pass_wave<CW, EPI, BB>), dim3((unsigned)tiles), dim3(2048 / CW), lds,
-                     stream, F, nz, rs, g, w, (int)tiles_x);
+  hipLaunchKernelGGL((k_column_pass_wave<CW, BB>), dim3((unsigned)tiles), dim3(2048 / CW), lds, stream,
+                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode());
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }
@@ -169,16 +194,9 @@ static int launch_wave_ceb(float *F, const uint32_t *nz, const uint32_t *rs, con
 template <int CW>
 static int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                          int bb, int epi, hipStream_t stream) {
-  switch ((epi & 3) * 2 + (bb ? 1 : 0)) {
-    case 0: return launch_wave_ceb<CW, 0, false>(F, nz, rs, g, w, stream);
-    case 1: return launch_wave_ceb<CW, 0, true>(F, nz, rs, g, w, stream);
-    case 2: return launch_wave_ceb<CW, 1, false>(F, nz, rs, g, w, stream);
-    case 3: return launch_wave_ceb<CW, 1, true>(F, nz, rs, g, w, stream);
-    case 4: return launch_wave_ceb<CW, 2, false>(F, nz, rs, g, w, stream);
-    case 5: return launch_wave_ceb<CW, 2, true>(F, nz, rs, g, w, stream);
-    case 6: return launch_wave_ceb<CW, 3, false>(F, nz, rs, g, w, stream);
-    default: return launch_wave_ceb<CW, 3, true>(F, nz, rs, g, w, stream);
-  }
+  // the border rule is a compile-time variant of the kernel, the fused epilogue a run-time one
+  return bb ? launch_wave_cb<CW, true>(F, nz, rs, g, w, epi, stream)
+            : launch_wave_cb<CW, false>(F, nz, rs, g, w, epi, stream);
 }
 
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,

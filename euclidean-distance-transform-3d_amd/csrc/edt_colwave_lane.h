@@ -76,18 +76,30 @@ struct Lane {
   int n;                 // rows of the scan axis
   double w2;
   uint32_t nzw, rsw;     // foreground / run-start bits of this lane's 32 rows
+  // run structure carried across bands (one wave-level scan over the column's bands):
+  int lo_in;             // first row of the run that is open when the band begins (last run
+                         //   start in an earlier band; -1 if there is none)
+  int hi_out;            // last row of the run that is open when the band ends (row before the
+                         //   first run start in a later band, n-1 if there is none)
 };
 
-// exact (double)(d*d) for |d| < 4096
-EDT_LANE double sq_i(int d) { return (double)mul24(d, d); }
+// per-band inputs of that scan
+EDT_LANE int band_last_start(uint32_t rsw, int row0) { return rsw ? row0 + 31 - clz32(rsw) : -1; }
+EDT_LANE int band_first_start(uint32_t rsw, int row0, int n) { return rsw ? row0 + ctz32(rsw) : n; }
 
 // value of parabola j (height Fj) at row p -- the reference's output expression
-EDT_LANE double para(int p, int j, double Fj, double w2) { return fma64(w2, sq_i(p - j), Fj); }
+// w2*sq(p-j) + Fj.  d = p - j as a double: w2*d is exact (24 + 12 bits) and the fma multiplies
+// it by d exactly, so the only rounding is the final addition, as in the reference.
+EDT_LANE double para_d(int d, double Fj, double w2) {
+  const double dd = (double)d;
+  return fma64(w2 * dd, dd, Fj);
+}
+EDT_LANE double para(int p, int j, double Fj, double w2) { return para_d(p - j, Fj, w2); }
 
 // numerator of the crossing abscissa of parabolas p < q:  (Fq - Fp) + w2*(q-p)*(q+p)
 // (src/edt.hpp:206-208: ff[i] - ff[v[k]] + factor1 * factor2; the product is exact)
 EDT_LANE double edge_num(int p, double Fp, int q, double Fq, double w2) {
-  return fma64(w2, (double)mul24(q - p, q + p), Fq - Fp);
+  return fma64(w2 * (double)(q - p), (double)(q + p), Fq - Fp);
 }
 
 template <int CW>
@@ -127,57 +139,65 @@ EDT_LANE int next_set(const uint32_t *plane, int colc, int after, int hi) {
 
 // ---------------------------------------------------------------------------------------
 // phase 1: hull of the lane's own band.  f[r] = F(row0 + r) (registers).  Returns the alive
-// word.  The stack of the monotone chain IS the alive word; its top two entries (ia, ib) and
-// the numerator / width of the edge between them are cached in registers.
-//   pop while  s(ib,row) <= s(ia,ib)  <=>  num(ib,row)*(ib-ia) <= num(ia,ib)*(row-ib)
-//   (src/edt.hpp:210, :287).  A stack with fewer than two entries has nab = -inf.
+// word.  The stack of the monotone chain IS the alive word (it starts as the foreground word
+// and loses a bit per pop).  In a run every row is pushed, so when row r is examined the top of
+// the stack is row r-1 (F in a register) and the orientation test
+//     pop while  s(ib,row) <= s(ia,ib)  <=>  num(ib,row)*(ib-ia) <= num(ia,ib)*(row-ib)
+// (src/edt.hpp:210, :287) reduces, for its first and usually only evaluation, to
+//     num(r-1,r) * dab <= nab,     num(r-1,r) = (F[r]-F[r-1]) + w2*(2*row-1)
+// with (nab, dab) = numerator / width of the edge under the top, carried in registers.  Rows
+// whose test cannot fire (background, run start, row after a run start) are masked by `dis`;
+// the pop loop proper is the rare slow path and re-derives the stack from the alive word.
 // ---------------------------------------------------------------------------------------
 template <int CW>
 EDT_LANE uint32_t phase1_hull(const Lane &L, const float *f) {
   const uint32_t rs1 = L.rsw | 1u;  // the band's first row starts a (local) chain
-  const double w2 = L.w2;
-  uint32_t aw = 0, seg = 0xFFFFFFFFu;
-  int ia = L.row0, ib = L.row0;
-  double Fa = 0.0, Fb = 0.0, nab = -INFINITY, dab = 1.0;
+  const uint32_t dis = ~L.nzw | rs1 | (rs1 << 1);
+  const double w2 = L.w2, w2x2 = w2 + w2;
+  uint32_t aw = L.nzw;
+  double nab = -INFINITY, dab = 1.0;
+  double Fb = (double)f[0];
+  double c = w2 * (double)(2 * L.row0 - 1);  // w2*(2*row-1) for row = row0; exact, and so are its updates
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-  for (int r = 0; r < 32; ++r) {
-    if ((L.nzw >> r) & 1u) {
+  for (int r = 1; r < 32; ++r) {
+    c += w2x2;
+    const double Fi = (double)f[r];
+    double nbi = (Fi - Fb) + c;
+    double dbi = 1.0;
+    if (!((dis >> r) & 1u) && nbi * dab <= nab) {
+      // slow path: pop.  top = r-1, the entries below it come from the alive word
       const int row = L.row0 + r;
-      const double Fi = (double)f[r];
-      const bool fresh = (rs1 >> r) & 1u;
-      if (fresh) {
-        nab = -INFINITY;
-        seg = 0xFFFFFFFFu << r;
-      }
-      double nbi = edge_num(ib, Fb, row, Fi, w2);
-      double dbi = (double)(row - ib);
-      while (nbi * dab <= nab * dbi) {  // the top vertex lies on or above the chord
-        aw &= ~(1u << (ib - L.row0));
+      const uint32_t rsm = rs1 & (0xFFFFFFFFu >> (31 - r));
+      const uint32_t segmask = 0xFFFFFFFFu << (31 - clz32(rsm));
+      int ib = r - 1;
+      uint32_t below = aw & segmask & ((1u << ib) - 1u);
+      int ia = 31 - clz32(below);  // exists: the test only fires with two entries on the stack
+      double Fa = ldF<CW>(L, L.row0 + ia);
+      double Ftop = Fb;
+      while (true) {
+        aw &= ~(1u << ib);
         ib = ia;
-        Fb = Fa;
-        nbi = edge_num(ib, Fb, row, Fi, w2);
-        dbi = (double)(row - ib);
-        const uint32_t below = aw & seg & ((1u << (ib - L.row0)) - 1u);
+        Ftop = Fa;
+        below = aw & segmask & ((1u << ib) - 1u);
         if (below) {
-          ia = L.row0 + 31 - clz32(below);
-          Fa = ldF<CW>(L, ia);
-          nab = edge_num(ia, Fa, ib, Fb, w2);
+          ia = 31 - clz32(below);
+          Fa = ldF<CW>(L, L.row0 + ia);
+          nab = edge_num(L.row0 + ia, Fa, L.row0 + ib, Ftop, w2);
           dab = (double)(ib - ia);
         } else {
           nab = -INFINITY;
           dab = 1.0;
         }
+        nbi = edge_num(L.row0 + ib, Ftop, row, Fi, w2);
+        dbi = (double)(r - ib);
+        if (!(nbi * dab <= nab * dbi)) break;
       }
-      aw |= 1u << r;
-      ia = ib;
-      Fa = Fb;
-      nab = fresh ? -INFINITY : nbi;
-      dab = fresh ? 1.0 : dbi;
-      ib = row;
-      Fb = Fi;
     }
+    nab = nbi;  // push r: the edge under the new top is (old top, r)
+    dab = dbi;
+    Fb = Fi;
   }
   return aw;
 }
@@ -197,10 +217,10 @@ EDT_LANE void phase2_merge(const Lane &L, int half) {
   int ghi = (L.band + half) * 32;
   if (ghi > L.n) ghi = L.n;
   ghi -= 1;
-  int Llo = prev_set<CW>(L.rsp, L.colc, R, glo);
-  if (Llo < 0) Llo = glo;
-  const int nxt = next_set<CW>(L.rsp, L.colc, R, ghi);
-  const int Rhi = nxt < 0 ? ghi : nxt - 1;
+  const int Llo = L.lo_in > glo ? L.lo_in : glo;
+  const uint32_t above = L.rsw & 0xFFFFFFFEu;
+  const int run_hi = above ? R + ctz32(above) - 1 : L.hi_out;
+  const int Rhi = run_hi < ghi ? run_hi : ghi;
 
   int u = R - 1;  // last vertex of the left hull (always alive)
   int v = R;      // first vertex of the right hull (always alive)
@@ -239,36 +259,43 @@ EDT_LANE float finish_f(float m, int epi) {
 // ---------------------------------------------------------------------------------------
 // phase 3: evaluate the envelope on the lane's 32 rows.  f[r] holds F(row0+r) on entry and
 // the result on exit (background rows keep their 0).  `aw` = this band's merged alive word.
+//
+// Sweep state (row indices relative to row0, so they may be negative or exceed 31):
+//   jr / Fj    the hull vertex owning the current row,
+//   jnr / Fjn  the next hull vertex of the run (Fjn = +inf when there is none),
+//   awrun      alive bits of this band that belong to the current run,
+//   lo1r/hi1r  the rows just outside the run where a border parabola sits (far away if none).
+// Common path per row: two parabola evaluations, one compare, the border term in fp32.
 // ---------------------------------------------------------------------------------------
-template <int CW, int EPI, bool BB>
-EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f) {
+template <int CW, bool BB>
+EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f, int epi) {
   constexpr int kFar = 1 << 14;  // "no border on this side" distance
   const double w2 = L.w2;
+  const float w2f = (float)w2;  // exactly the fp32 product w*w
   const int row0 = L.row0, n = L.n;
   const uint32_t nzw = L.nzw, rsw = L.rsw;
   if (nzw == 0) return;
+  const int hi_carry = L.hi_out - row0;  // last row (relative) of the run open at the band's end
 
-  // last row of the run that is still open when the band ends
-  int hi_carry = row0 + 31;
-  if (row0 + 31 < n - 1 && (nzw >> 31)) {
-    const int nx = next_set<CW>(L.rsp, L.colc, row0 + 31, n - 1);
-    hi_carry = nx < 0 ? n - 1 : nx - 1;
-  }
-  if (hi_carry > n - 1) hi_carry = n - 1;
-
-  int j = row0, jn = -1, run_hi = row0;
-  int lo1 = -kFar, hi1 = 2 * kFar;  // run_lo - 1 / run_hi + 1 where that side has a border
-  double Fj = 0.0, Fjn = 0.0;
+  // Sweep state.  Distances are carried as floating-point numbers and stepped by +-1 per row
+  // (small integers: exact), which keeps integer->fp conversions out of the per-row path.
+  int jr = 0, jnr = 0, run_hir = 0;
+  uint32_t awrun = 0;
+  double Fj = 0.0, Fjn = INFINITY;
+  double dj = 0.0, dn = 0.0;            // r - jr  and  jnr - r
+  float dl = (float)kFar, dr = (float)(4 * kFar);  // r - (run_lo - 1)  and  (run_hi + 1) - r
+  // (a missing border is a distance >= kFar: dl only grows, dr shrinks by at most n <= 2048)
   if ((nzw & 1u) && !(rsw & 1u)) {
     // The band begins inside a run that started in an earlier band: find the hull vertex that
     // owns row0 -- start from the last vertex at or before it and walk down the (unimodal)
     // values towards earlier vertices.
-    const int run_lo = prev_set<CW>(L.rsp, L.colc, row0, 0);
+    const int run_lo = L.lo_in;
     const uint32_t above = rsw & 0xFFFFFFFEu;
-    run_hi = above ? row0 + ctz32(above) - 1 : hi_carry;
-    lo1 = (BB || run_lo > 0) ? run_lo - 1 : -kFar;
-    hi1 = (BB || run_hi < n - 1) ? run_hi + 1 : 2 * kFar;
-    j = prev_set<CW>(L.alive, L.colc, row0 + 1, run_lo);
+    run_hir = above ? ctz32(above) - 1 : hi_carry;
+    awrun = aw & (0xFFFFFFFFu >> (31 - (run_hir < 31 ? run_hir : 31)));
+    dl = (BB || run_lo > 0) ? (float)(row0 - run_lo + 1) : (float)kFar;
+    dr = (BB || row0 + run_hir < n - 1) ? (float)(run_hir + 1) : (float)(4 * kFar);
+    int j = prev_set<CW>(L.alive, L.colc, row0 + 1, run_lo);
     Fj = ldF<CW>(L, j);
     double vj = para(row0, j, Fj, w2);
     while (true) {
@@ -281,15 +308,22 @@ EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f) {
       Fj = Fjp;
       vj = vp;
     }
+    jr = j - row0;
+    dj = (double)(-jr);
     // next hull vertex after j
-    if (j >= row0) {
-      const uint32_t m = aw & 0xFFFFFFFEu;  // j == row0
-      if (m && row0 + ctz32(m) <= run_hi) jn = row0 + ctz32(m);
-      else jn = run_hi > row0 + 31 ? next_set<CW>(L.alive, L.colc, row0 + 31, run_hi) : -1;
+    int q = -1;
+    if (jr == 0) {
+      const uint32_t m = awrun & 0xFFFFFFFEu;
+      if (m) q = row0 + ctz32(m);
+      else if (run_hir > 31) q = next_set<CW>(L.alive, L.colc, row0 + 31, row0 + run_hir);
     } else {
-      jn = next_set<CW>(L.alive, L.colc, j, run_hi);
+      q = next_set<CW>(L.alive, L.colc, j, row0 + run_hir);
     }
-    Fjn = jn >= 0 ? ldF<CW>(L, jn) : 0.0;
+    if (q >= 0) {
+      jnr = q - row0;
+      dn = (double)jnr;
+      Fjn = ldF<CW>(L, q);
+    }
   }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -297,56 +331,79 @@ EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f) {
 #endif
   for (int r = 0; r < 32; ++r) {
     if ((nzw >> r) & 1u) {
-      const int p = row0 + r;
-      bool need = false;  // jn / Fjn must be (re)loaded
-      if ((rsw >> r) & 1u) {  // a run starts at p: its first hull vertex is p
+      if ((rsw >> r) & 1u) {  // a run starts at this row: its first hull vertex is the row itself
         const uint32_t above = r < 31 ? (rsw & (0xFFFFFFFEu << r)) : 0u;
-        run_hi = above ? row0 + ctz32(above) - 1 : hi_carry;
-        lo1 = (BB || p > 0) ? p - 1 : -kFar;
-        hi1 = (BB || run_hi < n - 1) ? run_hi + 1 : 2 * kFar;
-        j = p;
+        run_hir = above ? ctz32(above) - 1 : hi_carry;
+        awrun = aw & (0xFFFFFFFFu >> (31 - (run_hir < 31 ? run_hir : 31))) & (0xFFFFFFFFu << r);
+        dl = (BB || row0 + r > 0) ? 1.0f : (float)kFar;
+        dr = (BB || row0 + run_hir < n - 1) ? (float)(run_hir + 1 - r) : (float)(4 * kFar);
+        jr = r;
+        dj = 0.0;
         Fj = (double)f[r];
-        need = true;
-      }
-      double best = para(p, j, Fj, w2);
-      while (true) {
-        if (need) {
-          // next hull vertex after j: a bit scan of this lane's own alive word ...
-          const unsigned rj = (unsigned)(j - row0);
-          int q = -1;
-          if (rj < 32u) {
-            const uint32_t m = rj < 31u ? (aw & (0xFFFFFFFEu << rj)) : 0u;
-            if (m != 0u) {
-              q = row0 + ctz32(m);
-              if (q > run_hi) q = -1;
-            } else if (run_hi > row0 + 31) {
-              // ... unless the run continues past this band
-              q = next_set<CW>(L.alive, L.colc, row0 + 31, run_hi);
-            }
-          } else {  // j sits in an earlier band
-            q = next_set<CW>(L.alive, L.colc, j, run_hi);
+        const uint32_t m = r < 31 ? (awrun & (0xFFFFFFFEu << r)) : 0u;
+        Fjn = INFINITY;
+        if (m) {
+          jnr = ctz32(m);
+          Fjn = ldF<CW>(L, row0 + jnr);
+        } else if (run_hir > 31) {
+          const int q = next_set<CW>(L.alive, L.colc, row0 + 31, row0 + run_hir);
+          if (q >= 0) {
+            jnr = q - row0;
+            Fjn = ldF<CW>(L, q);
           }
-          jn = q;
-          if (q == p + 1 && r < 31) Fjn = (double)f[r < 31 ? r + 1 : r];  // still the input value
-          else if (q >= 0) Fjn = ldF<CW>(L, q);
-          need = false;
         }
-        if (jn < 0) break;
-        const double cand = para(p, jn, Fjn, w2);
-        if (!(cand < best)) break;
-        best = cand;
-        j = jn;
-        Fj = Fjn;
-        need = true;
+        dn = (double)(jnr - r);
       }
-      // border parabolas of height 0 just outside the run.  fp32 rounding is monotone, so one
-      // narrowing of the fp64 minimum equals the reference's separate narrowings
-      // (src/edt.hpp:233-242, :310-311); the nearer border dominates the farther one.
-      const int dl = p - lo1, dr = hi1 - p;
-      const int dm = dl < dr ? dl : dr;
-      if (dm < kFar) best = fmin(best, w2 * sq_i(dm));
-      f[r] = finish_f((float)best, EPI);
+      double best = fma64(w2 * dj, dj, Fj);
+      double cand = fma64(w2 * dn, dn, Fjn);
+      while (cand < best) {  // the next vertex takes over (Fjn = +inf never does)
+        best = cand;
+        jr = jnr;
+        Fj = Fjn;
+        dj = -dn;
+        Fjn = INFINITY;
+        const uint32_t m = (unsigned)jr < 31u ? (awrun & (0xFFFFFFFEu << jr)) : 0u;
+        if (m) {
+          jnr = ctz32(m);
+          if (jnr == r + 1 && r < 31) Fjn = (double)f[r < 31 ? r + 1 : r];  // still the input value
+          else Fjn = ldF<CW>(L, row0 + jnr);
+        } else if (jr < 0 || run_hir > 31) {
+          // the owner still sits in an earlier band, or the run continues past this band
+          const int q = next_set<CW>(L.alive, L.colc, (jr < 0 || jr >= 31) ? row0 + jr : row0 + 31,
+                                     row0 + run_hir);
+          if (q >= 0) {
+            jnr = q - row0;
+            Fjn = ldF<CW>(L, q);
+          }
+        }
+        dn = (double)(jnr - r);
+        cand = fma64(w2 * dn, dn, Fjn);
+      }
+      // border parabolas of height 0 just outside the run (src/edt.hpp:233-242, :310-311):
+      // fl32(w2 * d^2) is one exact-product fp32 multiply; the nearer border dominates.
+      float res = (float)best;
+      const float dm = fminf(dl, dr);
+      if (BB || dm < (float)kFar) res = fminf(res, w2f * (dm * dm));
+      f[r] = res;
     }
+    dj += 1.0;
+    dn -= 1.0;
+    dl += 1.0f;
+    dr -= 1.0f;
+  }
+  // fused epilogue of the last pass, as whole-band loops behind wave-uniform branches (inside
+  // the row loop the compiler would evaluate the sqrt sequence unconditionally and select)
+  if (epi & kLaneEpiToInf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 32; ++r) f[r] = f[r] >= 3.402823466e+38f ? INFINITY : f[r];
+  }
+  if (epi & kLaneEpiSqrt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 32; ++r) f[r] = sqrtf(f[r]);
   }
 }
 

@@ -19,9 +19,9 @@ using namespace edt_lane;
 
 namespace {
 
-template <int CW, int EPI, bool BB>
+template <int CW, bool BB>
 void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t sx, int n, int NB,
-               int64_t stride, int64_t x0, float w) {
+               int64_t stride, int64_t x0, float w, int epi) {
   constexpr int NBP = 64 / CW;
   constexpr int W = 32 / CW;
   constexpr int K = (CW / 4) & 7;
@@ -56,6 +56,21 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
       }
       rsp[addr_word<CW>(L.colc, L.band)] = L.rsw;
     }
+  // the wave-level scan over the bands of a column (the kernel does it with lane shuffles)
+  for (auto &P : lanes) {
+    P.L.lo_in = -1;
+    P.L.hi_out = n - 1;
+    for (auto &Q : lanes) {
+      if (Q.L.colc != P.L.colc) continue;
+      if (Q.L.band < P.L.band) {
+        const int v = band_last_start(Q.L.rsw, Q.L.row0);
+        if (v > P.L.lo_in) P.L.lo_in = v;
+      } else if (Q.L.band > P.L.band) {
+        const int v = band_first_start(Q.L.rsw, Q.L.row0, n) - 1;
+        if (v < P.L.hi_out) P.L.hi_out = v;
+      }
+    }
+  }
   for (auto &P : lanes) {
     const float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
     for (int r = 0; r < 32; ++r) P.f[r] = own[r * 32];
@@ -68,7 +83,7 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
     for (auto &P : lanes) phase2_merge<CW>(P.L, half);
   for (auto &P : lanes) {
     P.aw = alive[addr_word<CW>(P.L.colc, P.L.band)];
-    phase3_eval<CW, EPI, BB>(P.L, P.aw, P.f);
+    phase3_eval<CW, BB>(P.L, P.aw, P.f, epi);
   }
   for (auto &P : lanes) {
     float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
@@ -87,18 +102,8 @@ template <int CW>
 void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n, int NB, int64_t stride,
              float w, int bb, int epi) {
   for (int64_t x0 = 0; x0 < sx; x0 += 32) {
-#define GO(E, B) tile_pass<CW, E, B>(F, nz, rs, sx, n, NB, stride, x0, w)
-    switch ((epi & 3) * 2 + (bb ? 1 : 0)) {
-      case 0: GO(0, false); break;
-      case 1: GO(0, true); break;
-      case 2: GO(1, false); break;
-      case 3: GO(1, true); break;
-      case 4: GO(2, false); break;
-      case 5: GO(2, true); break;
-      case 6: GO(3, false); break;
-      default: GO(3, true); break;
-    }
-#undef GO
+    if (bb) tile_pass<CW, true>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3);
+    else tile_pass<CW, false>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3);
   }
 }
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools_pmc.sh <tag> [bench args...]  -- PMC passes (each in its own rocprofv3 run, kernel-trace only)
 tag=$1; shift
+maxpass=${PMC_PASSES:-6}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for ctrs in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
@@ -10,6 +11,7 @@ for ctrs in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
             "WRITE_SIZE GRBM_GUI_ACTIVE" \
             "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   i=$((i+1))
+  if [ $i -gt $maxpass ]; then break; fi
   rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/pmc_${tag}_$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/pmc_${tag}_$i.log 2>&1
   echo "pass $i rc=$?"
 done

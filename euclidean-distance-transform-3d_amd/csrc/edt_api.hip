@@ -138,6 +138,16 @@ static int launch_column_inplace(float *F, const uint32_t *nz, const uint32_t *r
   return launch_column_pass_tiled(F, nz, rs, g, w, bb, epi, stream);
 }
 
+// Pass 1 with the bit planes of the column passes as a by-product: the register-resident kernel
+// for rows up to 512 voxels, the LDS-staged one for longer rows.  (debug bit 32 forces the latter.)
+static int launch_row_bits(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
+                           uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
+                           int to_finite, hipStream_t stream) {
+  if (row_pass_wave_supported(dtype, sx, sy, sz) && !(g_debug_mode & 32))
+    return launch_row_pass_wave(dtype, labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream);
+  return launch_row_pass_tiled(dtype, labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream);
+}
+
 static int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
   if (dtype_size(dtype) == 0) { set_error("unknown dtype code"); return EDT_ERR_BAD_ARG; }
   if (ndim < 1 || ndim > 3) { set_error("ndim must be 1, 2 or 3"); return EDT_ERR_BAD_ARG; }
@@ -201,8 +211,8 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     // labels are read once: pass 1 also emits the run bit-planes of the y and z axes
     {
       ScopedPass t("x_pass", stream);
-      rc = launch_row_pass_tiled(dtype, d_labels, cur, p.nz_y, p.rs_y, ndim == 3 ? p.zs_y : nullptr, sx,
-                                 sy, sz, wx, bb, bb ? 0 : 1, stream);
+      rc = launch_row_bits(dtype, d_labels, cur, p.nz_y, p.rs_y, ndim == 3 ? p.zs_y : nullptr, sx, sy, sz,
+                           wx, bb, bb ? 0 : 1, stream);
       if (rc != EDT_OK) return rc;
     }
     if (ndim == 3) {
@@ -495,8 +505,8 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
   const bool tiled_y = !force_generic && column_inplace_supported(gy);
   float *xout = tiled_y ? d_partial : p.bufB;  // the tiled y pass runs in place
   if (tiled_x) {
-    rc = launch_row_pass_tiled(dtype, d_labels, xout, p.nz, p.rs, nullptr, sx, sy, sz_local, wx, bb,
-                               bb ? 0 : 1, stream);
+    rc = launch_row_bits(dtype, d_labels, xout, p.nz, p.rs, nullptr, sx, sy, sz_local, wx, bb, bb ? 0 : 1,
+                         stream);
     if (rc != EDT_OK) return rc;
   } else {
     rc = launch_row_pass_serial(dtype, d_labels, xout, sx, sy * sz_local, wx, bb, bb ? 0 : 1, 0, stream);

@@ -76,3 +76,11 @@ bool column_pass_wave_supported(const AxisGeom &g);
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                             float w, int bb, int epi, hipStream_t stream);
 }  // namespace edt_amd
+
+namespace edt_amd {
+// ---- register-resident pass 1 (rows up to 512 voxels): edt_rowwave.hip -------------------------
+bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz);
+int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
+                         uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
+                         int to_finite, hipStream_t stream);
+}  // namespace edt_amd

@@ -1,0 +1,248 @@
+// edt_rowwave.hip -- pass 1 (x axis) for gfx950, register-resident: one wavefront per group of
+// 32 consecutive rows of one z-slice, rows up to 512 voxels (8 chunks of 64 lanes).
+//
+// Pass 1 is a label-aware 1-D distance along contiguous rows.  The reference walks each row
+// twice with fp32 recurrences (src/edt.hpp:83-118); the result has the closed form
+//     d(i) = min( L, R ),   L = T[i-s+1]  (if a boundary exists on the left,  else +inf)
+//                           R = T[e-i+1]  (if a boundary exists on the right, else +inf)
+//     T[0] = 0, T[k] = fl32(T[k-1] + w)        (the SAME sequential fp32 sums)
+// for a voxel i inside the maximal run [s,e] of one non-zero label, and F = fl32(d*d).
+//
+// The kernel is bound by VALU issue, not by HBM, so everything that can live on the scalar
+// unit does: a row is 8 wave-wide compares ("label differs from its left neighbour") whose
+// results ARE the 64-bit run-start masks, held in SGPRs; run starts / ends that lie in another
+// chunk are carried with scalar find-first-bit instructions; per voxel only the bit scan of
+// its own chunk mask, two table look-ups (T lives in LDS), a min and a multiply remain.
+//
+// The same sweep emits, per voxel, the three bits the column passes need, so that labels are
+// read from HBM exactly ONCE by the whole pipeline:
+//     nz : label != 0
+//     ys : label differs from the voxel at y-1 (run start along y)
+//     zs : label differs from the voxel at z-1 (run start along z)
+// packed 32 consecutive y per word, layout [z][y/32][x].  A lane builds its three words with
+// one add-with-carry per row: w = 2*w + (this row's compare bit), the compare mask being the
+// carry-in -- the words come out bit-reversed and are flipped once at the end.
+#include "edt_common.h"
+#include "edt_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace edt_amd {
+
+namespace {
+
+constexpr int kRowWaves = 4;  // waves per workgroup (they only share the T table)
+
+// w = 2*w + bit(lane) of `mask`
+__device__ __forceinline__ void shift_in(uint32_t &w, unsigned long long mask) {
+  asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(w) : "s"(mask) : "vcc");
+}
+
+__device__ __forceinline__ int as_int(float v) { return __float_as_int(v); }
+
+// Buffer addressing: a wave-uniform descriptor (SGPRs) + a wave-uniform byte offset (the row) +
+// a per-lane 32-bit byte offset (the voxel).  Unlike flat 64-bit per-lane pointers this keeps the
+// 24 loads of a row down to 16 offset registers and no address arithmetic at all.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ T buf_load(rsrc_t r, uint32_t voff, uint32_t soff) {
+  if constexpr (sizeof(T) == 1) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0));
+  else if constexpr (sizeof(T) == 2) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0));
+  else if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+}  // namespace
+
+template <typename T, int NC, bool HAS_Z>
+__global__ void __launch_bounds__(kRowWaves * 64)
+k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t *__restrict__ nz_y,
+                uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, float w,
+                int bb, int to_finite, int nby, int ngroups) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *Ttab = reinterpret_cast<float *>(smem);  // [sx + 3]: T[0..sx+1], then +inf
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+
+  // The reference's sequential fp32 sums of the voxel size (src/edt.hpp:97, :113).
+  if (threadIdx.x == 0) {
+    float acc = 0.0f;
+    Ttab[0] = 0.0f;
+    for (int k = 1; k <= sx + 1; ++k) {
+      acc = acc + w;
+      Ttab[k] = acc;
+    }
+    Ttab[sx + 2] = INFINITY;
+  }
+  __syncthreads();
+
+  const int idx_inf = sx + 2;
+  const int64_t sxy = (int64_t)sx * sy;
+  const unsigned long long le_mask = ~0ull >> (63 - lane);  // bits 0..lane
+  const unsigned long long gt_mask = ~le_mask;              // bits lane+1..63
+  const int flim = to_finite ? 0x7f7fffff : 0x7f800000;     // FLT_MAX / +inf bit patterns
+
+  for (int grp = (int)blockIdx.x * kRowWaves + wave; grp < ngroups; grp += (int)gridDim.x * kRowWaves) {
+    const int z = grp / nby, yb = grp - z * nby;
+    const int y0 = yb * 32;
+    const int nrows = (sy - y0) < 32 ? (sy - y0) : 32;
+    const T *base = labels + ((int64_t)z * sy + y0) * sx;  // row y0 of this slice
+    float *obase = out + ((int64_t)z * sy + y0) * sx;
+    const rsrc_t rs_lab = make_rsrc(base);
+    const rsrc_t rs_bel = make_rsrc((HAS_Z && z > 0) ? base - sxy : base);
+    const rsrc_t rs_out = make_rsrc(obase);
+
+    uint32_t xs[NC], xl[NC];  // per-lane BYTE offsets inside a row
+    T above[NC];
+    uint32_t nzw[NC], ysw[NC], zsw[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int x = c * 64 + lane;
+      // every load is unconditional, clamped to a voxel that exists; lanes past the end of the row
+      // read the last voxel as their own AND as their left neighbour, so they never mark a start
+      xs[c] = (uint32_t)(x < sx ? x : sx - 1) * (uint32_t)sizeof(T);
+      xl[c] = (uint32_t)(x < sx ? (x > 0 ? x - 1 : 0) : sx - 1) * (uint32_t)sizeof(T);
+      nzw[c] = 0; ysw[c] = 0; zsw[c] = 0;
+      above[c] = y0 > 0 ? buf_load<T>(make_rsrc(base - sx), xs[c], 0) : T(0);
+    }
+
+#pragma unroll 1
+    for (int r = 0; r < nrows; ++r) {
+      const uint32_t soff = (uint32_t)(r * sx) * (uint32_t)sizeof(T);  // wave-uniform row offset
+      T lab[NC], left[NC], below[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        lab[c] = buf_load<T>(rs_lab, xs[c], soff);
+        left[c] = buf_load<T>(rs_lab, xl[c], soff);
+        below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], soff) : lab[c];
+      }
+      // ---- compares -> masks (SGPRs), bit words --------------------------------------------
+      unsigned long long M[NC], FG[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        M[c] = __ballot(lab[c] != left[c]);
+        FG[c] = __ballot(lab[c] != T(0));
+        shift_in(nzw[c], FG[c]);
+        shift_in(ysw[c], __ballot(lab[c] != above[c]));
+        if (HAS_Z) shift_in(zsw[c], __ballot(lab[c] != below[c]));
+        above[c] = lab[c];
+      }
+      // voxel 0 starts a run; without a black border that run has no boundary on its left,
+      // which is expressed by NOT marking it and carrying a start position far to the left
+      if (bb) M[0] |= 1ull; else M[0] &= ~1ull;
+      // ---- run starts / ends carried across chunks (scalar unit) ----------------------------
+      int pre[NC], suf[NC];
+      {
+        int last = bb ? 0 : -(1 << 20);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          pre[c] = last;
+          if (M[c]) last = c * 64 + 63 - __builtin_clzll(M[c]);
+        }
+        int nxt = bb ? sx : (1 << 20);
+#pragma unroll
+        for (int c = NC - 1; c >= 0; --c) {
+          suf[c] = nxt;
+          if (M[c]) nxt = c * 64 + __builtin_ctzll(M[c]);
+        }
+      }
+      // ---- distances ---------------------------------------------------------------------------
+      const uint32_t ooff = (uint32_t)(r * sx) * 4u;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int x = c * 64 + lane;
+        const unsigned long long m1 = M[c] & le_mask;
+        const unsigned long long m2 = M[c] & gt_mask;
+        const int s = m1 ? c * 64 + 63 - __builtin_clzll(m1) : pre[c];   // first voxel of the run
+        const int e1 = m2 ? c * 64 + __builtin_ctzll(m2) : suf[c];        // one past its last voxel
+        int il = x - s + 1, ir = e1 - x;
+        il = il < idx_inf ? il : idx_inf;
+        ir = ir < idx_inf ? ir : idx_inf;
+        const int dL = as_int(Ttab[il]), dR = as_int(Ttab[ir]);
+        const float d = __int_as_float(dL < dR ? dL : dR);  // positive floats order like integers
+        int f = as_int(d * d);
+        f = f < flim ? f : flim;                             // tofinite (src/edt.hpp:39-45)
+        f = ((FG[c] >> lane) & 1ull) ? f : 0;
+        if (x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)f, rs_out, (uint32_t)x * 4u, ooff, 0);
+      }
+    }
+
+    // ---- the three bit words of this (z, y-band) -----------------------------------------------
+    const int sh = 32 - nrows;
+    const int64_t wbase = ((int64_t)z * nby + yb) * sx;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int x = c * 64 + lane;
+      if (x < sx) {
+        // row 0 of the volume starts a run along y, slice 0 starts every run along z
+        const uint32_t ys = (__brev(ysw[c]) >> sh) | (y0 == 0 ? 1u : 0u);
+        const uint32_t zs = z == 0 ? (0xFFFFFFFFu >> sh) : (__brev(zsw[c]) >> sh);
+        nz_y[wbase + x] = __brev(nzw[c]) >> sh;
+        ys_y[wbase + x] = ys;
+        if (HAS_Z) zs_y[wbase + x] = zs;
+      }
+    }
+  }
+}
+
+bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
+  return sx >= 1 && sx <= 512 && sy * sz < (int64_t)1 << 30 && sx * sy * sz < ((int64_t)1 << 40);
+}
+
+template <typename T, int NC>
+static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
+                              uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
+                              int to_finite, hipStream_t stream) {
+  const int64_t nby = ceil_div(sy, kBandRows);
+  const int64_t ngroups = nby * sz;
+  if (ngroups <= 0) return EDT_OK;
+  const size_t lds = (size_t)(sx + 3) * sizeof(float);
+  int64_t blocks = ceil_div(ngroups, kRowWaves);
+  const int64_t resident = 256 * 8;  // persistent grid: the T table is built once per workgroup
+  if (blocks > resident) blocks = resident;
+  if (zs_y != nullptr)
+    hipLaunchKernelGGL((k_row_pass_wave<T, NC, true>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds,
+                       stream, (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb,
+                       to_finite, (int)nby, (int)ngroups);
+  else
+    hipLaunchKernelGGL((k_row_pass_wave<T, NC, false>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds,
+                       stream, (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb,
+                       to_finite, (int)nby, (int)ngroups);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+template <typename T>
+static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
+                             uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
+                             int to_finite, hipStream_t stream) {
+  const int64_t nc = ceil_div(sx, 64);
+#define GO(N) return launch_row_wave_tn<T, N>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream)
+  if (nc <= 1) GO(1);
+  if (nc <= 2) GO(2);
+  if (nc <= 4) GO(4);
+  GO(8);
+#undef GO
+}
+
+int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
+                         uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
+                         int to_finite, hipStream_t stream) {
+#define ROW_WAVE(T) \
+  return launch_row_wave_t<T>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream)
+  switch (dtype) {
+    case EDT_U8: case EDT_BOOL: ROW_WAVE(uint8_t);
+    case EDT_U16: ROW_WAVE(uint16_t);
+    case EDT_U32: ROW_WAVE(uint32_t);
+    case EDT_U64: ROW_WAVE(uint64_t);
+    case EDT_F32: ROW_WAVE(float);
+    case EDT_F64: ROW_WAVE(double);
+    default: set_error("unknown dtype"); return EDT_ERR_BAD_ARG;
+  }
+#undef ROW_WAVE
+}
+
+}  // namespace edt_amd

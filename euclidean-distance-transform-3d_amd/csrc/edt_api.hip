@@ -127,13 +127,13 @@ static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws) {
 }
 
 // In-place LDS-tiled column pass: the wave-autonomous kernel where the axis fits its register
-// budget, the workgroup-phased kernel for longer axes.  (debug bit 16 forces the latter.)
+// budget, the workgroup-phased kernel for longer axes.  (debug bit 64 forces the latter.)
 static bool column_inplace_supported(const AxisGeom &g) {
   return column_pass_wave_supported(g) || column_pass_tiled_supported(g);
 }
 static int launch_column_inplace(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                                  float w, int bb, int epi, hipStream_t stream) {
-  if (column_pass_wave_supported(g) && !(g_debug_mode & 16))
+  if (column_pass_wave_supported(g) && !(g_debug_mode & 64))
     return launch_column_pass_wave(F, nz, rs, g, w, bb, epi, stream);
   return launch_column_pass_tiled(F, nz, rs, g, w, bb, epi, stream);
 }

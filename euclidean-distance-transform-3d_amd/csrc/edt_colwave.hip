@@ -60,7 +60,7 @@ __device__ __forceinline__ void scan_runs(edt_lane::Lane &L, int lane) {
 }  // namespace
 
 template <int CW, bool BB>
-__global__ void __launch_bounds__(2048 / CW)
+__global__ void __launch_bounds__(2048 / CW, 4)
 k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
                    const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x,
                    int epi, int dbg) {
@@ -129,7 +129,9 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 
   // ---- phase 1 / 2 / 3 (wave-local) ----------------------------------------------------------
   // (dbg: diagnostics only -- bit1 skips the hull build, bit2 the merges, bit3 the evaluation)
-  uint32_t aw = (dbg & 2) ? L.nzw : phase1_hull<CW>(L, f);
+  uint32_t flat = 0;
+  const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
+  uint32_t aw = (dbg & 2) ? L.nzw : phase1_hull<CW>(L, f, fprev, flat);
   alive[addr_word<CW>(L.colc, L.band)] = aw;
   wave_sync();
   if (!(dbg & 4)) {
@@ -140,6 +142,16 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     }
   }
   aw = alive[addr_word<CW>(L.colc, L.band)];
+  {
+    // self-owned rows need bit 31 of the band below and bit 0 of the band above
+    uint32_t prev31 = __shfl_up(aw >> 31, CW);
+    uint32_t next0 = __shfl_down((L.nzw & 1u) | ((L.rsw & 1u) << 1) | ((aw & 1u) << 2) | ((flat & 1u) << 3), CW);
+    if (lane < CW) prev31 = 0;
+    if (lane >= 64 - CW) next0 = 0;
+    L.own = own_mask(L.nzw, L.rsw, aw, flat, prev31, next0 & 1u, (next0 >> 1) & 1u, (next0 >> 2) & 1u,
+                     (next0 >> 3) & 1u);
+    if (dbg & 16) L.own = 0;  // diagnostics: no self-owned shortcut
+  }
   if (!(dbg & 8)) phase3_eval<CW, BB>(L, aw, f, epi);
   wave_sync();  // every lane of the wave is done reading the tile
 

@@ -42,11 +42,23 @@ namespace edt_lane {
 constexpr int kTileCols = 32;  // columns of a workgroup tile = floats per LDS tile row
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// w = 2*w + cond: one add-with-carry whose carry-in is the wave-wide compare mask.  Being a
+// volatile asm it also pins the accumulation to the row it belongs to (written as plain C the
+// compiler gathers the 32 compares into an OR tree at the end and keeps every operand alive).
+#define EDT_SHIFT_IN(w, cond)                                                                  \
+  asm volatile("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(w) : "s"(__ballot(cond)) : "vcc")
+EDT_LANE uint32_t brev32(uint32_t v) { return __brev(v); }
 EDT_LANE int mul24(int a, int b) { return __mul24(a, b); }
 EDT_LANE int clz32(uint32_t v) { return __builtin_clz(v); }
 EDT_LANE int ctz32(uint32_t v) { return __builtin_ctz(v); }
 EDT_LANE double fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #else
+#define EDT_SHIFT_IN(w, cond) (w) = ((w) << 1) | ((cond) ? 1u : 0u)
+EDT_LANE uint32_t brev32(uint32_t v) {
+  uint32_t r = 0;
+  for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
 EDT_LANE int mul24(int a, int b) { return a * b; }
 EDT_LANE int clz32(uint32_t v) { return __builtin_clz(v); }
 EDT_LANE int ctz32(uint32_t v) { return __builtin_ctz(v); }
@@ -81,6 +93,7 @@ struct Lane {
                          //   start in an earlier band; -1 if there is none)
   int hi_out;            // last row of the run that is open when the band ends (row before the
                          //   first run start in a later band, n-1 if there is none)
+  uint32_t own;          // rows of this band that are self-owned (own_mask), set after the merges
 };
 
 // per-band inputs of that scan
@@ -150,13 +163,17 @@ EDT_LANE int next_set(const uint32_t *plane, int colc, int after, int hi) {
 // the pop loop proper is the rare slow path and re-derives the stack from the alive word.
 // ---------------------------------------------------------------------------------------
 template <int CW>
-EDT_LANE uint32_t phase1_hull(const Lane &L, const float *f) {
+EDT_LANE uint32_t phase1_hull(const Lane &L, const float *f, float fprev, uint32_t &flat) {
   const uint32_t rs1 = L.rsw | 1u;  // the band's first row starts a (local) chain
   const uint32_t dis = ~L.nzw | rs1 | (rs1 << 1);
   const double w2 = L.w2, w2x2 = w2 + w2;
   uint32_t aw = L.nzw;
   double nab = -INFINITY, dab = 1.0;
   double Fb = (double)f[0];
+  // flat bit r: |F[r] - F[r-1]| <= w2 (exact in fp64).  Where that holds on both sides of an
+  // alive row, the row's own parabola is the envelope there (see own_mask).
+  uint32_t fl = 0;  // built most-significant-row first, flipped at the end
+  EDT_SHIFT_IN(fl, fabs(Fb - (double)fprev) <= w2);
   double c = w2 * (double)(2 * L.row0 - 1);  // w2*(2*row-1) for row = row0; exact, and so are its updates
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -164,7 +181,9 @@ EDT_LANE uint32_t phase1_hull(const Lane &L, const float *f) {
   for (int r = 1; r < 32; ++r) {
     c += w2x2;
     const double Fi = (double)f[r];
-    double nbi = (Fi - Fb) + c;
+    const double t = Fi - Fb;
+    EDT_SHIFT_IN(fl, fabs(t) <= w2);
+    double nbi = t + c;
     double dbi = 1.0;
     if (!((dis >> r) & 1u) && nbi * dab <= nab) {
       // slow path: pop.  top = r-1, the entries below it come from the alive word
@@ -199,7 +218,29 @@ EDT_LANE uint32_t phase1_hull(const Lane &L, const float *f) {
     dab = dbi;
     Fb = Fi;
   }
+  flat = brev32(fl);
   return aw;
+}
+
+// ---------------------------------------------------------------------------------------
+// Rows whose own parabola is the envelope value at the row itself ("self-owned").  On a lower
+// hull the values para(p, j) over consecutive vertices j are unimodal, so vertex p owns row p
+// iff it is no worse there than its two hull neighbours; when those are the adjacent rows that
+// is |F[p] - F[p-1]| <= w2 and |F[p+1] - F[p]| <= w2 (the `flat` bits) -- a side that ends the
+// run has no neighbour (the border parabola is min'ed in separately).  Inputs are this band's
+// words plus bit 31 of the band below and bit 0 of the band above (0 where there is none).
+// ---------------------------------------------------------------------------------------
+EDT_LANE uint32_t own_mask(uint32_t nzw, uint32_t rsw, uint32_t aw, uint32_t flat, uint32_t aw_prev31,
+                           uint32_t nz_next0, uint32_t rs_next0, uint32_t aw_next0, uint32_t flat_next0) {
+  const uint32_t alive_m1 = (aw << 1) | (aw_prev31 & 1u);
+  const uint32_t alive_p1 = (aw >> 1) | (aw_next0 << 31);
+  const uint32_t flat_p1 = (flat >> 1) | (flat_next0 << 31);
+  const uint32_t nz_p1 = (nzw >> 1) | (nz_next0 << 31);
+  const uint32_t rs_p1 = (rsw >> 1) | (rs_next0 << 31);
+  const uint32_t ends = rs_p1 | ~nz_p1;  // the run ends at this row
+  const uint32_t P = rsw | (alive_m1 & flat);
+  const uint32_t N = ends | (alive_p1 & flat_p1);
+  return nzw & aw & P & N;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -267,127 +308,132 @@ EDT_LANE float finish_f(float m, int epi) {
 //   lo1r/hi1r  the rows just outside the run where a border parabola sits (far away if none).
 // Common path per row: two parabola evaluations, one compare, the border term in fp32.
 // ---------------------------------------------------------------------------------------
+// next hull vertex after the one at relative row jr (run up to run_hir, alive bits of this band that
+// belong to the run in awrun).  r = the row being evaluated; fnext = F(row0+r+1) from a register.
+template <int CW>
+EDT_LANE void find_next(const Lane &L, int jr, int r, uint32_t awrun, int run_hir, float fnext,
+                        int &jnr, double &Fjn, double &dn) {
+  const int row0 = L.row0;
+  Fjn = INFINITY;
+  const uint32_t m = (unsigned)jr < 31u ? (awrun & (0xFFFFFFFEu << jr)) : 0u;
+  if (m) {
+    jnr = ctz32(m);
+    if (jnr == r + 1) Fjn = (double)fnext;  // still the input value
+    else Fjn = ldF<CW>(L, row0 + jnr);
+  } else if (jr < 0 || run_hir > 31) {
+    // the owner still sits in an earlier band, or the run continues past this band
+    const int q = next_set<CW>(L.alive, L.colc, (jr < 0 || jr >= 31) ? row0 + jr : row0 + 31,
+                               row0 + run_hir);
+    if (q >= 0) {
+      jnr = q - row0;
+      Fjn = ldF<CW>(L, q);
+    }
+  }
+  dn = (double)(jnr - r);
+}
+
 template <int CW, bool BB>
 EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f, int epi) {
   constexpr int kFar = 1 << 14;  // "no border on this side" distance
   const double w2 = L.w2;
   const float w2f = (float)w2;  // exactly the fp32 product w*w
   const int row0 = L.row0, n = L.n;
-  const uint32_t nzw = L.nzw, rsw = L.rsw;
+  const uint32_t nzw = L.nzw, rsw = L.rsw, own = L.own;
   if (nzw == 0) return;
   const int hi_carry = L.hi_out - row0;  // last row (relative) of the run open at the band's end
 
-  // Sweep state.  Distances are carried as floating-point numbers and stepped by +-1 per row
-  // (small integers: exact), which keeps integer->fp conversions out of the per-row path.
-  int jr = 0, jnr = 0, run_hir = 0;
+  // Run state (every foreground row): run_hir, awrun, and the distances to the rows just outside
+  // the run where a border parabola sits, as floats stepped by +-1 per row (a missing border is
+  // a distance >= kFar: dl only grows, dr shrinks by at most n <= 2048).
+  int run_hir = 0;
   uint32_t awrun = 0;
-  double Fj = 0.0, Fjn = INFINITY;
-  double dj = 0.0, dn = 0.0;            // r - jr  and  jnr - r
-  float dl = (float)kFar, dr = (float)(4 * kFar);  // r - (run_lo - 1)  and  (run_hi + 1) - r
-  // (a missing border is a distance >= kFar: dl only grows, dr shrinks by at most n <= 2048)
-  if ((nzw & 1u) && !(rsw & 1u)) {
-    // The band begins inside a run that started in an earlier band: find the hull vertex that
-    // owns row0 -- start from the last vertex at or before it and walk down the (unimodal)
-    // values towards earlier vertices.
+  float dl = (float)kFar, dr = (float)(4 * kFar);
+  const bool midrun = (nzw & 1u) && !(rsw & 1u);  // the band begins inside a run of an earlier band
+  if (midrun) {
     const int run_lo = L.lo_in;
     const uint32_t above = rsw & 0xFFFFFFFEu;
     run_hir = above ? ctz32(above) - 1 : hi_carry;
     awrun = aw & (0xFFFFFFFFu >> (31 - (run_hir < 31 ? run_hir : 31)));
     dl = (BB || run_lo > 0) ? (float)(row0 - run_lo + 1) : (float)kFar;
     dr = (BB || row0 + run_hir < n - 1) ? (float)(run_hir + 1) : (float)(4 * kFar);
-    int j = prev_set<CW>(L.alive, L.colc, row0 + 1, run_lo);
-    Fj = ldF<CW>(L, j);
-    double vj = para(row0, j, Fj, w2);
-    while (true) {
-      const int jp = prev_set<CW>(L.alive, L.colc, j, run_lo);
-      if (jp < 0) break;
-      const double Fjp = ldF<CW>(L, jp);
-      const double vp = para(row0, jp, Fjp, w2);
-      if (!(vp < vj)) break;
-      j = jp;
-      Fj = Fjp;
-      vj = vp;
-    }
-    jr = j - row0;
-    dj = (double)(-jr);
-    // next hull vertex after j
-    int q = -1;
-    if (jr == 0) {
-      const uint32_t m = awrun & 0xFFFFFFFEu;
-      if (m) q = row0 + ctz32(m);
-      else if (run_hir > 31) q = next_set<CW>(L.alive, L.colc, row0 + 31, row0 + run_hir);
-    } else {
-      q = next_set<CW>(L.alive, L.colc, j, row0 + run_hir);
-    }
-    if (q >= 0) {
-      jnr = q - row0;
-      dn = (double)jnr;
-      Fjn = ldF<CW>(L, q);
-    }
   }
+  // Sweep state (only kept across consecutive rows that are NOT self-owned): owner vertex jr / Fj,
+  // next vertex jnr / Fjn (Fjn = +inf: none), and dj = r - jr, dn = jnr - r as doubles.
+  int jr = 0, jnr = 0;
+  double Fj = 0.0, Fjn = INFINITY, dj = 0.0, dn = 0.0;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
   for (int r = 0; r < 32; ++r) {
     if ((nzw >> r) & 1u) {
-      if ((rsw >> r) & 1u) {  // a run starts at this row: its first hull vertex is the row itself
+      const bool fresh = (rsw >> r) & 1u;
+      if (fresh) {  // a run starts at this row
         const uint32_t above = r < 31 ? (rsw & (0xFFFFFFFEu << r)) : 0u;
         run_hir = above ? ctz32(above) - 1 : hi_carry;
         awrun = aw & (0xFFFFFFFFu >> (31 - (run_hir < 31 ? run_hir : 31))) & (0xFFFFFFFFu << r);
         dl = (BB || row0 + r > 0) ? 1.0f : (float)kFar;
         dr = (BB || row0 + run_hir < n - 1) ? (float)(run_hir + 1 - r) : (float)(4 * kFar);
-        jr = r;
-        dj = 0.0;
-        Fj = (double)f[r];
-        const uint32_t m = r < 31 ? (awrun & (0xFFFFFFFEu << r)) : 0u;
-        Fjn = INFINITY;
-        if (m) {
-          jnr = ctz32(m);
-          Fjn = ldF<CW>(L, row0 + jnr);
-        } else if (run_hir > 31) {
-          const int q = next_set<CW>(L.alive, L.colc, row0 + 31, row0 + run_hir);
-          if (q >= 0) {
-            jnr = q - row0;
-            Fjn = ldF<CW>(L, q);
-          }
-        }
-        dn = (double)(jnr - r);
       }
-      double best = fma64(w2 * dj, dj, Fj);
-      double cand = fma64(w2 * dn, dn, Fjn);
-      while (cand < best) {  // the next vertex takes over (Fjn = +inf never does)
-        best = cand;
-        jr = jnr;
-        Fj = Fjn;
-        dj = -dn;
-        Fjn = INFINITY;
-        const uint32_t m = (unsigned)jr < 31u ? (awrun & (0xFFFFFFFEu << jr)) : 0u;
-        if (m) {
-          jnr = ctz32(m);
-          if (jnr == r + 1 && r < 31) Fjn = (double)f[r < 31 ? r + 1 : r];  // still the input value
-          else Fjn = ldF<CW>(L, row0 + jnr);
-        } else if (jr < 0 || run_hir > 31) {
-          // the owner still sits in an earlier band, or the run continues past this band
-          const int q = next_set<CW>(L.alive, L.colc, (jr < 0 || jr >= 31) ? row0 + jr : row0 + 31,
-                                     row0 + run_hir);
-          if (q >= 0) {
-            jnr = q - row0;
-            Fjn = ldF<CW>(L, q);
+      float res;
+      if ((own >> r) & 1u) {
+        res = f[r];  // the row's own parabola is the envelope here: no fp64 work at all
+      } else {
+        const float fnext = f[r < 31 ? r + 1 : r];
+        // (re)establish the sweep state where the previous row did not leave one
+        bool need = false;  // the next vertex must be (re)loaded
+        if (r == 0 && !fresh) {
+          // The band begins inside a run: find the hull vertex that owns row0 -- start from the
+          // last vertex at or before it and walk down the (unimodal) values towards earlier ones.
+          const int run_lo = L.lo_in;
+          int j = prev_set<CW>(L.alive, L.colc, row0 + 1, run_lo);
+          Fj = ldF<CW>(L, j);
+          double vj = para(row0, j, Fj, w2);
+          while (true) {
+            const int jp = prev_set<CW>(L.alive, L.colc, j, run_lo);
+            if (jp < 0) break;
+            const double Fjp = ldF<CW>(L, jp);
+            const double vp = para(row0, jp, Fjp, w2);
+            if (!(vp < vj)) break;
+            j = jp;
+            Fj = Fjp;
+            vj = vp;
           }
+          jr = j - row0;
+          dj = (double)(-jr);
+          need = true;
+        } else if (fresh) {
+          jr = r;  // the first hull vertex of a run is its first row
+          dj = 0.0;
+          Fj = (double)f[r];
+          need = true;
+        } else if ((own >> (r > 0 ? r - 1 : 0)) & 1u) {
+          jr = r - 1;  // the previous row owned itself (its register already holds the result)
+          dj = 1.0;
+          Fj = ldF<CW>(L, row0 + r - 1);
+          need = true;
         }
-        dn = (double)(jnr - r);
-        cand = fma64(w2 * dn, dn, Fjn);
+        double best = fma64(w2 * dj, dj, Fj);
+        while (true) {
+          if (need) find_next<CW>(L, jr, r, awrun, run_hir, fnext, jnr, Fjn, dn);
+          const double cand = fma64(w2 * dn, dn, Fjn);
+          if (!(cand < best)) break;  // (Fjn = +inf never wins)
+          best = cand;  // the next vertex takes over
+          jr = jnr;
+          Fj = Fjn;
+          dj = -dn;
+          need = true;
+        }
+        res = (float)best;
+        dj += 1.0;
+        dn -= 1.0;
       }
       // border parabolas of height 0 just outside the run (src/edt.hpp:233-242, :310-311):
       // fl32(w2 * d^2) is one exact-product fp32 multiply; the nearer border dominates.
-      float res = (float)best;
       const float dm = fminf(dl, dr);
       if (BB || dm < (float)kFar) res = fminf(res, w2f * (dm * dm));
       f[r] = res;
     }
-    dj += 1.0;
-    dn -= 1.0;
     dl += 1.0f;
     dr -= 1.0f;
   }

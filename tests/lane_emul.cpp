@@ -36,7 +36,7 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
       if (row < n && 4 * gg < cols_left)
         std::memcpy(&tile[(size_t)i * 256 + lane * 4], F + x0 + (int64_t)row * stride + 4 * gg, 16);
     }
-  struct PerLane { Lane L; float f[32]; uint32_t aw; };
+  struct PerLane { Lane L; float f[32]; uint32_t aw, flat; };
   std::vector<PerLane> lanes((size_t)W * 64);
   for (int wave = 0; wave < W; ++wave)
     for (int lane = 0; lane < 64; ++lane) {
@@ -75,16 +75,27 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
     const float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
     for (int r = 0; r < 32; ++r) P.f[r] = own[r * 32];
   }
+  auto lane_of = [&](int colc, int band) -> PerLane * {
+    for (auto &Q : lanes)
+      if (Q.L.colc == colc && Q.L.band == band) return &Q;
+    return nullptr;
+  };
   for (auto &P : lanes) {
-    P.aw = phase1_hull<CW>(P.L, P.f);
+    PerLane *below = lane_of(P.L.colc, P.L.band - 1);  // the kernel gets these through lane shuffles
+    const float fprev = below ? below->f[31] : 0.0f;
+    P.aw = phase1_hull<CW>(P.L, P.f, fprev, P.flat);
     alive[addr_word<CW>(P.L.colc, P.L.band)] = P.aw;
   }
   for (int half = 1; half < NBP; half <<= 1)
     for (auto &P : lanes) phase2_merge<CW>(P.L, half);
+  for (auto &P : lanes) P.aw = alive[addr_word<CW>(P.L.colc, P.L.band)];
   for (auto &P : lanes) {
-    P.aw = alive[addr_word<CW>(P.L.colc, P.L.band)];
-    phase3_eval<CW, BB>(P.L, P.aw, P.f, epi);
+    PerLane *below = lane_of(P.L.colc, P.L.band - 1), *above = lane_of(P.L.colc, P.L.band + 1);
+    P.L.own = own_mask(P.L.nzw, P.L.rsw, P.aw, P.flat, below ? below->aw >> 31 : 0u,
+                       above ? above->L.nzw & 1u : 0u, above ? above->L.rsw & 1u : 0u,
+                       above ? above->aw & 1u : 0u, above ? above->flat & 1u : 0u);
   }
+  for (auto &P : lanes) phase3_eval<CW, BB>(P.L, P.aw, P.f, epi);
   for (auto &P : lanes) {
     float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
     for (int r = 0; r < 32; ++r) own[r * 32] = P.f[r];

@@ -22,7 +22,7 @@ t = timeit(lambda: a.sum()); print(f"torch sum 512MB (read only): {t*1e3:.3f} ms
 t = timeit(lambda: b.fill_(1.0)); print(f"torch fill 512MB (write only): {t*1e3:.3f} ms  {a.numel()*4/t/1e12:.2f} TB/s")
 lab = torch.ones((n, n, n), dtype=torch.int32, device=dev); out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
 plan = device.Plan((n, n, n), 2, dev)
-for mode in (0, 2, 4, 8, 2|4, 2|4|8):
+for mode in (0, 16, 2, 4, 8, 2|4|8):
     lib.edt_hip_set_debug_mode(mode)
     device.set_profiling(True)
     acc = {}

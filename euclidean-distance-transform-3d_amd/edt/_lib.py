@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libedt_hip.so")
+# EDT_HIP_LIB overrides the in-tree library (used to A/B kernel variants; never a CPU fallback)
+LIB_PATH = os.environ.get("EDT_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libedt_hip.so")
 
 # dtype codes of include/edt_hip.h
 U8, U16, U32, U64, F32, F64, BOOL = range(7)

@@ -13,11 +13,12 @@
 namespace edt_amd {
 
 static thread_local std::string g_last_error = "";
+static int g_debug_mode = 0;
 
 void set_error(const std::string &msg) { g_last_error = msg; }
-
-static int g_debug_mode = 0;
 int debug_mode() { return g_debug_mode; }
+
+
 
 // ---- per-pass event timing (bench.py reads this) -------------------------------------
 struct PassLog {
@@ -43,6 +44,7 @@ struct ScopedPass {
   hipStream_t stream;
   int start = -1;
   ScopedPass(const char *name, hipStream_t s) : stream(s) {
+    if (g_debug_mode & 0x1000) fprintf(stderr, "[edt_hip] pass start: %s\n", name);
     if (!g_log.enabled) return;
     hipEvent_t e = log_event();
     if (!e) return;
@@ -51,6 +53,10 @@ struct ScopedPass {
     g_log.names.push_back(name);
   }
   ~ScopedPass() {
+    if (g_debug_mode & 0x1000) {  // diagnostics: name every pass as it completes
+      const hipError_t e = hipStreamSynchronize(stream);
+      fprintf(stderr, "[edt_hip] pass done: %s\n", hipGetErrorString(e));
+    }
     if (start < 0) return;
     hipEvent_t e = log_event();
     if (!e) return;
@@ -87,6 +93,8 @@ struct Plan {
   float *bufB = nullptr;
   int32_t *stack = nullptr;
   uint32_t *nz_y = nullptr, *rs_y = nullptr, *zs_y = nullptr, *nz_z = nullptr, *rs_z = nullptr;
+  void *xrec = nullptr;   // per-row run records of pass 1 (fused X+Y path)
+  float *ttab = nullptr;  // T[0..sx+2]
   size_t bytes = 0;
 };
 
@@ -121,6 +129,10 @@ static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws) {
     p.nz_z = c.take<uint32_t>(wz);
     p.rs_z = c.take<uint32_t>(wz);
     p.zs_y = c.take<uint32_t>((size_t)(p.gy.sx * p.gy.nbands * p.gy.nouter));
+  }
+  if (ndim >= 2) {
+    p.xrec = c.take<unsigned char>(row_records_bytes(sx, sy, sz));
+    p.ttab = c.take<float>((size_t)sx + 3);
   }
   p.bytes = align_up(c.off, 256) + 256;
   return p;
@@ -207,7 +219,25 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   float *cur = (swaps % 2 == 0) ? d_out : p.bufB;
   float *other = (cur == d_out) ? p.bufB : d_out;
   const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
-  if (tiled_x) {
+  // Fused X+Y: pass 1 only emits bit planes and per-row run records, the first column pass rebuilds
+  // F from them (no fp32 volume is written by pass 1 or read by pass 2).  MEASURED SLOWER on MI355X
+  // (0.905 vs 0.83 ms per 512^3 step: both kernels are bound by instruction issue, not by HBM, so
+  // trading 1 GB of traffic for ~25 more instructions per voxel loses) -- kept behind debug bit 128.
+  const bool fused_xy = !force_generic && (g_debug_mode & 128) && !(g_debug_mode & (64 | 32)) && sx <= 512 &&
+                        row_pass_wave_supported(dtype, sx, sy, sz) && column_pass_wave_supported(p.gy);
+  if (fused_xy) {
+    {
+      ScopedPass t("x_bits", stream);
+      rc = launch_row_records(dtype, d_labels, p.xrec, p.ttab, p.nz_y, p.rs_y, ndim == 3 ? p.zs_y : nullptr,
+                              sx, sy, sz, wx, bb, stream);
+      if (rc != EDT_OK) return rc;
+    }
+    if (ndim == 3) {
+      ScopedPass t("z_bits", stream);
+      rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
+      if (rc != EDT_OK) return rc;
+    }
+  } else if (tiled_x) {
     // labels are read once: pass 1 also emits the run bit-planes of the y and z axes
     {
       ScopedPass t("x_pass", stream);
@@ -240,7 +270,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   {
     ScopedPass t("y_pass", stream);
     const int epi = ndim == 2 ? last_epi : 0;
-    if (tiled_y) {
+    if (fused_xy) {
+      rc = launch_column_pass_wave_xfused(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, p.xrec, p.ttab,
+                                          bb ? 0 : 1, stream);
+    } else if (tiled_y) {
       rc = launch_column_inplace(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, stream);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_y, p.rs_y, p.stack, p.gy, wy, bb, epi, stream);

@@ -69,11 +69,21 @@ __device__ __forceinline__ void scan_runs(edt_lane::Lane &L, int lane) {
 
 }  // namespace
 
-template <int CW, bool BB>
+// Arguments of the fused pass 1 (XF kernels): the per-row run records written by k_row_bits
+// ([outer][chunk][row], 16 B each), the table T of sequential fp32 sums of wx, and its limits.
+struct XFuse {
+  const edt_lane::XRowMeta *meta;
+  const float *ttab;
+  int nchunks;   // 64-voxel chunks per row
+  int idx_inf;   // index of the +inf entry of T (= sx + 2)
+  int flim;      // bit pattern of FLT_MAX (tofinite) or +inf
+};
+
+template <int CW, bool BB, bool XF>
 __global__ void __launch_bounds__(2048 / CW, 4)
 k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
                    const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x,
-                   int epi, int dbg) {
+                   int epi, int dbg, XFuse xf) {
   using namespace edt_lane;
   constexpr int NBP = 64 / CW;  // bands per column handled by a wave (power of two)
   constexpr int W = 32 / CW;    // waves per workgroup
@@ -82,6 +92,10 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   float *tile = reinterpret_cast<float *>(smem);                           // [NBP*32][32]
   uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * 32 * 32);    // [NBP][32]
   uint32_t *rsp = alive + NBP * 32;                                        // [NBP][32]
+  // XF only: row records, one spare slot per band so that the bands of a half-wave read
+  // different banks ([33*NBP] x 16 B), then the table T ([sx+3] floats)
+  XRowMeta *xrec = reinterpret_cast<XRowMeta *>(rsp + NBP * 32);
+  float *xT = reinterpret_cast<float *>(xrec + 33 * NBP);
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
@@ -93,17 +107,24 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   float *Ftile = F + x0 + o * g.outer_stride;
   const int cols_left = (int)(g.sx - x0);  // columns of this tile that exist (multiple of 4)
 
-  // ---- phase 0: the whole tile, HBM -> LDS --------------------------------------------
-  // one instruction = 64 granules = 8 rows of 128 B; all 8 rows belong to one band
-  for (int i = wave; i < NBP * 4; i += W) {
-    const int row = 8 * i + (lane >> 3);
-    const int slot = lane & 7;
-    const int gg = slot ^ (((i >> 2) * K) & 7);  // global granule that lands in this slot
-    if (row < n && 4 * gg < cols_left) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + 4 * gg),
-          (__attribute__((address_space(3))) void *)(tile + i * 256), 16, 0, EDT_TILE_LOAD_AUX);
+  if constexpr (!XF) {
+    // ---- phase 0: the whole tile, HBM -> LDS --------------------------------------------
+    // one instruction = 64 granules = 8 rows of 128 B; all 8 rows belong to one band
+    for (int i = wave; i < NBP * 4; i += W) {
+      const int row = 8 * i + (lane >> 3);
+      const int slot = lane & 7;
+      const int gg = slot ^ (((i >> 2) * K) & 7);  // global granule that lands in this slot
+      if (row < n && 4 * gg < cols_left) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + 4 * gg),
+            (__attribute__((address_space(3))) void *)(tile + i * 256), 16, 0, EDT_TILE_LOAD_AUX);
+      }
     }
+  } else {
+    // ---- phase 0 (fused pass 1): the row records of this tile's chunk and the table T -> LDS ----
+    const XRowMeta *recs = xf.meta + ((int64_t)o * xf.nchunks + (x0 >> 6)) * n;
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) xrec[i + (i >> 5)] = recs[i];
+    for (int i = (int)threadIdx.x; i < xf.idx_inf + 1; i += (int)blockDim.x) xT[i] = xf.ttab[i];
   }
 
   Lane L;
@@ -131,10 +152,24 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 
   // ---- own rows -> registers ---------------------------------------------------------------
   float f[32];
-  {
+  if constexpr (!XF) {
     const float *own = tile + addr_tile<CW>(L.colc, L.row0);
 #pragma unroll
     for (int r = 0; r < 32; ++r) f[r] = own[r * 32];
+  } else {
+    // pass 1 rebuilt from the row records (edt_colwave_lane.h: xpass_value), published in the tile
+    // for the hull look-ups of the other lanes of this wave
+    float *own = tile + addr_tile<CW>(L.colc, L.row0);
+    const int h = (int)((x0 >> 5) & 1), cbase = (int)(x0 & ~(int64_t)63);
+    const XRowMeta *rec = xrec + L.row0 + L.band;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      float v = 0.0f;
+      if (L.row0 + r < n) v = xpass_value(rec[r], h, cbase, L.colc, xT, xf.idx_inf, xf.flim, (L.nzw >> r) & 1u);
+      f[r] = v;
+      own[r * 32] = v;
+    }
+    wave_sync();
   }
 
   // ---- phase 1 / 2 / 3 (wave-local) ----------------------------------------------------------
@@ -193,14 +228,15 @@ bool column_pass_wave_supported(const AxisGeom &g) {
          (g.outer_stride % 4) == 0;
 }
 
-template <int CW, bool BB>
-static int launch_wave_cb(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
-                          int epi, hipStream_t stream) {
+template <int CW, bool BB, bool XF>
+static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
+                           int epi, const XFuse &xf, hipStream_t stream) {
   constexpr int NBP = 64 / CW;
-  const size_t lds = (size_t)NBP * 32 * 32 * sizeof(float) + 2 * (size_t)NBP * 32 * sizeof(uint32_t);
+  size_t lds = (size_t)NBP * 32 * 32 * sizeof(float) + 2 * (size_t)NBP * 32 * sizeof(uint32_t);
+  if (XF) lds += (size_t)33 * NBP * sizeof(edt_lane::XRowMeta) + (size_t)(xf.idx_inf + 1) * sizeof(float);
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
-    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB>),
+    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -208,29 +244,52 @@ static int launch_wave_cb(float *F, const uint32_t *nz, const uint32_t *rs, cons
   const int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL((k_column_pass_wave<CW, BB>), dim3((unsigned)tiles), dim3(2048 / CW), lds, stream,
-                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode());
+  hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF>), dim3((unsigned)tiles), dim3(2048 / CW), lds, stream,
+                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), xf);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }
 
 template <int CW>
 static int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
-                         int bb, int epi, hipStream_t stream) {
-  // the border rule is a compile-time variant of the kernel, the fused epilogue a run-time one
-  return bb ? launch_wave_cb<CW, true>(F, nz, rs, g, w, epi, stream)
-            : launch_wave_cb<CW, false>(F, nz, rs, g, w, epi, stream);
+                         int bb, int epi, const XFuse *xf, hipStream_t stream) {
+  // the border rule and the fused pass 1 are compile-time variants, the epilogue a run-time one
+  const XFuse none = {nullptr, nullptr, 0, 0, 0};
+  if (xf)
+    return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream)
+              : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream);
+  return bb ? launch_wave_cbx<CW, true, false>(F, nz, rs, g, w, epi, none, stream)
+            : launch_wave_cbx<CW, false, false>(F, nz, rs, g, w, epi, none, stream);
+}
+
+static int launch_wave_any(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
+                           int bb, int epi, const XFuse *xf, hipStream_t stream) {
+  const int64_t NB = g.nbands;
+  if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, xf, stream);
+  if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream);
+  if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream);
+  if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream);
+  set_error("axis too long for the wave column pass");
+  return EDT_ERR_UNSUPPORTED;
 }
 
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                             float w, int bb, int epi, hipStream_t stream) {
-  const int64_t NB = g.nbands;
-  if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, stream);
-  if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, stream);
-  if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, stream);
-  if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, stream);
-  set_error("axis too long for the wave column pass");
-  return EDT_ERR_UNSUPPORTED;
+  return launch_wave_any(F, nz, rs, g, w, bb, epi, nullptr, stream);
+}
+
+// First column pass with pass 1 fused in: F is only written.  `meta` = row records of k_row_bits,
+// `ttab` = T[0..sx+2] (sequential fp32 sums of wx, +inf at sx+2), to_finite as in pass 1.
+int launch_column_pass_wave_xfused(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                                   float w, int bb, int epi, const void *meta, const float *ttab,
+                                   int to_finite, hipStream_t stream) {
+  XFuse xf;
+  xf.meta = static_cast<const edt_lane::XRowMeta *>(meta);
+  xf.ttab = ttab;
+  xf.nchunks = (int)ceil_div(g.sx, 64);
+  xf.idx_inf = (int)g.sx + 2;
+  xf.flim = to_finite ? 0x7f7fffff : 0x7f800000;
+  return launch_wave_any(F, nz, rs, g, w, bb, epi, &xf, stream);
 }
 
 }  // namespace edt_amd

@@ -32,6 +32,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #ifndef EDT_LANE
 #error "define EDT_LANE (function qualifiers) before including edt_colwave_lane.h"
@@ -95,6 +96,61 @@ struct Lane {
                          //   first run start in a later band, n-1 if there is none)
   uint32_t own;          // rows of this band that are self-owned (own_mask), set after the merges
 };
+
+// ---------------------------------------------------------------------------------------
+// Pass 1 fused into the first column pass.  Pass 1 (src/edt.hpp:70-119) has the closed form
+//     F = fl32(d*d),  d = min(T[x-s+1], T[e-x+1]),  T[k] = k-fold sequential fp32 sum of wx,
+// for a voxel x inside the maximal run [s,e] of one non-zero label (a side without a boundary
+// contributes +inf).  So a row of pass-1 output is fully described by its run-start bits:
+// the bit kernel (edt_rowwave.hip) stores, per row and 64-voxel chunk, 16 bytes
+//     { start mask (64 bits), last start before the chunk, first start after the chunk }
+// and the column kernel rebuilds F for its 32 columns of the row from ONE such record instead
+// of reading 128 bytes of fp32 -- pass 1 never writes F to HBM and pass 2 never reads it.
+// "No boundary on this side" is a start position far outside the row (+-2^20): the table index
+// saturates at idx_inf, where T holds +inf.
+// ---------------------------------------------------------------------------------------
+struct XRowMeta {
+  uint32_t lo, hi;  // run starts of the chunk's voxels 0..31 / 32..63
+  int pre;          // position of the last run start before the chunk
+  int suf;          // position of the first run start after the chunk
+};
+
+// F(x0 + col) for the row described by `m`; the tile covers half `h` (0/1) of the chunk that
+// begins at voxel `cbase`; T / idx_inf as above; flim = bit pattern of FLT_MAX (tofinite,
+// src/edt.hpp:39-45) or of +inf; nz = the voxel is foreground.
+EDT_LANE float xpass_value(const XRowMeta &m, int h, int cbase, int col, const float *T, int idx_inf,
+                           int flim, bool nz) {
+  const uint32_t W = h ? m.hi : m.lo;
+  const int x0 = cbase + 32 * h;
+  const int fpre = h ? (m.lo ? cbase + 31 - clz32(m.lo) : m.pre) : m.pre;
+  const int fsuf = h ? m.suf : (m.hi ? cbase + 32 + ctz32(m.hi) : m.suf);
+  const uint32_t m1 = W & (0xFFFFFFFFu >> (31 - col));            // starts at or before the voxel
+  const uint32_t m2 = col < 31 ? (W & (0xFFFFFFFEu << col)) : 0u;  // starts after it
+  const int x = x0 + col;
+  const int s = m1 ? x0 + 31 - clz32(m1) : fpre;  // first voxel of the run
+  const int e1 = m2 ? x0 + ctz32(m2) : fsuf;      // one past its last voxel
+  int il = x - s + 1, ir = e1 - x;
+  il = il < idx_inf ? il : idx_inf;
+  ir = ir < idx_inf ? ir : idx_inf;
+  // non-negative floats order like their bit patterns: integer min / clamp, no NaN handling
+  int dl, dr;
+  {
+    const float tl = T[il], tr = T[ir];
+    memcpy(&dl, &tl, 4);
+    memcpy(&dr, &tr, 4);
+  }
+  const int dbits = dl < dr ? dl : dr;
+  float d;
+  memcpy(&d, &dbits, 4);
+  const float sq = d * d;
+  int f;
+  memcpy(&f, &sq, 4);
+  f = f < flim ? f : flim;
+  f = nz ? f : 0;
+  float out;
+  memcpy(&out, &f, 4);
+  return out;
+}
 
 // per-band inputs of that scan
 EDT_LANE int band_last_start(uint32_t rsw, int row0) { return rsw ? row0 + 31 - clz32(rsw) : -1; }

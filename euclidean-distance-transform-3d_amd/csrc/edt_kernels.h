@@ -75,6 +75,10 @@ namespace edt_amd {
 bool column_pass_wave_supported(const AxisGeom &g);
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                             float w, int bb, int epi, hipStream_t stream);
+// the same with pass 1 fused in (F is write-only): needs the row records + T of edt_rowwave.hip
+int launch_column_pass_wave_xfused(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                                   float w, int bb, int epi, const void *meta, const float *ttab,
+                                   int to_finite, hipStream_t stream);
 }  // namespace edt_amd
 
 namespace edt_amd {
@@ -83,4 +87,9 @@ bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz);
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
                          int to_finite, hipStream_t stream);
+// bit planes + per-row run records only (pass 1 is then rebuilt inside the first column pass);
+// `ttab` receives T[0..sx+2].  Scratch sizes: row_records_bytes / (sx+3)*4.
+size_t row_records_bytes(int64_t sx, int64_t sy, int64_t sz);
+int launch_row_records(int dtype, const void *labels, void *meta, float *ttab, uint32_t *nz_y, uint32_t *ys_y,
+                    uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb, hipStream_t stream);
 }  // namespace edt_amd

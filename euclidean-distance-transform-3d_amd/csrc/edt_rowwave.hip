@@ -57,7 +57,13 @@ __device__ __forceinline__ T buf_load(rsrc_t r, uint32_t voff, uint32_t soff) {
 
 }  // namespace
 
-template <typename T, int NC, bool HAS_Z>
+// FULL: sx == 64*NC exactly, so no lane ever falls off the end of a row (no clamped offsets, no
+// store guards).  Every instruction counts here: measured on MI355X this kernel is bound by the
+// number of instructions a SIMD can issue (~1 per 4-5 cycles over all types, rocprofv3
+// SQ_ACTIVE_INST_ANY ~ 85 % of the kernel time), not by HBM and not by load latency -- hence the
+// wave-uniform fast paths below (a chunk without run starts, a chunk without background, a row
+// without any start) which skip whole groups of per-voxel and scalar instructions.
+template <typename T, int NC, bool HAS_Z, bool FULL>
 __global__ void __launch_bounds__(kRowWaves * 64)
 k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t *__restrict__ nz_y,
                 uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, float w,
@@ -84,6 +90,10 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
   const unsigned long long le_mask = ~0ull >> (63 - lane);  // bits 0..lane
   const unsigned long long gt_mask = ~le_mask;              // bits lane+1..63
   const int flim = to_finite ? 0x7f7fffff : 0x7f800000;     // FLT_MAX / +inf bit patterns
+  // start of the row = initial carry: position 0 with a black border, far to the left without
+  // (voxel 0 never marks itself -- it is its own left neighbour); end of the row likewise
+  const int pre0 = bb ? 0 : -(1 << 20);
+  const int suf0 = bb ? sx : (1 << 20);
 
   for (int grp = (int)blockIdx.x * kRowWaves + wave; grp < ngroups; grp += (int)gridDim.x * kRowWaves) {
     const int z = grp / nby, yb = grp - z * nby;
@@ -94,6 +104,148 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
     const rsrc_t rs_lab = make_rsrc(base);
     const rsrc_t rs_bel = make_rsrc((HAS_Z && z > 0) ? base - sxy : base);
     const rsrc_t rs_out = make_rsrc(obase);
+
+    uint32_t xs[NC], xl[NC];  // per-lane BYTE offsets inside a row
+    T above[NC];
+    uint32_t nzw[NC], ysw[NC], zsw[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int x = c * 64 + lane;
+      // every load is unconditional, clamped to a voxel that exists; lanes past the end of the row
+      // read the last voxel as their own AND as their left neighbour, so they never mark a start
+      xs[c] = (uint32_t)((FULL || x < sx) ? x : sx - 1) * (uint32_t)sizeof(T);
+      xl[c] = (uint32_t)((FULL || x < sx) ? (x > 0 ? x - 1 : 0) : sx - 1) * (uint32_t)sizeof(T);
+      nzw[c] = 0; ysw[c] = 0; zsw[c] = 0;
+      above[c] = y0 > 0 ? buf_load<T>(make_rsrc(base - sx), xs[c], 0) : T(0);
+    }
+
+#pragma unroll 1
+    for (int r = 0; r < nrows; ++r) {
+      const uint32_t soff = (uint32_t)(r * sx) * (uint32_t)sizeof(T);  // wave-uniform row offset
+      T lab[NC], left[NC], below[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        lab[c] = buf_load<T>(rs_lab, xs[c], soff);
+        left[c] = buf_load<T>(rs_lab, xl[c], soff);
+        below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], soff) : lab[c];
+      }
+      // ---- compares -> masks (SGPRs), bit words --------------------------------------------
+      unsigned long long M[NC];
+      unsigned long long any_start = 0;  // OR of the start masks of the row
+      uint32_t all_fg = 0;               // bit c: chunk c has no background voxel
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        M[c] = __ballot(lab[c] != left[c]);
+        const unsigned long long fg = __ballot(lab[c] != T(0));
+        shift_in(nzw[c], fg);
+        shift_in(ysw[c], __ballot(lab[c] != above[c]));
+        if (HAS_Z) shift_in(zsw[c], __ballot(lab[c] != below[c]));
+        above[c] = lab[c];
+        any_start |= M[c];
+        all_fg |= (fg == ~0ull ? 1u : 0u) << c;
+      }
+      // ---- run starts / ends carried across chunks (scalar unit) ----------------------------
+      int pre[NC], suf[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { pre[c] = pre0; suf[c] = suf0; }
+      if (any_start) {
+        int last = pre0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          pre[c] = last;
+          if (M[c]) last = c * 64 + 63 - __builtin_clzll(M[c]);
+        }
+        int nxt = suf0;
+#pragma unroll
+        for (int c = NC - 1; c >= 0; --c) {
+          suf[c] = nxt;
+          if (M[c]) nxt = c * 64 + __builtin_ctzll(M[c]);
+        }
+      }
+      // ---- distances ---------------------------------------------------------------------------
+      const uint32_t ooff = (uint32_t)(r * sx) * 4u;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int x = c * 64 + lane;
+        int il, ir;
+        if (M[c] == 0) {
+          // no run starts inside this chunk (wave-uniform test): every voxel belongs to the run
+          // carried in from the left and out to the right -- no bit scans, no selects
+          il = x - pre[c] + 1;
+          ir = suf[c] - x;
+        } else {
+          const unsigned long long m1 = M[c] & le_mask;
+          const unsigned long long m2 = M[c] & gt_mask;
+          const int s = m1 ? c * 64 + 63 - __builtin_clzll(m1) : pre[c];   // first voxel of the run
+          const int e1 = m2 ? c * 64 + __builtin_ctzll(m2) : suf[c];        // one past its last voxel
+          il = x - s + 1;
+          ir = e1 - x;
+        }
+        il = il < idx_inf ? il : idx_inf;
+        ir = ir < idx_inf ? ir : idx_inf;
+        const int dL = as_int(Ttab[il]), dR = as_int(Ttab[ir]);
+        const float d = __int_as_float(dL < dR ? dL : dR);  // positive floats order like integers
+        int f = as_int(d * d);
+        f = f < flim ? f : flim;                             // tofinite (src/edt.hpp:39-45)
+        if (!((all_fg >> c) & 1u)) f = lab[c] != T(0) ? f : 0;  // (wave-uniform test)
+        if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)f, rs_out, (uint32_t)x * 4u, ooff, 0);
+      }
+    }
+
+    // ---- the three bit words of this (z, y-band) -----------------------------------------------
+    const int sh = 32 - nrows;
+    const int64_t wbase = ((int64_t)z * nby + yb) * sx;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int x = c * 64 + lane;
+      if (FULL || x < sx) {
+        // row 0 of the volume starts a run along y, slice 0 starts every run along z
+        const uint32_t ys = (__brev(ysw[c]) >> sh) | (y0 == 0 ? 1u : 0u);
+        const uint32_t zs = z == 0 ? (0xFFFFFFFFu >> sh) : (__brev(zsw[c]) >> sh);
+        nz_y[wbase + x] = __brev(nzw[c]) >> sh;
+        ys_y[wbase + x] = ys;
+        if (HAS_Z) zs_y[wbase + x] = zs;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pass 1 WITHOUT its output: when the first column pass runs the wave kernel, the fp32 result
+// of pass 1 is never materialised in HBM.  This kernel reads the labels (once), writes the three
+// bit planes as above, and -- instead of 4 bytes per voxel -- one 16-byte record per row and
+// 64-voxel chunk { run-start mask, last start before the chunk, first start after it }, laid out
+// [z][chunk][y] so that a column tile finds the records of its rows contiguous.  The column
+// kernel rebuilds F from them (edt_colwave_lane.h: xpass_value).  k_build_ttab writes the table
+// of sequential fp32 sums of wx that the closed form indexes.
+// ---------------------------------------------------------------------------------------
+__global__ void k_build_ttab(float *__restrict__ ttab, int sx, float w) {
+  // the reference's own accumulation order (src/edt.hpp:97, :113): T[k] = fl32(T[k-1] + w)
+  float acc = 0.0f;
+  ttab[0] = 0.0f;
+  for (int k = 1; k <= sx + 1; ++k) {
+    acc = acc + w;
+    ttab[k] = acc;
+  }
+  ttab[sx + 2] = INFINITY;
+}
+
+template <typename T, int NC, bool HAS_Z>
+__global__ void __launch_bounds__(kRowWaves * 64)
+k_row_records(const T *__restrict__ labels, uint4 *__restrict__ meta, uint32_t *__restrict__ nz_y,
+              uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, int bb,
+              int nby, int ngroups, int ncr) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int64_t sxy = (int64_t)sx * sy;
+
+  for (int grp = (int)blockIdx.x * kRowWaves + wave; grp < ngroups; grp += (int)gridDim.x * kRowWaves) {
+    const int z = grp / nby, yb = grp - z * nby;
+    const int y0 = yb * 32;
+    const int nrows = (sy - y0) < 32 ? (sy - y0) : 32;
+    const T *base = labels + ((int64_t)z * sy + y0) * sx;  // row y0 of this slice
+    const rsrc_t rs_lab = make_rsrc(base);
+    const rsrc_t rs_bel = make_rsrc((HAS_Z && z > 0) ? base - sxy : base);
 
     uint32_t xs[NC], xl[NC];  // per-lane BYTE offsets inside a row
     T above[NC];
@@ -119,21 +271,17 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
         left[c] = buf_load<T>(rs_lab, xl[c], soff);
         below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], soff) : lab[c];
       }
-      // ---- compares -> masks (SGPRs), bit words --------------------------------------------
-      unsigned long long M[NC], FG[NC];
+      unsigned long long M[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         M[c] = __ballot(lab[c] != left[c]);
-        FG[c] = __ballot(lab[c] != T(0));
-        shift_in(nzw[c], FG[c]);
+        shift_in(nzw[c], __ballot(lab[c] != T(0)));
         shift_in(ysw[c], __ballot(lab[c] != above[c]));
         if (HAS_Z) shift_in(zsw[c], __ballot(lab[c] != below[c]));
         above[c] = lab[c];
       }
-      // voxel 0 starts a run; without a black border that run has no boundary on its left,
-      // which is expressed by NOT marking it and carrying a start position far to the left
-      if (bb) M[0] |= 1ull; else M[0] &= ~1ull;
-      // ---- run starts / ends carried across chunks (scalar unit) ----------------------------
+      // run starts / ends carried across chunks (scalar unit).  Voxel 0 never marks itself: the
+      // start of the row is the initial carry -- position 0 with a black border, far away without.
       int pre[NC], suf[NC];
       {
         int last = bb ? 0 : -(1 << 20);
@@ -149,24 +297,17 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
           if (M[c]) nxt = c * 64 + __builtin_ctzll(M[c]);
         }
       }
-      // ---- distances ---------------------------------------------------------------------------
-      const uint32_t ooff = (uint32_t)(r * sx) * 4u;
+      // the records of this row: lane c stores chunk c's
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int x = c * 64 + lane;
-        const unsigned long long m1 = M[c] & le_mask;
-        const unsigned long long m2 = M[c] & gt_mask;
-        const int s = m1 ? c * 64 + 63 - __builtin_clzll(m1) : pre[c];   // first voxel of the run
-        const int e1 = m2 ? c * 64 + __builtin_ctzll(m2) : suf[c];        // one past its last voxel
-        int il = x - s + 1, ir = e1 - x;
-        il = il < idx_inf ? il : idx_inf;
-        ir = ir < idx_inf ? ir : idx_inf;
-        const int dL = as_int(Ttab[il]), dR = as_int(Ttab[ir]);
-        const float d = __int_as_float(dL < dR ? dL : dR);  // positive floats order like integers
-        int f = as_int(d * d);
-        f = f < flim ? f : flim;                             // tofinite (src/edt.hpp:39-45)
-        f = ((FG[c] >> lane) & 1ull) ? f : 0;
-        if (x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)f, rs_out, (uint32_t)x * 4u, ooff, 0);
+        if (lane == c && c < ncr) {
+          uint4 rec;
+          rec.x = (uint32_t)M[c];
+          rec.y = (uint32_t)(M[c] >> 32);
+          rec.z = (uint32_t)pre[c];
+          rec.w = (uint32_t)suf[c];
+          meta[((int64_t)z * ncr + c) * sy + (y0 + r)] = rec;
+        }
       }
     }
 
@@ -188,6 +329,64 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
   }
 }
 
+size_t row_records_bytes(int64_t sx, int64_t sy, int64_t sz) {
+  return (size_t)(ceil_div(sx, 64) * sy * sz) * sizeof(uint4);
+}
+
+template <typename T, int NC>
+static int launch_row_records_tn(const void *labels, void *meta, uint32_t *nz_y, uint32_t *ys_y,
+                                 uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, int bb,
+                                 hipStream_t stream) {
+  const int64_t nby = ceil_div(sy, kBandRows);
+  const int64_t ngroups = nby * sz;
+  if (ngroups <= 0) return EDT_OK;
+  int64_t blocks = ceil_div(ngroups, kRowWaves);
+  const int64_t resident = 256 * 8;
+  if (blocks > resident) blocks = resident;
+  const int ncr = (int)ceil_div(sx, 64);
+  if (zs_y != nullptr)
+    hipLaunchKernelGGL((k_row_records<T, NC, true>), dim3((unsigned)blocks), dim3(kRowWaves * 64), 0, stream,
+                       (const T *)labels, (uint4 *)meta, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, bb,
+                       (int)nby, (int)ngroups, ncr);
+  else
+    hipLaunchKernelGGL((k_row_records<T, NC, false>), dim3((unsigned)blocks), dim3(kRowWaves * 64), 0, stream,
+                       (const T *)labels, (uint4 *)meta, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, bb,
+                       (int)nby, (int)ngroups, ncr);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+template <typename T>
+static int launch_row_records_t(const void *labels, void *meta, uint32_t *nz_y, uint32_t *ys_y,
+                                uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, int bb,
+                                hipStream_t stream) {
+  const int64_t nc = ceil_div(sx, 64);
+#define GO(N) return launch_row_records_tn<T, N>(labels, meta, nz_y, ys_y, zs_y, sx, sy, sz, bb, stream)
+  if (nc <= 1) GO(1);
+  if (nc <= 2) GO(2);
+  if (nc <= 4) GO(4);
+  GO(8);
+#undef GO
+}
+
+int launch_row_records(int dtype, const void *labels, void *meta, float *ttab, uint32_t *nz_y, uint32_t *ys_y,
+                       uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(k_build_ttab, dim3(1), dim3(1), 0, stream, ttab, (int)sx, w);
+  EDT_HIP_TRY(hipGetLastError());
+#define ROW_REC(T) return launch_row_records_t<T>(labels, meta, nz_y, ys_y, zs_y, sx, sy, sz, bb, stream)
+  switch (dtype) {
+    case EDT_U8: case EDT_BOOL: ROW_REC(uint8_t);
+    case EDT_U16: ROW_REC(uint16_t);
+    case EDT_U32: ROW_REC(uint32_t);
+    case EDT_U64: ROW_REC(uint64_t);
+    case EDT_F32: ROW_REC(float);
+    case EDT_F64: ROW_REC(double);
+    default: set_error("unknown dtype"); return EDT_ERR_BAD_ARG;
+  }
+#undef ROW_REC
+}
+
 bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
   return sx >= 1 && sx <= 512 && sy * sz < (int64_t)1 << 30 && sx * sy * sz < ((int64_t)1 << 40);
 }
@@ -203,14 +402,14 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
   int64_t blocks = ceil_div(ngroups, kRowWaves);
   const int64_t resident = 256 * 8;  // persistent grid: the T table is built once per workgroup
   if (blocks > resident) blocks = resident;
-  if (zs_y != nullptr)
-    hipLaunchKernelGGL((k_row_pass_wave<T, NC, true>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds,
-                       stream, (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb,
-                       to_finite, (int)nby, (int)ngroups);
-  else
-    hipLaunchKernelGGL((k_row_pass_wave<T, NC, false>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds,
-                       stream, (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb,
-                       to_finite, (int)nby, (int)ngroups);
+#define LAUNCH(Z, F)                                                                                      \
+  hipLaunchKernelGGL((k_row_pass_wave<T, NC, Z, F>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds, stream,  \
+                     (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb, to_finite, \
+                     (int)nby, (int)ngroups)
+  const bool full = sx == 64 * NC;
+  if (zs_y != nullptr) { if (full) LAUNCH(true, true); else LAUNCH(true, false); }
+  else { if (full) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }

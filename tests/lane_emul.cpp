@@ -9,6 +9,8 @@
 //
 //   g++ -O2 -ffp-contract=off -shared -fPIC -I<csrc> tests/lane_emul.cpp -o liblane_emul.so
 #include <cstdint>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -21,7 +23,8 @@ namespace {
 
 template <int CW, bool BB>
 void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t sx, int n, int NB,
-               int64_t stride, int64_t x0, float w, int epi) {
+               int64_t stride, int64_t x0, float w, int epi, const XRowMeta *meta = nullptr,
+               const float *Ttab = nullptr, int idx_inf = 0, int flim = 0) {
   constexpr int NBP = 64 / CW;
   constexpr int W = 32 / CW;
   constexpr int K = (CW / 4) & 7;
@@ -71,9 +74,26 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
       }
     }
   }
-  for (auto &P : lanes) {
-    const float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
-    for (int r = 0; r < 32; ++r) P.f[r] = own[r * 32];
+  if (meta) {
+    // fused pass 1: every lane rebuilds F for its rows from the row records, then publishes them
+    // in the LDS tile (the kernel does exactly this instead of the HBM fill)
+    for (auto &P : lanes) {
+      float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
+      for (int r = 0; r < 32; ++r) {
+        const int row = P.L.row0 + r;
+        float v = 0.0f;
+        if (row < n && P.L.colc < cols_left)
+          v = xpass_value(meta[row], (int)((x0 >> 5) & 1), (int)(x0 & ~63), P.L.colc, Ttab, idx_inf, flim,
+                          (P.L.nzw >> r) & 1u);
+        P.f[r] = v;
+        own[r * 32] = v;
+      }
+    }
+  } else {
+    for (auto &P : lanes) {
+      const float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
+      for (int r = 0; r < 32; ++r) P.f[r] = own[r * 32];
+    }
   }
   auto lane_of = [&](int colc, int band) -> PerLane * {
     for (auto &Q : lanes)
@@ -111,10 +131,12 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
 
 template <int CW>
 void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n, int NB, int64_t stride,
-             float w, int bb, int epi) {
+             float w, int bb, int epi, const XRowMeta *meta = nullptr, const float *Ttab = nullptr,
+             int idx_inf = 0, int flim = 0) {
   for (int64_t x0 = 0; x0 < sx; x0 += 32) {
-    if (bb) tile_pass<CW, true>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3);
-    else tile_pass<CW, false>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3);
+    const XRowMeta *m = meta ? meta + (x0 >> 6) * n : nullptr;  // records are [chunk][row]
+    if (bb) tile_pass<CW, true>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim);
+    else tile_pass<CW, false>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim);
   }
 }
 
@@ -138,5 +160,55 @@ extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t s
   else if (NB <= 4) pass_cw<16>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
   else if (NB <= 8) pass_cw<8>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
   else pass_cw<4>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  return 0;
+}
+
+// Fused passes 1+2 on a 2-D image: labels [n][sx] uint32 -> out [n][sx] fp32 (no pass-1 buffer at all).
+// The per-row records are built here the way the bit kernel builds them.
+extern "C" int lane_emul_fused_xy(const uint32_t *labels, float *out, int64_t sx, int64_t n, float wx,
+                                  float wy, int bb, int epi) {
+  const int NB = (int)((n + 31) / 32);
+  if (NB < 1 || NB > 16 || sx % 4 != 0 || sx > 512) return -1;
+  const int NC = (int)((sx + 63) / 64);
+  std::vector<uint32_t> nz((size_t)NB * sx, 0), rs((size_t)NB * sx, 0);
+  for (int64_t x = 0; x < sx; ++x)
+    for (int64_t y = 0; y < n; ++y) {
+      const uint32_t lab = labels[y * sx + x];
+      const bool start = (y == 0) || lab != labels[(y - 1) * sx + x];
+      if (lab != 0) nz[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
+      if (start) rs[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
+    }
+  std::vector<XRowMeta> meta((size_t)NC * n);
+  for (int64_t y = 0; y < n; ++y) {
+    std::vector<uint64_t> M(NC, 0);
+    for (int64_t x = 1; x < sx; ++x)  // voxel 0 never marks itself
+      if (labels[y * sx + x] != labels[y * sx + x - 1]) M[x >> 6] |= 1ull << (x & 63);
+    int last = bb ? 0 : -(1 << 20);
+    std::vector<int> pre(NC), suf(NC);
+    for (int c = 0; c < NC; ++c) {
+      pre[c] = last;
+      if (M[c]) last = c * 64 + 63 - __builtin_clzll(M[c]);
+    }
+    int nxt = bb ? (int)sx : (1 << 20);
+    for (int c = NC - 1; c >= 0; --c) {
+      suf[c] = nxt;
+      if (M[c]) nxt = c * 64 + __builtin_ctzll(M[c]);
+    }
+    for (int c = 0; c < NC; ++c) meta[(size_t)c * n + y] = XRowMeta{(uint32_t)M[c], (uint32_t)(M[c] >> 32), pre[c], suf[c]};
+  }
+  std::vector<float> T((size_t)sx + 3);
+  {
+    float acc = 0.0f;
+    T[0] = 0.0f;
+    for (int64_t k = 1; k <= sx + 1; ++k) { acc = acc + wx; T[k] = acc; }
+    T[sx + 2] = INFINITY;
+  }
+  const int idx_inf = (int)sx + 2;
+  const int flim = bb ? 0x7f800000 : 0x7f7fffff;
+  std::fill(out, out + sx * n, -777.0f);
+  if (NB <= 2) pass_cw<32>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, meta.data(), T.data(), idx_inf, flim);
+  else if (NB <= 4) pass_cw<16>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, meta.data(), T.data(), idx_inf, flim);
+  else if (NB <= 8) pass_cw<8>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, meta.data(), T.data(), idx_inf, flim);
+  else pass_cw<4>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, meta.data(), T.data(), idx_inf, flim);
   return 0;
 }

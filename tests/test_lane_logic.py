@@ -86,3 +86,26 @@ def test_column_pass_matches_oracle(emul, oracle_port, n, sx, kind):
             assert np.array_equal(got, want), (n, sx, kind, wx, wy, bb)
             got_sqrt = column_pass(emul, lab, f1, wy, bb, (0 if bb else 1) | 2)
             assert np.array_equal(got_sqrt, np.sqrt(want)), (n, sx, kind, wx, wy, bb, "sqrt")
+
+
+def fused_xy(lib, labels_yx, wx, wy, bb, epi):
+    n, sx = labels_yx.shape
+    lab = np.ascontiguousarray(labels_yx, dtype=np.uint32)
+    out = np.empty((n, sx), dtype=np.float32)
+    rc = lib.lane_emul_fused_xy(lab.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+                                ctypes.c_int64(sx), ctypes.c_int64(n), ctypes.c_float(wx), ctypes.c_float(wy),
+                                ctypes.c_int(int(bb)), ctypes.c_int(epi))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("n,sx,kind", CASES)
+def test_fused_xy_matches_oracle(emul, oracle_port, n, sx, kind):
+    """Pass 1 rebuilt inside the column pass from the per-row run records (no pass-1 buffer)."""
+    rng = np.random.default_rng(n * 1000 + sx + 7)
+    lab = make_labels(n, sx, kind, rng)
+    for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (0.7, 1.3)):
+        for bb in (True, False):
+            want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
+            got = fused_xy(emul, lab, wx, wy, bb, 0 if bb else 1)
+            assert np.array_equal(got, want), (n, sx, kind, wx, wy, bb)

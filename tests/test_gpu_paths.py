@@ -1,0 +1,85 @@
+"""GPU tests (`-m gpu`) of the kernel FAMILIES and of the Z-sharded building blocks.
+
+1. Every column / row kernel variant against the oracle on the same inputs: the default path
+   (register-resident pass 1 + wave-autonomous column pass), the workgroup-phased LDS kernels
+   (debug bit 64 / 32), the fused X+Y path (bit 128) and the size-agnostic fallback.
+2. The two shard phases (edt_hip_shard_xy_device / edt_hip_shard_z_device) driven as VIRTUAL ranks
+   on one device: slabs, one-slice label halo, Z-slab -> Y-slab re-partition (done with plain tensor
+   slicing here; torch.distributed does it across GPUs), compared with the oracle on the whole volume.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from synth import blocky_labels, voronoi_labels
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+SHAPES = [(512, 40, 36), (256, 96, 20), (100, 130, 70), (64, 64, 64), (36, 500, 24), (8, 33, 257)]
+
+
+@pytest.mark.parametrize("mode,name", [(0, "default"), (64, "phased-column"), (32, "lds-row"),
+                                        (96, "phased-both"), (128, "fused-xy")])
+def test_kernel_families_agree_with_the_oracle(edt_gpu, oracle_port, mode, name):
+    from edt import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    try:
+        lib.edt_hip_set_debug_mode(mode)
+        for i, shape in enumerate(SHAPES):
+            lab = blocky_labels(shape, nlabels=5, zero_frac=0.2 if i % 2 else 0.0,
+                                block=int(rng.integers(2, 24)), rng=rng).astype(np.uint32)
+            lab = np.asfortranarray(lab)
+            for an, bb in (((1, 1, 1), False), ((6, 6, 30), True), ((0.5, 0.7, 1.3), False)):
+                want = oracle_port.edtsq(lab, an, bb)
+                got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+                assert same(got, want), (name, shape, an, bb)
+                assert same(edt_gpu.edt(lab, anisotropy=an, black_border=bb), np.sqrt(want)), (name, shape, "sqrt")
+        # a 2-D image goes through the same kernels with the fused epilogue on the first column pass
+        img = np.asfortranarray(blocky_labels((300, 200), nlabels=3, zero_frac=0.1, block=9, rng=rng).astype(np.uint16))
+        assert same(edt_gpu.edtsq(img, anisotropy=(2, 3), black_border=False), oracle_port.edtsq(img, (2, 3), False))
+    finally:
+        lib.edt_hip_set_debug_mode(0)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("shape", [(96, 80, 72), (512, 64, 40), (40, 24, 33)])
+def test_shard_phases_as_virtual_ranks(edt_gpu, oracle_port, world, shape):
+    import torch
+    from edt import _lib
+    from edt.distributed import HipOps, balanced_partition
+
+    sx, sy, sz = shape
+    if sz < world or sy < world:
+        pytest.skip("fewer slices than ranks")
+    dev = torch.device("cuda", 0)
+    ops = HipOps()
+    lab = voronoi_labels(shape, nseeds=40, seed=world, upsample=4, membrane=0.04)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev)  # (sz, sy, sx), x fastest
+    zparts, yparts = balanced_partition(sz, world), balanced_partition(sy, world)
+    for an, bb, sqrt in (((6.0, 6.0, 30.0), True, False), ((1.0, 1.5, 0.5), False, True)):
+        flags = _lib.FLAG_BLACK_BORDER if bb else 0
+        partial, zflags = [], []
+        for r, (zs, ze) in enumerate(zparts):
+            halo = t[zs - 1].contiguous() if r > 0 else None  # the previous rank's last slice
+            p, f = ops.xy(t[zs:ze].contiguous(), halo, _lib.U32, an, flags)
+            partial.append(p)
+            zflags.append(f)
+        torch.cuda.synchronize()
+        partial, zflags = torch.cat(partial, 0), torch.cat(zflags, 0)
+        outs = []
+        for (ys, ye) in yparts:  # the all-to-all: rank h receives (all z, its y range)
+            o = ops.z(partial[:, ys:ye, :].contiguous(), zflags[:, ys:ye, :].contiguous(), an[2],
+                      flags | (_lib.FLAG_SQRT if sqrt else 0))
+            outs.append(o.clone())
+        got = torch.cat(outs, 1).cpu().numpy().T
+        want = oracle_port.edtsq(lab, an, bb)
+        if sqrt:
+            want = np.sqrt(want)
+        assert same(got, want), (world, shape, an, bb)

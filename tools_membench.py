@@ -20,14 +20,17 @@ t = timeit(lambda: b4.copy_(a4)); print(f"torch copy 2GB: {t*1e3:.3f} ms  {2*a4.
 t = timeit(lambda: torch.add(a, 1.0, out=b)); print(f"torch add 512MB: {t*1e3:.3f} ms  {2*a.numel()*4/t/1e12:.2f} TB/s")
 t = timeit(lambda: a.sum()); print(f"torch sum 512MB (read only): {t*1e3:.3f} ms  {a.numel()*4/t/1e12:.2f} TB/s")
 t = timeit(lambda: b.fill_(1.0)); print(f"torch fill 512MB (write only): {t*1e3:.3f} ms  {a.numel()*4/t/1e12:.2f} TB/s")
-lab = torch.ones((n, n, n), dtype=torch.int32, device=dev); out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
+from synth import config_volume
+cfg = os.environ.get("MB_CFG", "cfg2")
+lab_np, an, bb = config_volume(cfg, n)
+lab = torch.from_numpy(np.ascontiguousarray(lab_np.T).view(np.int32)).to(dev); out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
 plan = device.Plan((n, n, n), 2, dev)
 for mode in (0, 16, 2, 4, 8, 2|4|8):
     lib.edt_hip_set_debug_mode(mode)
     device.set_profiling(True)
     acc = {}
     for _ in range(5):
-        plan.run(lab, (6.0, 6.0, 30.0), black_border=True, out=out); torch.cuda.synchronize()
+        plan.run(lab, an, black_border=bb, out=out); torch.cuda.synchronize()
         for k, v in device.pass_times(): acc.setdefault(k, []).append(v)
     device.set_profiling(False)
     print("debug_mode", mode, {k: round(float(np.mean(v[1:])), 4) for k, v in acc.items()})

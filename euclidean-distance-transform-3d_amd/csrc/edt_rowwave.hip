@@ -63,11 +63,22 @@ __device__ __forceinline__ T buf_load(rsrc_t r, uint32_t voff, uint32_t soff) {
 // SQ_ACTIVE_INST_ANY ~ 85 % of the kernel time), not by HBM and not by load latency -- hence the
 // wave-uniform fast paths below (a chunk without run starts, a chunk without background, a row
 // without any start) which skip whole groups of per-voxel and scalar instructions.
+// XCD-aware schedule (see the kernels): worth it when every XCD gets at least one y-band and z is
+// long enough to have neighbours in flight; returns 1 and rounds the grid to 8 workgroup columns.
+static int row_xcd_schedule(int64_t nby, int64_t sz, int64_t *blocks) {
+  if (nby < 8 || sz < 2 || debug_mode() & 256) return 0;
+  const int64_t per_xcd = ceil_div(nby, 8) * sz;  // groups of the busiest XCD
+  int64_t bx = ceil_div(per_xcd, kRowWaves);
+  if (bx > 256) bx = 256;
+  *blocks = bx * 8;
+  return 1;
+}
+
 template <typename T, int NC, bool HAS_Z, bool FULL>
 __global__ void __launch_bounds__(kRowWaves * 64)
 k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t *__restrict__ nz_y,
                 uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, float w,
-                int bb, int to_finite, int nby, int ngroups) {
+                int bb, int to_finite, int nby, int ngroups, int xcd_sched) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *Ttab = reinterpret_cast<float *>(smem);  // [sx + 3]: T[0..sx+1], then +inf
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -95,8 +106,19 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
   const int pre0 = bb ? 0 : -(1 << 20);
   const int suf0 = bb ? sx : (1 << 20);
 
-  for (int grp = (int)blockIdx.x * kRowWaves + wave; grp < ngroups; grp += (int)gridDim.x * kRowWaves) {
-    const int z = grp / nby, yb = grp - z * nby;
+  // Work distribution.  The `zs` bits need the labels of slice z-1, which some other wave reads as
+  // ITS slice: when both run on the same XCD at about the same time the second read hits in that
+  // XCD's L2 instead of crossing the fabric again (observed placement: workgroup b runs on XCD
+  // b % 8 -- used for speed only).  So every XCD takes the y-bands congruent to its index and
+  // walks z in order: slices z-1 and z of one band are then neighbouring waves of one XCD.
+  const bool by_xcd = xcd_sched != 0;
+  const int xcd = (int)(blockIdx.x & 7), nyk = by_xcd ? (nby - xcd + 7) >> 3 : 0;
+  const int first = by_xcd ? (int)(blockIdx.x >> 3) * kRowWaves + wave : (int)blockIdx.x * kRowWaves + wave;
+  const int step = by_xcd ? (int)(gridDim.x >> 3) * kRowWaves : (int)gridDim.x * kRowWaves;
+  const int count = by_xcd ? nyk * sz : ngroups;
+  for (int i = first; i < count; i += step) {
+    const int z = by_xcd ? i / nyk : i / nby;
+    const int yb = by_xcd ? xcd + 8 * (i - z * nyk) : i - z * nby;
     const int y0 = yb * 32;
     const int nrows = (sy - y0) < 32 ? (sy - y0) : 32;
     const T *base = labels + ((int64_t)z * sy + y0) * sx;  // row y0 of this slice
@@ -234,13 +256,24 @@ template <typename T, int NC, bool HAS_Z>
 __global__ void __launch_bounds__(kRowWaves * 64)
 k_row_records(const T *__restrict__ labels, uint4 *__restrict__ meta, uint32_t *__restrict__ nz_y,
               uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, int bb,
-              int nby, int ngroups, int ncr) {
+              int nby, int ngroups, int ncr, int xcd_sched) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
   const int64_t sxy = (int64_t)sx * sy;
 
-  for (int grp = (int)blockIdx.x * kRowWaves + wave; grp < ngroups; grp += (int)gridDim.x * kRowWaves) {
-    const int z = grp / nby, yb = grp - z * nby;
+  // Work distribution.  The `zs` bits need the labels of slice z-1, which some other wave reads as
+  // ITS slice: when both run on the same XCD at about the same time the second read hits in that
+  // XCD's L2 instead of crossing the fabric again (observed placement: workgroup b runs on XCD
+  // b % 8 -- used for speed only).  So every XCD takes the y-bands congruent to its index and
+  // walks z in order: slices z-1 and z of one band are then neighbouring waves of one XCD.
+  const bool by_xcd = xcd_sched != 0;
+  const int xcd = (int)(blockIdx.x & 7), nyk = by_xcd ? (nby - xcd + 7) >> 3 : 0;
+  const int first = by_xcd ? (int)(blockIdx.x >> 3) * kRowWaves + wave : (int)blockIdx.x * kRowWaves + wave;
+  const int step = by_xcd ? (int)(gridDim.x >> 3) * kRowWaves : (int)gridDim.x * kRowWaves;
+  const int count = by_xcd ? nyk * sz : ngroups;
+  for (int i = first; i < count; i += step) {
+    const int z = by_xcd ? i / nyk : i / nby;
+    const int yb = by_xcd ? xcd + 8 * (i - z * nyk) : i - z * nby;
     const int y0 = yb * 32;
     const int nrows = (sy - y0) < 32 ? (sy - y0) : 32;
     const T *base = labels + ((int64_t)z * sy + y0) * sx;  // row y0 of this slice
@@ -343,15 +376,16 @@ static int launch_row_records_tn(const void *labels, void *meta, uint32_t *nz_y,
   int64_t blocks = ceil_div(ngroups, kRowWaves);
   const int64_t resident = 256 * 8;
   if (blocks > resident) blocks = resident;
+  const int xcd_sched = row_xcd_schedule(nby, sz, &blocks);
   const int ncr = (int)ceil_div(sx, 64);
   if (zs_y != nullptr)
     hipLaunchKernelGGL((k_row_records<T, NC, true>), dim3((unsigned)blocks), dim3(kRowWaves * 64), 0, stream,
                        (const T *)labels, (uint4 *)meta, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, bb,
-                       (int)nby, (int)ngroups, ncr);
+                       (int)nby, (int)ngroups, ncr, xcd_sched);
   else
     hipLaunchKernelGGL((k_row_records<T, NC, false>), dim3((unsigned)blocks), dim3(kRowWaves * 64), 0, stream,
                        (const T *)labels, (uint4 *)meta, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, bb,
-                       (int)nby, (int)ngroups, ncr);
+                       (int)nby, (int)ngroups, ncr, xcd_sched);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }
@@ -402,10 +436,11 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
   int64_t blocks = ceil_div(ngroups, kRowWaves);
   const int64_t resident = 256 * 8;  // persistent grid: the T table is built once per workgroup
   if (blocks > resident) blocks = resident;
+  const int xcd_sched = row_xcd_schedule(nby, sz, &blocks);
 #define LAUNCH(Z, F)                                                                                      \
   hipLaunchKernelGGL((k_row_pass_wave<T, NC, Z, F>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds, stream,  \
                      (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb, to_finite, \
-                     (int)nby, (int)ngroups)
+                     (int)nby, (int)ngroups, xcd_sched)
   const bool full = sx == 64 * NC;
   if (zs_y != nullptr) { if (full) LAUNCH(true, true); else LAUNCH(true, false); }
   else { if (full) LAUNCH(false, true); else LAUNCH(false, false); }

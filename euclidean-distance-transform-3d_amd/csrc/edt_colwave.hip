@@ -174,16 +174,26 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 
   // ---- phase 1 / 2 / 3 (wave-local) ----------------------------------------------------------
   // (dbg: diagnostics only -- bit1 skips the hull build, bit2 the merges, bit3 the evaluation)
-  uint32_t flat = 0;
   const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
-  uint32_t aw = (dbg & 2) ? L.nzw : phase1_hull<CW>(L, f, fprev, flat);
+  Hull1 H;
+  if (dbg & 2) { H.aw = L.nzw; H.flat = 0; H.nb0 = H.nb1 = H.nb31 = 0.0; }
+  else H = phase1_hull<CW>(L, f, fprev);
+  uint32_t aw = H.aw;
+  const uint32_t flat = H.flat;
   alive[addr_word<CW>(L.colc, L.band)] = aw;
   wave_sync();
   if (!(dbg & 4)) {
+    // the merge rounds change nothing for a wave whose band boundaries are all quiet
+    uint32_t prev_aw = __shfl_up(aw, CW), prev_rs = __shfl_up(L.rsw, CW);
+    const double prev_nb31 = __shfl_up(H.nb31, CW);
+    if (lane < CW) { prev_aw = 0; prev_rs = 0; }
+    const bool quiet = boundary_quiet(L, H, prev_aw, prev_rs, prev_nb31);
+    if (__ballot(!quiet) != 0ull || (dbg & 32)) {
 #pragma unroll
-    for (int half = 1; half < NBP; half <<= 1) {
-      phase2_merge<CW>(L, half);
-      wave_sync();
+      for (int half = 1; half < NBP; half <<= 1) {
+        phase2_merge<CW>(L, half);
+        wave_sync();
+      }
     }
   }
   aw = alive[addr_word<CW>(L.colc, L.band)];

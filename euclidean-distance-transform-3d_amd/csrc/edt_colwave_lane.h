@@ -218,8 +218,15 @@ EDT_LANE int next_set(const uint32_t *plane, int colc, int after, int hi) {
 // whose test cannot fire (background, run start, row after a run start) are masked by `dis`;
 // the pop loop proper is the rare slow path and re-derives the stack from the alive word.
 // ---------------------------------------------------------------------------------------
+// what phase 1 leaves behind besides the alive word
+struct Hull1 {
+  uint32_t aw;    // alive word of the band
+  uint32_t flat;  // bit r: |F[r] - F[r-1]| <= w2
+  double nb0, nb1, nb31;  // crossing numerators num(r-1, r) of the band's rows 0, 1 and 31
+};
+
 template <int CW>
-EDT_LANE uint32_t phase1_hull(const Lane &L, const float *f, float fprev, uint32_t &flat) {
+EDT_LANE Hull1 phase1_hull(const Lane &L, const float *f, float fprev) {
   const uint32_t rs1 = L.rsw | 1u;  // the band's first row starts a (local) chain
   const uint32_t dis = ~L.nzw | rs1 | (rs1 << 1);
   const double w2 = L.w2, w2x2 = w2 + w2;
@@ -231,6 +238,10 @@ EDT_LANE uint32_t phase1_hull(const Lane &L, const float *f, float fprev, uint32
   uint32_t fl = 0;  // built most-significant-row first, flipped at the end
   EDT_SHIFT_IN(fl, fabs(Fb - (double)fprev) <= w2);
   double c = w2 * (double)(2 * L.row0 - 1);  // w2*(2*row-1) for row = row0; exact, and so are its updates
+  Hull1 H;
+  H.nb0 = (Fb - (double)fprev) + c;
+  H.nb1 = 0.0;
+  H.nb31 = 0.0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -240,6 +251,8 @@ EDT_LANE uint32_t phase1_hull(const Lane &L, const float *f, float fprev, uint32
     const double t = Fi - Fb;
     EDT_SHIFT_IN(fl, fabs(t) <= w2);
     double nbi = t + c;
+    if (r == 1) H.nb1 = nbi;
+    if (r == 31) H.nb31 = nbi;
     double dbi = 1.0;
     if (!((dis >> r) & 1u) && nbi * dab <= nab) {
       // slow path: pop.  top = r-1, the entries below it come from the alive word
@@ -274,8 +287,9 @@ EDT_LANE uint32_t phase1_hull(const Lane &L, const float *f, float fprev, uint32
     dab = dbi;
     Fb = Fi;
   }
-  flat = brev32(fl);
-  return aw;
+  H.flat = brev32(fl);
+  H.aw = aw;
+  return H;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -297,6 +311,27 @@ EDT_LANE uint32_t own_mask(uint32_t nzw, uint32_t rsw, uint32_t aw, uint32_t fla
   const uint32_t P = rsw | (alive_m1 & flat);
   const uint32_t N = ends | (alive_p1 & flat_p1);
   return nzw & aw & P & N;
+}
+
+// ---------------------------------------------------------------------------------------
+// Is the band boundary below this lane "quiet", i.e. would the bridge walk of phase 2 find the
+// tangent (R-1, R) at once and remove nothing?  With the neighbours R-2 and R+1 alive and
+// adjacent, the two orientation tests of the walk are exactly the pop tests phase 1 would have
+// made for rows R and R+1 had the column not been cut:  num(R-1,R) <= num(R-2,R-1)  and
+// num(R,R+1) <= num(R-1,R)  (same expressions, same rounding).  A side on which the run ends has
+// no neighbour and cannot lose a vertex.  If every boundary of a wave is quiet the merge rounds
+// would change nothing at any level and are skipped altogether.
+// prev_* : alive / run-start words and nb31 of the band below, after phase 1.
+// ---------------------------------------------------------------------------------------
+EDT_LANE bool boundary_quiet(const Lane &L, const Hull1 &H, uint32_t prev_aw, uint32_t prev_rsw,
+                             double prev_nb31) {
+  const bool cross = L.row0 > 0 && L.row0 < L.n && (L.nzw & 1u) && !(L.rsw & 1u);
+  if (!cross) return true;  // no run crosses: nothing to merge
+  const bool has_up = !((prev_rsw >> 31) & 1u);                       // row R-2 belongs to the run
+  const bool has_vn = ((L.nzw >> 1) & 1u) && !((L.rsw >> 1) & 1u);     // row R+1 belongs to the run
+  const bool ok_l = !has_up || (((prev_aw >> 30) & 1u) && !(H.nb0 <= prev_nb31));
+  const bool ok_r = !has_vn || (((H.aw >> 1) & 1u) && !(H.nb1 <= H.nb0));
+  return ok_l && ok_r;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -39,7 +39,7 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
       if (row < n && 4 * gg < cols_left)
         std::memcpy(&tile[(size_t)i * 256 + lane * 4], F + x0 + (int64_t)row * stride + 4 * gg, 16);
     }
-  struct PerLane { Lane L; float f[32]; uint32_t aw, flat; };
+  struct PerLane { Lane L; float f[32]; uint32_t aw, flat; Hull1 H; };
   std::vector<PerLane> lanes((size_t)W * 64);
   for (int wave = 0; wave < W; ++wave)
     for (int lane = 0; lane < 64; ++lane) {
@@ -103,11 +103,24 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
   for (auto &P : lanes) {
     PerLane *below = lane_of(P.L.colc, P.L.band - 1);  // the kernel gets these through lane shuffles
     const float fprev = below ? below->f[31] : 0.0f;
-    P.aw = phase1_hull<CW>(P.L, P.f, fprev, P.flat);
+    P.H = phase1_hull<CW>(P.L, P.f, fprev);
+    P.aw = P.H.aw;
+    P.flat = P.H.flat;
     alive[addr_word<CW>(P.L.colc, P.L.band)] = P.aw;
   }
-  for (int half = 1; half < NBP; half <<= 1)
-    for (auto &P : lanes) phase2_merge<CW>(P.L, half);
+  // the merge rounds are skipped by a wave whose band boundaries are all quiet
+  for (int wave = 0; wave < W; ++wave) {
+    bool all_quiet = true;
+    for (int lane = 0; lane < 64; ++lane) {
+      PerLane &P = lanes[(size_t)wave * 64 + lane];
+      PerLane *below = lane_of(P.L.colc, P.L.band - 1);
+      if (!boundary_quiet(P.L, P.H, below ? below->H.aw : 0u, below ? below->L.rsw : 0u, below ? below->H.nb31 : 0.0))
+        all_quiet = false;
+    }
+    if (all_quiet) continue;
+    for (int half = 1; half < NBP; half <<= 1)
+      for (int lane = 0; lane < 64; ++lane) phase2_merge<CW>(lanes[(size_t)wave * 64 + lane].L, half);
+  }
   for (auto &P : lanes) P.aw = alive[addr_word<CW>(P.L.colc, P.L.band)];
   for (auto &P : lanes) {
     PerLane *below = lane_of(P.L.colc, P.L.band - 1), *above = lane_of(P.L.colc, P.L.band + 1);

@@ -48,6 +48,19 @@ def test_kernel_families_agree_with_the_oracle(edt_gpu, oracle_port, mode, name)
         lib.edt_hip_set_debug_mode(0)
 
 
+def test_axes_beyond_the_wave_kernels(edt_gpu, oracle_port):
+    """Rows / columns of 513..2048 voxels take the LDS-staged row kernel and the workgroup-phased column
+    kernel (the 1024^3 multi-GPU configuration lives here)."""
+    rng = np.random.default_rng(5)
+    for shape in ((1030, 40, 24), (48, 1040, 12), (40, 36, 1100), (1024, 64, 8), (600, 700, 3)):
+        lab = np.asfortranarray(blocky_labels(shape, nlabels=4, zero_frac=0.1, block=int(rng.integers(5, 60)),
+                                              rng=rng).astype(np.uint32))
+        for an, bb in (((6, 6, 30), True), ((1, 1, 1), False)):
+            want = oracle_port.edtsq(lab, an, bb)
+            got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+            assert same(got, want), (shape, an, bb)
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("shape", [(96, 80, 72), (512, 64, 40), (40, 24, 33)])
 def test_shard_phases_as_virtual_ranks(edt_gpu, oracle_port, world, shape):

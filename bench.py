@@ -115,7 +115,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     n = args.size
-    if world > 1:
+    if world > 1 or os.environ.get("EDT_BENCH_FORCE_SHARDED") == "1":  # (the env var: 1-rank dry run of the N > 1 leg)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         from edt import distributed as edist

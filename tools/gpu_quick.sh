@@ -5,7 +5,7 @@ python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee gpurun_out/pytest_gpu.l
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.err
 python bench.py --steps 20 --warmup 3 --config cfg3 --no-cpu-baseline > gpurun_out/bench_cfg3.json 2> gpurun_out/bench_cfg3.err
 python bench.py --steps 20 --warmup 3 --config cfg3m --no-cpu-baseline > gpurun_out/bench_cfg3m.json 2> gpurun_out/bench_cfg3m.err
-python tools_membench.py > gpurun_out/membench.log 2>&1
+python tools/membench.py > gpurun_out/membench.log 2>&1
 tail -3 gpurun_out/bench_cfg2.err
 python - <<'PY'
 import json

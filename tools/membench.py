@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Calibrate the box: achievable HBM copy bandwidth (torch copy) and the column pass's memory-only floor."""
 import sys, os, time, ctypes
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "euclidean-distance-transform-3d_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from edt import _lib, device

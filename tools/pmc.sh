@@ -15,4 +15,4 @@ for ctrs in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
   rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/pmc_${tag}_$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/pmc_${tag}_$i.log 2>&1
   echo "pass $i rc=$?"
 done
-python tools_pmc_summary.py $tag | tee gpurun_out/pmc_${tag}_summary.txt
+python tools/pmc_summary.py $tag | tee gpurun_out/pmc_${tag}_summary.txt

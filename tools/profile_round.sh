@@ -11,5 +11,5 @@ for ctrs in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_s
   rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/pmc_${tag}_$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${tag}_$i.log 2>&1
   echo "pmc pass $i rc=$?"
 done
-python tools_pmc_summary.py $tag | tee gpurun_out/pmc_${tag}_summary.txt
+python tools/pmc_summary.py $tag | tee gpurun_out/pmc_${tag}_summary.txt
 python bench.py --steps 20 --warmup 3 | tee gpurun_out/bench_$tag.json

@@ -45,7 +45,7 @@ def algorithmic_bytes_per_voxel(label_bytes, fused):
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the PMC passes of the round (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
-    tools_profile_round.sh collects them, profiles/r01_traffic.json holds the per-kernel result."""
+    tools/profile_round.sh collects them, profiles/r01_traffic.json holds the per-kernel result."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
     try:
         with open(path) as f:

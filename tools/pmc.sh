@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> [bench args...]  -- PMC passes (each in its own rocprofv3 run, kernel-trace only)
+# usage: tools/pmc.sh <tag> [bench args...]  -- PMC passes (each in its own rocprofv3 run, kernel-trace only)
 tag=$1; shift
 maxpass=${PMC_PASSES:-6}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

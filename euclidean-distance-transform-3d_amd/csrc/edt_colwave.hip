@@ -87,7 +87,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   using namespace edt_lane;
   constexpr int NBP = 64 / CW;  // bands per column handled by a wave (power of two)
   constexpr int W = 32 / CW;    // waves per workgroup
-  constexpr int K = (CW / 4) & 7;
+  using IO = TileIO<CW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *tile = reinterpret_cast<float *>(smem);                           // [NBP*32][32]
   uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * 32 * 32);    // [NBP][32]
@@ -109,15 +109,14 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 
   if constexpr (!XF) {
     // ---- phase 0: the whole tile, HBM -> LDS --------------------------------------------
-    // one instruction = 64 granules = 8 rows of 128 B; all 8 rows belong to one band
-    for (int i = wave; i < NBP * 4; i += W) {
-      const int row = 8 * i + (lane >> 3);
-      const int slot = lane & 7;
-      const int gg = slot ^ (((i >> 2) * K) & 7);  // global granule that lands in this slot
-      if (row < n && 4 * gg < cols_left) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + 4 * gg),
-            (__attribute__((address_space(3))) void *)(tile + i * 256), 16, 0, EDT_TILE_LOAD_AUX);
+    // one instruction = 64 lanes x kGran floats = kRows rows of 128 B, all rows in one band
+    for (int i = wave; i < NBP * 32 / IO::kRows; i += W) {
+      const int row = io_row<CW>(i, lane), gc = io_gcol<CW>(i, lane);
+      if (row < n && gc < cols_left) {
+        const auto *src = (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + gc);
+        auto *dst = (__attribute__((address_space(3))) void *)(tile + i * 64 * IO::kGran);
+        if constexpr (IO::kGran == 4) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, EDT_TILE_LOAD_AUX);
+        else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, EDT_TILE_LOAD_AUX);
       }
     }
   } else {
@@ -217,14 +216,16 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     for (int r = 0; r < 32; ++r) own[r * 32] = f[r];
   }
   __syncthreads();
-  for (int i = wave; i < NBP * 4; i += W) {
-    const int row = 8 * i + (lane >> 3);
-    const int slot = lane & 7;
-    const int gg = slot ^ (((i >> 2) * K) & 7);
-    if (row < n && 4 * gg < cols_left) {
-      typedef float v4f __attribute__((ext_vector_type(4)));
-      const v4f v = *reinterpret_cast<const v4f *>(tile + i * 256 + lane * 4);
-      EDT_TILE_STORE(reinterpret_cast<v4f *>(Ftile + (int64_t)row * st + 4 * gg), v);
+  for (int i = wave; i < NBP * 32 / IO::kRows; i += W) {
+    const int row = io_row<CW>(i, lane), gc = io_gcol<CW>(i, lane);
+    if (row < n && gc < cols_left) {
+      if constexpr (IO::kGran == 4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = *reinterpret_cast<const v4f *>(tile + io_lds_word<CW>(i, lane));
+        EDT_TILE_STORE(reinterpret_cast<v4f *>(Ftile + (int64_t)row * st + gc), v);
+      } else {
+        Ftile[(int64_t)row * st + gc] = tile[io_lds_word<CW>(i, lane)];
+      }
     }
   }
 }
@@ -233,8 +234,8 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 // launcher
 // ---------------------------------------------------------------------------------------
 bool column_pass_wave_supported(const AxisGeom &g) {
-  // rows in VGPRs: one band per lane, at most 16 bands per column (n <= 512); 16-byte granules
-  return g.nbands >= 1 && g.nbands <= 16 && (g.sx % 4) == 0 && (g.stride % 4) == 0 &&
+  // rows in VGPRs: one band per lane, at most 32 bands per column (n <= 1024); 16-byte granules
+  return g.nbands >= 1 && g.nbands <= 32 && (g.sx % 4) == 0 && (g.stride % 4) == 0 &&
          (g.outer_stride % 4) == 0;
 }
 
@@ -279,6 +280,7 @@ static int launch_wave_any(float *F, const uint32_t *nz, const uint32_t *rs, con
   if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream);
   if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream);
   if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream);
+  if (NB <= 32 && xf == nullptr) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, nullptr, stream);
   set_error("axis too long for the wave column pass");
   return EDT_ERR_UNSUPPORTED;
 }

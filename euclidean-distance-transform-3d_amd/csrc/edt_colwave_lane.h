@@ -73,7 +73,7 @@ enum : int { kLaneEpiToInf = 1, kLaneEpiSqrt = 2 };
 // half-wave (32/CW bands x CW columns) read 32 different banks when each reads "its" row.
 // The bit planes ([band][32] words) use the same rotation.
 template <int CW>
-EDT_LANE int addr_swz(int band) { return ((band * ((CW / 4) & 7)) & 7) << 2; }
+EDT_LANE int addr_swz(int band) { return (band * CW) & 31; }  // rotate by one wave's columns per band
 template <int CW>
 EDT_LANE int addr_tile(int colc, int row) { return (row << 5) + (colc ^ addr_swz<CW>(row >> 5)); }
 template <int CW>
@@ -151,6 +151,25 @@ EDT_LANE float xpass_value(const XRowMeta &m, int h, int cbase, int col, const f
   memcpy(&out, &f, 4);
   return out;
 }
+
+// How one wave-wide memory instruction of the tile fill / write-back maps to the tile: lane l of
+// instruction i moves kGran consecutive floats of tile row `row` whose LDS words are linear
+// (row*32 + phys .. ) -- that is what global_load_lds requires -- and whose global columns are
+// phys ^ swz(band).  16-byte granules where the rotation is a multiple of 4 columns (CW >= 4),
+// single floats for the 2-column waves of 1024-row axes.
+template <int CW>
+struct TileIO {
+  static constexpr int kGran = CW >= 4 ? 4 : 1;        // floats per lane
+  static constexpr int kRows = 64 * kGran / 32;         // tile rows per instruction
+};
+template <int CW>
+EDT_LANE int io_row(int i, int lane) { return TileIO<CW>::kRows * i + (lane * TileIO<CW>::kGran) / 32; }
+template <int CW>
+EDT_LANE int io_gcol(int i, int lane) {
+  return ((lane * TileIO<CW>::kGran) & 31) ^ addr_swz<CW>(io_row<CW>(i, lane) >> 5);
+}
+template <int CW>
+EDT_LANE int io_lds_word(int i, int lane) { return (i * 64 + lane) * TileIO<CW>::kGran; }
 
 // per-band inputs of that scan
 EDT_LANE int band_last_start(uint32_t rsw, int row0) { return rsw ? row0 + 31 - clz32(rsw) : -1; }

@@ -422,7 +422,7 @@ int launch_row_records(int dtype, const void *labels, void *meta, float *ttab, u
 }
 
 bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
-  return sx >= 1 && sx <= 512 && sy * sz < (int64_t)1 << 30 && sx * sy * sz < ((int64_t)1 << 40);
+  return sx >= 1 && sx <= 1024 && sy * sz < (int64_t)1 << 30 && sx * sy * sz < ((int64_t)1 << 40);
 }
 
 template <typename T, int NC>
@@ -458,7 +458,8 @@ static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uin
   if (nc <= 1) GO(1);
   if (nc <= 2) GO(2);
   if (nc <= 4) GO(4);
-  GO(8);
+  if (nc <= 8) GO(8);
+  GO(16);
 #undef GO
 }
 

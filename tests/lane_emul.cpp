@@ -27,17 +27,16 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
                const float *Ttab = nullptr, int idx_inf = 0, int flim = 0) {
   constexpr int NBP = 64 / CW;
   constexpr int W = 32 / CW;
-  constexpr int K = (CW / 4) & 7;
+  using IO = TileIO<CW>;
   std::vector<float> tile((size_t)NBP * 32 * 32, -12345.0f);
   std::vector<uint32_t> alive((size_t)NBP * 32, 0), rsp((size_t)NBP * 32, 0);
   const int cols_left = (int)(sx - x0);
   // phase 0: the swizzled fill, exactly as the kernel addresses it
-  for (int i = 0; i < NBP * 4; ++i)
+  for (int i = 0; i < NBP * 32 / IO::kRows; ++i)
     for (int lane = 0; lane < 64; ++lane) {
-      const int row = 8 * i + (lane >> 3), slot = lane & 7;
-      const int gg = slot ^ (((i >> 2) * K) & 7);
-      if (row < n && 4 * gg < cols_left)
-        std::memcpy(&tile[(size_t)i * 256 + lane * 4], F + x0 + (int64_t)row * stride + 4 * gg, 16);
+      const int row = io_row<CW>(i, lane), gc = io_gcol<CW>(i, lane);
+      if (row < n && gc < cols_left)
+        std::memcpy(&tile[(size_t)io_lds_word<CW>(i, lane)], F + x0 + (int64_t)row * stride + gc, 4 * IO::kGran);
     }
   struct PerLane { Lane L; float f[32]; uint32_t aw, flat; Hull1 H; };
   std::vector<PerLane> lanes((size_t)W * 64);
@@ -133,12 +132,11 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
     float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
     for (int r = 0; r < 32; ++r) own[r * 32] = P.f[r];
   }
-  for (int i = 0; i < NBP * 4; ++i)
+  for (int i = 0; i < NBP * 32 / IO::kRows; ++i)
     for (int lane = 0; lane < 64; ++lane) {
-      const int row = 8 * i + (lane >> 3), slot = lane & 7;
-      const int gg = slot ^ (((i >> 2) * K) & 7);
-      if (row < n && 4 * gg < cols_left)
-        std::memcpy(F + x0 + (int64_t)row * stride + 4 * gg, &tile[(size_t)i * 256 + lane * 4], 16);
+      const int row = io_row<CW>(i, lane), gc = io_gcol<CW>(i, lane);
+      if (row < n && gc < cols_left)
+        std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<CW>(i, lane)], 4 * IO::kGran);
     }
 }
 
@@ -160,7 +158,7 @@ void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n
 extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t sx, int64_t n, float w,
                                      int bb, int epi) {
   const int NB = (int)((n + 31) / 32);
-  if (NB < 1 || NB > 16 || sx % 4 != 0) return -1;
+  if (NB < 1 || NB > 32 || sx % 4 != 0) return -1;
   std::vector<uint32_t> nz((size_t)NB * sx, 0), rs((size_t)NB * sx, 0);
   for (int64_t x = 0; x < sx; ++x)
     for (int64_t y = 0; y < n; ++y) {
@@ -172,7 +170,8 @@ extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t s
   if (NB <= 2) pass_cw<32>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
   else if (NB <= 4) pass_cw<16>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
   else if (NB <= 8) pass_cw<8>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
-  else pass_cw<4>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  else if (NB <= 16) pass_cw<4>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  else pass_cw<2>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
   return 0;
 }
 

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle fuzz over shapes / dtypes / label structures (diagnostics; the regular
+parity tests live in tests/).  usage: python tools/fuzz_gpu.py [ncases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "euclidean-distance-transform-3d_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import edt
+from oracle import harness
+from synth import blocky_labels
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+if not harness.have_port():
+    harness.build("port")
+o = harness.port()
+dtypes = [np.uint8, np.uint16, np.uint32, np.uint64, np.float32, bool]
+bad = 0
+t0 = time.time()
+for i in range(ncases):
+    dims = 3 if rng.random() < 0.8 else 2
+    big = int(rng.integers(0, dims))
+    shape = []
+    for d in range(dims):
+        hi = 1100 if d == big else 90
+        s = int(rng.integers(1, hi))
+        if rng.random() < 0.5:
+            s = max(4, s // 4 * 4)
+        shape.append(s)
+    shape = tuple(shape)
+    if np.prod(shape) > 6e6:
+        continue
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        lab = np.ones(shape, dtype=np.uint32)
+    else:
+        lab = blocky_labels(shape, nlabels=int(rng.integers(1, 6)), zero_frac=float(rng.random() * 0.3),
+                            block=int(rng.integers(1, 50)), rng=rng)
+    dt = dtypes[i % len(dtypes)]
+    lab = np.asfortranarray(lab.astype(dt)) if rng.random() < 0.7 else np.ascontiguousarray(lab.astype(dt))
+    an = tuple(float(a) for a in rng.choice([1, 2, 6, 30, 0.5, 1.3, 7.25], size=dims))
+    bb = bool(rng.integers(0, 2))
+    want = o.edtsq(lab, an, bb)
+    got = edt.edtsq(lab, anisotropy=an, black_border=bb)
+    if not np.array_equal(got, want):
+        bad += 1
+        print("MISMATCH", shape, dt.__name__, an, bb, int((got != want).sum()))
+print(f"{ncases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)

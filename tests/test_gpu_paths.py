@@ -49,8 +49,8 @@ def test_kernel_families_agree_with_the_oracle(edt_gpu, oracle_port, mode, name)
 
 
 def test_axes_beyond_the_wave_kernels(edt_gpu, oracle_port):
-    """Rows / columns of 513..2048 voxels take the LDS-staged row kernel and the workgroup-phased column
-    kernel (the 1024^3 multi-GPU configuration lives here)."""
+    """Rows / axes of 513..1024 voxels still take the wave kernels (16 chunks per row, 2-column waves);
+    beyond 1024 the LDS-staged row kernel and the workgroup-phased column kernel take over."""
     rng = np.random.default_rng(5)
     for shape in ((1030, 40, 24), (48, 1040, 12), (40, 36, 1100), (1024, 64, 8), (600, 700, 3)):
         lab = np.asfortranarray(blocky_labels(shape, nlabels=4, zero_frac=0.1, block=int(rng.integers(5, 60)),

@@ -141,16 +141,23 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
       above[c] = y0 > 0 ? buf_load<T>(make_rsrc(base - sx), xs[c], 0) : T(0);
     }
 
+    // Software pipeline.  On gfx9 loads and stores retire through ONE in-order counter (vmcnt), so
+    // a row whose loads are issued after the previous row's stores cannot be consumed before those
+    // stores have completed: load latency and store latency add up per row.  Here the loads of
+    // row r+1 are issued BEFORE the stores of row r; waiting for them then leaves the 8 younger
+    // stores in flight (s_waitcnt vmcnt(8)) and they drain behind the next row's arithmetic.
+    T lab[NC], left[NC], below[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      lab[c] = buf_load<T>(rs_lab, xs[c], 0);
+      left[c] = buf_load<T>(rs_lab, xl[c], 0);
+      below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], 0) : lab[c];
+    }
+    int pend[NC];  // results of the previous row, stored one iteration late (see below)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) pend[c] = 0;
 #pragma unroll 1
     for (int r = 0; r < nrows; ++r) {
-      const uint32_t soff = (uint32_t)(r * sx) * (uint32_t)sizeof(T);  // wave-uniform row offset
-      T lab[NC], left[NC], below[NC];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        lab[c] = buf_load<T>(rs_lab, xs[c], soff);
-        left[c] = buf_load<T>(rs_lab, xl[c], soff);
-        below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], soff) : lab[c];
-      }
       // ---- compares -> masks (SGPRs), bit words --------------------------------------------
       unsigned long long M[NC];
       unsigned long long any_start = 0;  // OR of the start masks of the row
@@ -165,6 +172,29 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
         above[c] = lab[c];
         any_start |= M[c];
         all_fg |= (fg == ~0ull ? 1u : 0u) << c;
+      }
+      // ---- the previous row's results leave now: issued after this row's loads have been waited
+      //      for and a whole distance stage before the next wait, they retire off the critical path
+      if (r > 0) {
+        const uint32_t poff = (uint32_t)((r - 1) * sx) * 4u;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int x = c * 64 + lane;
+          if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, 0);
+        }
+      }
+      // ---- next row's loads (the last row reloads itself: those hits cost nothing) ---------------
+      T cur[NC];  // this row's labels for the background select below
+      {
+        const int rn = r + 1 < nrows ? r + 1 : r;
+        const uint32_t soff = (uint32_t)(rn * sx) * (uint32_t)sizeof(T);  // wave-uniform row offset
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          cur[c] = lab[c];
+          lab[c] = buf_load<T>(rs_lab, xs[c], soff);
+          left[c] = buf_load<T>(rs_lab, xl[c], soff);
+          below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], soff) : lab[c];
+        }
       }
       // ---- run starts / ends carried across chunks (scalar unit) ----------------------------
       int pre[NC], suf[NC];
@@ -185,7 +215,6 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
         }
       }
       // ---- distances ---------------------------------------------------------------------------
-      const uint32_t ooff = (uint32_t)(r * sx) * 4u;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int x = c * 64 + lane;
@@ -209,8 +238,16 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
         const float d = __int_as_float(dL < dR ? dL : dR);  // positive floats order like integers
         int f = as_int(d * d);
         f = f < flim ? f : flim;                             // tofinite (src/edt.hpp:39-45)
-        if (!((all_fg >> c) & 1u)) f = lab[c] != T(0) ? f : 0;  // (wave-uniform test)
-        if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)f, rs_out, (uint32_t)x * 4u, ooff, 0);
+        if (!((all_fg >> c) & 1u)) f = cur[c] != T(0) ? f : 0;  // (wave-uniform test)
+        pend[c] = f;
+      }
+    }
+    {
+      const uint32_t poff = (uint32_t)((nrows - 1) * sx) * 4u;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int x = c * 64 + lane;
+        if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, 0);
       }
     }
 

@@ -223,7 +223,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   // F from them (no fp32 volume is written by pass 1 or read by pass 2).  MEASURED SLOWER on MI355X
   // (0.905 vs 0.83 ms per 512^3 step: both kernels are bound by instruction issue, not by HBM, so
   // trading 1 GB of traffic for ~25 more instructions per voxel loses) -- kept behind debug bit 128.
-  const bool fused_xy = !force_generic && (g_debug_mode & 128) && !(g_debug_mode & (64 | 32)) && sx <= 512 &&
+  const bool fused_xy = !force_generic && (g_debug_mode & 128) && !(g_debug_mode & (64 | 32)) && sx <= 512 && sx % 4 == 0 && p.gy.nbands <= 16 &&
                         row_pass_wave_supported(dtype, sx, sy, sz) && column_pass_wave_supported(p.gy);
   if (fused_xy) {
     {

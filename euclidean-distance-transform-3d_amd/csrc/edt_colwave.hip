@@ -83,7 +83,7 @@ template <int CW, bool BB, bool XF>
 __global__ void __launch_bounds__(2048 / CW, 4)
 k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
                    const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x,
-                   int epi, int dbg, XFuse xf) {
+                   int epi, int dbg, int aligned16, XFuse xf) {
   using namespace edt_lane;
   constexpr int NBP = 64 / CW;  // bands per column handled by a wave (power of two)
   constexpr int W = 32 / CW;    // waves per workgroup
@@ -105,18 +105,26 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   const int64_t x0 = xt * 32;
   const int64_t st = g.stride;
   float *Ftile = F + x0 + o * g.outer_stride;
-  const int cols_left = (int)(g.sx - x0);  // columns of this tile that exist (multiple of 4)
+  const int cols_left = (int)(g.sx - x0);  // columns of this tile that exist
 
   if constexpr (!XF) {
     // ---- phase 0: the whole tile, HBM -> LDS --------------------------------------------
-    // one instruction = 64 lanes x kGran floats = kRows rows of 128 B, all rows in one band
-    for (int i = wave; i < NBP * 32 / IO::kRows; i += W) {
-      const int row = io_row<CW>(i, lane), gc = io_gcol<CW>(i, lane);
-      if (row < n && gc < cols_left) {
-        const auto *src = (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + gc);
-        auto *dst = (__attribute__((address_space(3))) void *)(tile + i * 64 * IO::kGran);
-        if constexpr (IO::kGran == 4) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, EDT_TILE_LOAD_AUX);
-        else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, EDT_TILE_LOAD_AUX);
+    // one instruction = 64 lanes x G floats = 2*G rows of 128 B, all rows in one band
+    if (IO::kGran == 4 && aligned16) {
+      for (int i = wave; i < NBP * 4; i += W) {
+        const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+        if (row < n && gc < cols_left)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + gc),
+              (__attribute__((address_space(3))) void *)(tile + i * 256), 16, 0, EDT_TILE_LOAD_AUX);
+      }
+    } else {
+      for (int i = wave; i < NBP * 16; i += W) {
+        const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+        if (row < n && gc < cols_left)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + gc),
+              (__attribute__((address_space(3))) void *)(tile + i * 64), 4, 0, EDT_TILE_LOAD_AUX);
       }
     }
   } else {
@@ -216,16 +224,19 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     for (int r = 0; r < 32; ++r) own[r * 32] = f[r];
   }
   __syncthreads();
-  for (int i = wave; i < NBP * 32 / IO::kRows; i += W) {
-    const int row = io_row<CW>(i, lane), gc = io_gcol<CW>(i, lane);
-    if (row < n && gc < cols_left) {
-      if constexpr (IO::kGran == 4) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f v = *reinterpret_cast<const v4f *>(tile + io_lds_word<CW>(i, lane));
+  if (IO::kGran == 4 && aligned16) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    for (int i = wave; i < NBP * 4; i += W) {
+      const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+      if (row < n && gc < cols_left) {
+        const v4f v = *reinterpret_cast<const v4f *>(tile + io_lds_word<4>(i, lane));
         EDT_TILE_STORE(reinterpret_cast<v4f *>(Ftile + (int64_t)row * st + gc), v);
-      } else {
-        Ftile[(int64_t)row * st + gc] = tile[io_lds_word<CW>(i, lane)];
       }
+    }
+  } else {
+    for (int i = wave; i < NBP * 16; i += W) {
+      const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+      if (row < n && gc < cols_left) Ftile[(int64_t)row * st + gc] = tile[io_lds_word<1>(i, lane)];
     }
   }
 }
@@ -234,9 +245,8 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 // launcher
 // ---------------------------------------------------------------------------------------
 bool column_pass_wave_supported(const AxisGeom &g) {
-  // rows in VGPRs: one band per lane, at most 32 bands per column (n <= 1024); 16-byte granules
-  return g.nbands >= 1 && g.nbands <= 32 && (g.sx % 4) == 0 && (g.stride % 4) == 0 &&
-         (g.outer_stride % 4) == 0;
+  // rows in VGPRs: one band per lane, at most 32 bands per column (n <= 1024)
+  return g.nbands >= 1 && g.nbands <= 32;
 }
 
 template <int CW, bool BB, bool XF>
@@ -254,9 +264,12 @@ static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, con
   const int64_t tiles_x = ceil_div(g.sx, 32);
   const int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;
+  // 16-byte granules need 16-byte aligned rows; otherwise the tile moves float by float
+  const int aligned16 = (g.sx % 4) == 0 && (g.stride % 4) == 0 && (g.outer_stride % 4) == 0 &&
+                        (reinterpret_cast<uintptr_t>(F) % 16) == 0;
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF>), dim3((unsigned)tiles), dim3(2048 / CW), lds, stream,
-                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), xf);
+                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), aligned16, xf);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }

@@ -153,23 +153,21 @@ EDT_LANE float xpass_value(const XRowMeta &m, int h, int cbase, int col, const f
 }
 
 // How one wave-wide memory instruction of the tile fill / write-back maps to the tile: lane l of
-// instruction i moves kGran consecutive floats of tile row `row` whose LDS words are linear
-// (row*32 + phys .. ) -- that is what global_load_lds requires -- and whose global columns are
-// phys ^ swz(band).  16-byte granules where the rotation is a multiple of 4 columns (CW >= 4),
-// single floats for the 2-column waves of 1024-row axes.
+// instruction i moves G consecutive floats of tile row `row` whose LDS words are linear
+// (row*32 + phys ..) -- that is what global_load_lds requires -- and whose global columns are
+// phys ^ swz(band).  G = 4 (16-byte granules) needs the band rotation to be a multiple of 4
+// columns (CW >= 4) and 16-byte aligned rows in memory; G = 1 serves the 2-column waves of
+// 1024-row axes and volumes whose x extent is not a multiple of 4.
 template <int CW>
 struct TileIO {
-  static constexpr int kGran = CW >= 4 ? 4 : 1;        // floats per lane
-  static constexpr int kRows = 64 * kGran / 32;         // tile rows per instruction
+  static constexpr int kGran = CW >= 4 ? 4 : 1;  // widest granule this wave shape allows
 };
-template <int CW>
-EDT_LANE int io_row(int i, int lane) { return TileIO<CW>::kRows * i + (lane * TileIO<CW>::kGran) / 32; }
-template <int CW>
-EDT_LANE int io_gcol(int i, int lane) {
-  return ((lane * TileIO<CW>::kGran) & 31) ^ addr_swz<CW>(io_row<CW>(i, lane) >> 5);
-}
-template <int CW>
-EDT_LANE int io_lds_word(int i, int lane) { return (i * 64 + lane) * TileIO<CW>::kGran; }
+template <int CW, int G>
+EDT_LANE int io_row(int i, int lane) { return (64 * G / 32) * i + (lane * G) / 32; }
+template <int CW, int G>
+EDT_LANE int io_gcol(int i, int lane) { return ((lane * G) & 31) ^ addr_swz<CW>(io_row<CW, G>(i, lane) >> 5); }
+template <int G>
+EDT_LANE int io_lds_word(int i, int lane) { return (i * 64 + lane) * G; }
 
 // per-band inputs of that scan
 EDT_LANE int band_last_start(uint32_t rsw, int row0) { return rsw ? row0 + 31 - clz32(rsw) : -1; }

@@ -31,13 +31,24 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
   std::vector<float> tile((size_t)NBP * 32 * 32, -12345.0f);
   std::vector<uint32_t> alive((size_t)NBP * 32, 0), rsp((size_t)NBP * 32, 0);
   const int cols_left = (int)(sx - x0);
-  // phase 0: the swizzled fill, exactly as the kernel addresses it
-  for (int i = 0; i < NBP * 32 / IO::kRows; ++i)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int row = io_row<CW>(i, lane), gc = io_gcol<CW>(i, lane);
-      if (row < n && gc < cols_left)
-        std::memcpy(&tile[(size_t)io_lds_word<CW>(i, lane)], F + x0 + (int64_t)row * stride + gc, 4 * IO::kGran);
-    }
+  // phase 0: the swizzled fill, exactly as the kernel addresses it (16-byte granules when the rows
+  // are 16-byte aligned and the wave shape allows, single floats otherwise)
+  const bool gran4 = IO::kGran == 4 && sx % 4 == 0;
+  if (gran4) {
+    for (int i = 0; i < NBP * 4; ++i)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+        if (row < n && gc < cols_left)
+          std::memcpy(&tile[(size_t)io_lds_word<4>(i, lane)], F + x0 + (int64_t)row * stride + gc, 16);
+      }
+  } else {
+    for (int i = 0; i < NBP * 16; ++i)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+        if (row < n && gc < cols_left)
+          std::memcpy(&tile[(size_t)io_lds_word<1>(i, lane)], F + x0 + (int64_t)row * stride + gc, 4);
+      }
+  }
   struct PerLane { Lane L; float f[32]; uint32_t aw, flat; Hull1 H; };
   std::vector<PerLane> lanes((size_t)W * 64);
   for (int wave = 0; wave < W; ++wave)
@@ -132,12 +143,21 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
     float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
     for (int r = 0; r < 32; ++r) own[r * 32] = P.f[r];
   }
-  for (int i = 0; i < NBP * 32 / IO::kRows; ++i)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int row = io_row<CW>(i, lane), gc = io_gcol<CW>(i, lane);
-      if (row < n && gc < cols_left)
-        std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<CW>(i, lane)], 4 * IO::kGran);
-    }
+  if (gran4) {
+    for (int i = 0; i < NBP * 4; ++i)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+        if (row < n && gc < cols_left)
+          std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<4>(i, lane)], 16);
+      }
+  } else {
+    for (int i = 0; i < NBP * 16; ++i)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+        if (row < n && gc < cols_left)
+          std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<1>(i, lane)], 4);
+      }
+  }
 }
 
 template <int CW>
@@ -158,7 +178,7 @@ void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n
 extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t sx, int64_t n, float w,
                                      int bb, int epi) {
   const int NB = (int)((n + 31) / 32);
-  if (NB < 1 || NB > 32 || sx % 4 != 0) return -1;
+  if (NB < 1 || NB > 32) return -1;
   std::vector<uint32_t> nz((size_t)NB * sx, 0), rs((size_t)NB * sx, 0);
   for (int64_t x = 0; x < sx; ++x)
     for (int64_t y = 0; y < n; ++y) {

@@ -14,10 +14,12 @@
 // The tile is read from HBM exactly once and written exactly once (8 B/voxel of traffic
 // against 12 B/voxel in the reference's data-movement model, which re-reads the labels).
 //
-// LDS image: fp32 tile [rows][32], the 16-byte granule of a column XOR-rotated by its band
+// LDS image: fp32 tile [rows][32], the columns of a wave XOR-rotated by CW columns per band
 // (edt_colwave_lane.h: addr_tile) so that "every lane reads its own row" is bank-conflict free;
-// because global_load_lds writes LDS linearly (lane i -> base + 16*i), the rotation is applied
-// to the per-lane SOURCE address, and again when the results are streamed back.
+// because global_load_lds writes LDS linearly (lane i -> base + 16*i, or 4*i for the 2-column waves
+// of 1024-row axes and for rows that are not 16-byte aligned), the rotation is applied to the
+// per-lane SOURCE address, and again when the results are streamed back.
+// Axes: up to 1024 rows (NBP = 2..32 bands per column, CW = 32..2 columns per wave).
 #include "edt_common.h"
 #include "edt_kernels.h"
 

@@ -15,13 +15,16 @@
 // phases): the lower envelope of the parabolas  w2*(p-j)^2 + F[j]  over one label run is the
 // lower convex hull of the points (j, F[j] + w2*j^2); a hull is a SUBSET of the rows and is
 // stored as one `alive` bit per row.
-//   phase 1: every lane builds the hull of its own 32 rows (monotone chain, rows in VGPRs);
+//   phase 1: every lane builds the hull of its own 32 rows (monotone chain, rows in VGPRs) and
+//            notes where the field is flat (|F[r]-F[r-1]| <= w2);
 //   phase 2: log2(NBP) rounds of pairwise hull merges across band-group boundaries (bridge
-//            walk), only where a label run crosses the boundary;
-//   phase 3: every lane sweeps its 32 rows over the merged hull and evaluates the
-//            reference's own expression fl32(w2*(p-j)^2 + F[j]) (src/edt.hpp:230, :307),
-//            the border parabolas (src/edt.hpp:233-242, :310-311) and the fused
-//            toinfinite / sqrt epilogue (src/edt.hpp:47-53, :599-601).
+//            walk), only where a label run crosses the boundary -- skipped altogether by a wave
+//            whose boundaries are all "quiet" (boundary_quiet);
+//   phase 3: rows that own themselves (own_mask: flat on both sides of an alive row) take
+//            min(F, border) directly; the others are swept over the merged hull with the
+//            reference's own expression fl32(w2*(p-j)^2 + F[j]) (src/edt.hpp:230, :307), the
+//            border parabolas (src/edt.hpp:233-242, :310-311) and the fused toinfinite / sqrt
+//            epilogue (src/edt.hpp:47-53, :599-601).
 //
 // Arithmetic notes (bit parity with the reference):
 //   * w2 is the fp32 product w*w widened to fp64 (src/edt.hpp:181, :258);

@@ -116,3 +116,26 @@ def test_sdf_definition(edt_gpu):
     got = edt_gpu.sdf(lab, anisotropy=(2, 3, 5), black_border=True)
     want = edt_gpu.edt(lab, anisotropy=(2, 3, 5), black_border=True) - edt_gpu.edt(lab == 0, anisotropy=(2, 3, 5), black_border=True)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("exp", range(-7, 9))
+def test_anisotropy_range(edt_gpu, oracle_port, exp):
+    # automated_test.py:791-817: anisotropies from 1e-7 to 1e8 -- here bit-for-bit against the oracle,
+    # on a multi-label volume with background, both border modes
+    from synth import blocky_labels
+    rng = np.random.default_rng(100 + exp)
+    lab = np.asfortranarray(blocky_labels((72, 40, 33), nlabels=4, zero_frac=0.15, block=5, rng=rng).astype(np.uint16))
+    w = 10.0 ** exp
+    for an in ((w, w, w), (w, 1.0, 3.0 * w)):
+        for bb in (True, False):
+            want = oracle_port.edtsq(lab, an, bb)
+            got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+            assert np.array_equal(got, want, equal_nan=True), (an, bb)
+
+
+def test_nan_large_array(edt_gpu):
+    # automated_test.py:819-823: a 46342 x 1 array of ones must not produce NaN
+    lab = np.ones((46342, 1), dtype=np.float64)
+    out = edt_gpu.edtsq(lab, anisotropy=(1, 1), black_border=True)
+    assert not np.any(np.isnan(out))
+    assert out.max() == 1.0

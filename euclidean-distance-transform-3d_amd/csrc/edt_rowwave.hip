@@ -294,8 +294,13 @@ __global__ void __launch_bounds__(kRowWaves * 64)
 k_row_records(const T *__restrict__ labels, uint4 *__restrict__ meta, uint32_t *__restrict__ nz_y,
               uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, int bb,
               int nby, int ngroups, int ncr, int xcd_sched) {
+  // the records of a wave's 32 rows are collected in LDS ([chunk][row], 16 B each) and leave as
+  // 512-byte runs at the end: the row loop then holds loads only, so the next row's loads can be
+  // in flight during this row's compares (stores would serialise behind them, see k_row_pass_wave)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
+  uint4 *recbuf = reinterpret_cast<uint4 *>(smem) + (size_t)wave * NC * 32;
   const int64_t sxy = (int64_t)sx * sy;
 
   // Work distribution.  The `zs` bits need the labels of slice z-1, which some other wave reads as
@@ -331,16 +336,15 @@ k_row_records(const T *__restrict__ labels, uint4 *__restrict__ meta, uint32_t *
       above[c] = y0 > 0 ? buf_load<T>(make_rsrc(base - sx), xs[c], 0) : T(0);
     }
 
+    T lab[NC], left[NC], below[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      lab[c] = buf_load<T>(rs_lab, xs[c], 0);
+      left[c] = buf_load<T>(rs_lab, xl[c], 0);
+      below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], 0) : lab[c];
+    }
 #pragma unroll 1
     for (int r = 0; r < nrows; ++r) {
-      const uint32_t soff = (uint32_t)(r * sx) * (uint32_t)sizeof(T);  // wave-uniform row offset
-      T lab[NC], left[NC], below[NC];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        lab[c] = buf_load<T>(rs_lab, xs[c], soff);
-        left[c] = buf_load<T>(rs_lab, xl[c], soff);
-        below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], soff) : lab[c];
-      }
       unsigned long long M[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
@@ -349,6 +353,16 @@ k_row_records(const T *__restrict__ labels, uint4 *__restrict__ meta, uint32_t *
         shift_in(ysw[c], __ballot(lab[c] != above[c]));
         if (HAS_Z) shift_in(zsw[c], __ballot(lab[c] != below[c]));
         above[c] = lab[c];
+      }
+      {  // next row's loads (the last row reloads itself)
+        const int rn = r + 1 < nrows ? r + 1 : r;
+        const uint32_t soff = (uint32_t)(rn * sx) * (uint32_t)sizeof(T);  // wave-uniform row offset
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          lab[c] = buf_load<T>(rs_lab, xs[c], soff);
+          left[c] = buf_load<T>(rs_lab, xl[c], soff);
+          below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], soff) : lab[c];
+        }
       }
       // run starts / ends carried across chunks (scalar unit).  Voxel 0 never marks itself: the
       // start of the row is the initial carry -- position 0 with a black border, far away without.
@@ -376,10 +390,20 @@ k_row_records(const T *__restrict__ labels, uint4 *__restrict__ meta, uint32_t *
           rec.y = (uint32_t)(M[c] >> 32);
           rec.z = (uint32_t)pre[c];
           rec.w = (uint32_t)suf[c];
-          meta[((int64_t)z * ncr + c) * sy + (y0 + r)] = rec;
+          recbuf[c * 32 + r] = rec;
         }
       }
     }
+    // records out: chunk c, rows y0..y0+nrows-1 are contiguous in [z][chunk][y]
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c2 = 0; c2 < NC; c2 += 2) {
+      const int c = c2 + (lane >> 5), rr = lane & 31;
+      if (c < ncr && c < NC && rr < nrows) meta[((int64_t)z * ncr + c) * sy + (y0 + rr)] = recbuf[c * 32 + rr];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     // ---- the three bit words of this (z, y-band) -----------------------------------------------
     const int sh = 32 - nrows;
@@ -416,11 +440,13 @@ static int launch_row_records_tn(const void *labels, void *meta, uint32_t *nz_y,
   const int xcd_sched = row_xcd_schedule(nby, sz, &blocks);
   const int ncr = (int)ceil_div(sx, 64);
   if (zs_y != nullptr)
-    hipLaunchKernelGGL((k_row_records<T, NC, true>), dim3((unsigned)blocks), dim3(kRowWaves * 64), 0, stream,
+    hipLaunchKernelGGL((k_row_records<T, NC, true>), dim3((unsigned)blocks), dim3(kRowWaves * 64),
+                       (size_t)kRowWaves * NC * 32 * sizeof(uint4), stream,
                        (const T *)labels, (uint4 *)meta, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, bb,
                        (int)nby, (int)ngroups, ncr, xcd_sched);
   else
-    hipLaunchKernelGGL((k_row_records<T, NC, false>), dim3((unsigned)blocks), dim3(kRowWaves * 64), 0, stream,
+    hipLaunchKernelGGL((k_row_records<T, NC, false>), dim3((unsigned)blocks), dim3(kRowWaves * 64),
+                       (size_t)kRowWaves * NC * 32 * sizeof(uint4), stream,
                        (const T *)labels, (uint4 *)meta, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, bb,
                        (int)nby, (int)ngroups, ncr, xcd_sched);
   EDT_HIP_TRY(hipGetLastError());

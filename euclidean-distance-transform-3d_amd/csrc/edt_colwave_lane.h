@@ -58,6 +58,11 @@ EDT_LANE int ctz32(uint32_t v) { return __builtin_ctz(v); }
 EDT_LANE double fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #else
 #define EDT_SHIFT_IN(w, cond) (w) = ((w) << 1) | ((cond) ? 1u : 0u)
+#ifdef EDT_LANE_STATS
+// host emulation only: event counters (::edt_lane_stat is declared by tests/lane_stats.cpp, which
+// aggregates them per wave and row)
+#define EDT_STAT(kind, row, count) ::edt_lane_stat((kind), (row), (count))
+#endif
 EDT_LANE uint32_t brev32(uint32_t v) {
   uint32_t r = 0;
   for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
@@ -70,6 +75,13 @@ EDT_LANE double fma64(double a, double b, double c) { return fma(a, b, c); }
 #endif
 
 enum : int { kLaneEpiToInf = 1, kLaneEpiSqrt = 2 };
+
+#ifndef EDT_STAT
+#define EDT_STAT(kind, row, count) ((void)0)
+#endif
+// event kinds of EDT_STAT
+enum : int { kStPop = 0, kStBridgeCall, kStBridgeStep, kStOwnRow, kStGeneralRow, kStResync, kStPrologueStep,
+             kStAdvance, kStFindNext, kStFindNextLds, kStFresh, kStKinds };
 
 // LDS addressing of one lane.  The fp32 tile is row-major [row][32]; the 16-byte granule
 // that holds the lane's column is XOR-rotated by its band so that the 32 lanes of a
@@ -285,6 +297,7 @@ EDT_LANE Hull1 phase1_hull(const Lane &L, const float *f, float fprev) {
       double Fa = ldF<CW>(L, L.row0 + ia);
       double Ftop = Fb;
       while (true) {
+        EDT_STAT(kStPop, r, 1);
         aw &= ~(1u << ib);
         ib = ia;
         Ftop = Fa;
@@ -381,7 +394,9 @@ EDT_LANE void phase2_merge(const Lane &L, int half) {
   int vn = next_set<CW>(L.alive, L.colc, v, Rhi);
   double Fup = up >= 0 ? ldF<CW>(L, up) : 0.0;
   double Fvn = vn >= 0 ? ldF<CW>(L, vn) : 0.0;
+  EDT_STAT(kStBridgeCall, half, 1);
   while (true) {
+    EDT_STAT(kStBridgeStep, half, 1);
     const double nuv = edge_num(u, Fu, v, Fv, w2);
     if (up >= 0 && nuv * (double)(u - up) <= edge_num(up, Fup, u, Fu, w2) * (double)(v - u)) {
       L.alive[addr_word<CW>(L.colc, u >> 5)] &= ~(1u << (u & 31));
@@ -426,6 +441,7 @@ EDT_LANE void find_next(const Lane &L, int jr, int r, uint32_t awrun, int run_hi
                         int &jnr, double &Fjn, double &dn) {
   const int row0 = L.row0;
   Fjn = INFINITY;
+  EDT_STAT(kStFindNext, r, 1);
   const uint32_t m = (unsigned)jr < 31u ? (awrun & (0xFFFFFFFEu << jr)) : 0u;
   if (m) {
     jnr = ctz32(m);
@@ -433,6 +449,7 @@ EDT_LANE void find_next(const Lane &L, int jr, int r, uint32_t awrun, int run_hi
     else Fjn = ldF<CW>(L, row0 + jnr);
   } else if (jr < 0 || run_hir > 31) {
     // the owner still sits in an earlier band, or the run continues past this band
+    EDT_STAT(kStFindNextLds, r, 1);
     const int q = next_set<CW>(L.alive, L.colc, (jr < 0 || jr >= 31) ? row0 + jr : row0 + 31,
                                row0 + run_hir);
     if (q >= 0) {
@@ -480,6 +497,7 @@ EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f, int epi) {
     if ((nzw >> r) & 1u) {
       const bool fresh = (rsw >> r) & 1u;
       if (fresh) {  // a run starts at this row
+        EDT_STAT(kStFresh, r, 1);
         const uint32_t above = r < 31 ? (rsw & (0xFFFFFFFEu << r)) : 0u;
         run_hir = above ? ctz32(above) - 1 : hi_carry;
         awrun = aw & (0xFFFFFFFFu >> (31 - (run_hir < 31 ? run_hir : 31))) & (0xFFFFFFFFu << r);
@@ -488,8 +506,10 @@ EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f, int epi) {
       }
       float res;
       if ((own >> r) & 1u) {
+        EDT_STAT(kStOwnRow, r, 1);
         res = f[r];  // the row's own parabola is the envelope here: no fp64 work at all
       } else {
+        EDT_STAT(kStGeneralRow, r, 1);
         const float fnext = f[r < 31 ? r + 1 : r];
         // (re)establish the sweep state where the previous row did not leave one
         bool need = false;  // the next vertex must be (re)loaded
@@ -501,6 +521,7 @@ EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f, int epi) {
           Fj = ldF<CW>(L, j);
           double vj = para(row0, j, Fj, w2);
           while (true) {
+            EDT_STAT(kStPrologueStep, r, 1);
             const int jp = prev_set<CW>(L.alive, L.colc, j, run_lo);
             if (jp < 0) break;
             const double Fjp = ldF<CW>(L, jp);
@@ -519,6 +540,7 @@ EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f, int epi) {
           Fj = (double)f[r];
           need = true;
         } else if ((own >> (r > 0 ? r - 1 : 0)) & 1u) {
+          EDT_STAT(kStResync, r, 1);
           jr = r - 1;  // the previous row owned itself (its register already holds the result)
           dj = 1.0;
           Fj = ldF<CW>(L, row0 + r - 1);
@@ -529,6 +551,7 @@ EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f, int epi) {
           if (need) find_next<CW>(L, jr, r, awrun, run_hir, fnext, jnr, Fjn, dn);
           const double cand = fma64(w2 * dn, dn, Fjn);
           if (!(cand < best)) break;  // (Fjn = +inf never wins)
+          EDT_STAT(kStAdvance, r, 1);
           best = cand;  // the next vertex takes over
           jr = jnr;
           Fj = Fjn;

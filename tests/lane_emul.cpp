@@ -17,6 +17,14 @@
 #define EDT_LANE static inline
 #include "edt_colwave_lane.h"
 
+// tests/lane_stats.cpp sets this to tell its counters which lane is running
+#ifdef EDT_LANE_STATS
+static int g_lane_base = 0;
+#define EMUL_LANE(P, lanes) (g_lane = g_lane_base + (int)(&(P) - &(lanes)[0]))
+#else
+#define EMUL_LANE(P, lanes) ((void)0)
+#endif
+
 using namespace edt_lane;
 
 namespace {
@@ -113,6 +121,7 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
   for (auto &P : lanes) {
     PerLane *below = lane_of(P.L.colc, P.L.band - 1);  // the kernel gets these through lane shuffles
     const float fprev = below ? below->f[31] : 0.0f;
+    EMUL_LANE(P, lanes);
     P.H = phase1_hull<CW>(P.L, P.f, fprev);
     P.aw = P.H.aw;
     P.flat = P.H.flat;
@@ -129,7 +138,10 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
     }
     if (all_quiet) continue;
     for (int half = 1; half < NBP; half <<= 1)
-      for (int lane = 0; lane < 64; ++lane) phase2_merge<CW>(lanes[(size_t)wave * 64 + lane].L, half);
+      for (int lane = 0; lane < 64; ++lane) {
+        EMUL_LANE(lanes[(size_t)wave * 64 + lane], lanes);
+        phase2_merge<CW>(lanes[(size_t)wave * 64 + lane].L, half);
+      }
   }
   for (auto &P : lanes) P.aw = alive[addr_word<CW>(P.L.colc, P.L.band)];
   for (auto &P : lanes) {
@@ -138,7 +150,13 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
                        above ? above->L.nzw & 1u : 0u, above ? above->L.rsw & 1u : 0u,
                        above ? above->aw & 1u : 0u, above ? above->flat & 1u : 0u);
   }
-  for (auto &P : lanes) phase3_eval<CW, BB>(P.L, P.aw, P.f, epi);
+  for (auto &P : lanes) {
+    EMUL_LANE(P, lanes);
+    phase3_eval<CW, BB>(P.L, P.aw, P.f, epi);
+  }
+#ifdef EDT_LANE_STATS
+  g_lane_base += (int)lanes.size();
+#endif
   for (auto &P : lanes) {
     float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
     for (int r = 0; r < 32; ++r) own[r * 32] = P.f[r];

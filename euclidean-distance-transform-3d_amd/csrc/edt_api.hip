@@ -297,20 +297,69 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
 }
 
 // ---- host-buffer staging -----------------------------------------------------------------
+// Device memory of the host-buffer entry points is kept between calls: hipMalloc / hipFree of the
+// gigabyte-sized label, output and scratch buffers cost more than the transfers (measured: 64 ms per
+// 512^3 uint32 call with fresh allocations, of which 2 x 9.5 ms are PCIe and 0.7 ms kernels).  One
+// process-wide pool, one host call at a time (the mutex is held for the whole call); released by
+// edt_hip_release_cache() or at exit.  EDT_HIP_NO_CACHE=1 restores allocate-per-call.
+struct DevicePool {
+  static constexpr int kSlots = 6;
+  void *p[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[kSlots] = {0, 0, 0, 0, 0, 0};
+  std::mutex m;
+  void release() {
+    for (int i = 0; i < kSlots; ++i) {
+      if (p[i]) (void)hipFree(p[i]);
+      p[i] = nullptr;
+      cap[i] = 0;
+    }
+  }
+  ~DevicePool() { /* the runtime may already be gone at static destruction: leak on purpose */ }
+};
+static DevicePool g_pool;
+
 struct DeviceBuf {
   void *p = nullptr;
-  ~DeviceBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) {
+  bool owned = false;
+  ~DeviceBuf() { if (p && owned) (void)hipFree(p); }
+  // slot < 0: private allocation, freed with the object; otherwise the pool slot is (re)used.
+  // The caller holds g_pool.m when it uses slots.
+  int alloc(size_t bytes, int slot = -1) {
     if (bytes == 0) bytes = 256;
-    hipError_t e = hipMalloc(&p, bytes);
+    if (slot >= 0) {
+      if (g_pool.cap[slot] < bytes) {
+        if (g_pool.p[slot]) (void)hipFree(g_pool.p[slot]);
+        g_pool.p[slot] = nullptr;
+        g_pool.cap[slot] = 0;
+        const hipError_t e = hipMalloc(&g_pool.p[slot], bytes);
+        if (e != hipSuccess) {
+          g_pool.p[slot] = nullptr;
+          (void)hipGetLastError();
+          g_pool.release();  // give everything back and let the caller see the failure
+          set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+          return EDT_ERR_NOMEM;
+        }
+        g_pool.cap[slot] = bytes;
+      }
+      p = g_pool.p[slot];
+      owned = false;
+      return EDT_OK;
+    }
+    const hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
       p = nullptr;
       set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
       return EDT_ERR_NOMEM;
     }
+    owned = true;
     return EDT_OK;
   }
 };
+
+static bool pool_enabled() {
+  const char *e = std::getenv("EDT_HIP_NO_CACHE");
+  return !(e && e[0] == '1');
+}
 
 static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz,
                     float wx, float wy, float wz, int flags, float *output) {
@@ -329,10 +378,13 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
   const size_t lbytes = (size_t)voxels * dtype_size(dtype);
   const size_t obytes = (size_t)voxels * sizeof(float);
   const size_t wbytes = edt_hip_workspace_bytes(dtype, ndim, sx, sy, sz);
+  const bool pooled = pool_enabled();
+  std::unique_lock<std::mutex> pool_lock(g_pool.m, std::defer_lock);
+  if (pooled) pool_lock.lock();
   DeviceBuf d_labels, d_out, d_ws;
-  if ((rc = d_labels.alloc(lbytes)) != EDT_OK) return rc;
-  if ((rc = d_out.alloc(obytes)) != EDT_OK) return rc;
-  if ((rc = d_ws.alloc(wbytes)) != EDT_OK) return rc;
+  if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
+  if ((rc = d_out.alloc(obytes, pooled ? 1 : -1)) != EDT_OK) return rc;
+  if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
   EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
   rc = run_device(d_labels.p, dtype, ndim, sx, sy, sz, wx, wy, wz, flags, (float *)d_out.p, d_ws.p,
                   wbytes, nullptr);
@@ -355,13 +407,16 @@ static int voxel_graph_host(const void *labels, int dtype, const uint8_t *graph,
   const int64_t big = X * Y * Z;
   const size_t lbytes = (size_t)voxels * dtype_size(dtype);
   const size_t wbytes = edt_hip_workspace_bytes(EDT_U8, ndim, X, Y, Z);
+  const bool pooled = pool_enabled();
+  std::unique_lock<std::mutex> pool_lock(g_pool.m, std::defer_lock);
+  if (pooled) pool_lock.lock();
   DeviceBuf d_labels, d_graph, d_big, d_bigdt, d_ws, d_out;
-  if ((rc = d_labels.alloc(lbytes)) != EDT_OK) return rc;
-  if ((rc = d_graph.alloc((size_t)voxels)) != EDT_OK) return rc;
-  if ((rc = d_big.alloc((size_t)big)) != EDT_OK) return rc;
-  if ((rc = d_bigdt.alloc((size_t)big * sizeof(float))) != EDT_OK) return rc;
-  if ((rc = d_ws.alloc(wbytes)) != EDT_OK) return rc;
-  if ((rc = d_out.alloc((size_t)voxels * sizeof(float))) != EDT_OK) return rc;
+  if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
+  if ((rc = d_out.alloc((size_t)voxels * sizeof(float), pooled ? 1 : -1)) != EDT_OK) return rc;
+  if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
+  if ((rc = d_graph.alloc((size_t)voxels, pooled ? 3 : -1)) != EDT_OK) return rc;
+  if ((rc = d_big.alloc((size_t)big, pooled ? 4 : -1)) != EDT_OK) return rc;
+  if ((rc = d_bigdt.alloc((size_t)big * sizeof(float), pooled ? 5 : -1)) != EDT_OK) return rc;
   EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
   EDT_HIP_TRY(hipMemcpy(d_graph.p, graph, (size_t)voxels, hipMemcpyHostToDevice));
   rc = launch_vg_expand(dtype, d_labels.p, (const uint8_t *)d_graph.p, (uint8_t *)d_big.p, sx, sy, sz,
@@ -465,6 +520,12 @@ int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, 
                          void *d_workspace, size_t workspace_bytes, void *stream) {
   return run_device(d_labels, dtype, ndim, sx, sy, sz, wx, wy, wz, flags, d_output, d_workspace,
                     workspace_bytes, (hipStream_t)stream);
+}
+
+int edt_hip_release_cache(void) {
+  std::lock_guard<std::mutex> lock(g_pool.m);
+  g_pool.release();
+  return EDT_OK;
 }
 
 int edt_hip_set_debug_mode(int mode) {

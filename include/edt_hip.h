@@ -100,6 +100,11 @@ int edt_hip_edt3dsq_voxel_graph(const void *labels, int dtype, const uint8_t *gr
                                 int64_t sy, int64_t sz, float wx, float wy, float wz,
                                 int black_border, float *workspace);
 
+/* The host-buffer entry points keep their device buffers (labels, output, scratch) between calls --
+ * allocating gigabytes per call costs more than moving them over PCIe.  This frees them.
+ * (EDT_HIP_NO_CACHE=1 in the environment disables the cache altogether.) */
+int edt_hip_release_cache(void);
+
 /* ---- device-resident entry points --------------------------------------------------
  * All pointers are DEVICE pointers on the current HIP device; `stream` is a hipStream_t
  * (NULL = the null stream).  Calls only enqueue work (no host synchronisation, no

@@ -456,6 +456,36 @@ static ShardPlan make_shard_plan(int64_t sx, int64_t sy, int64_t sz, void *ws) {
   return p;
 }
 
+// ---- slab records: the fast variant of the two sharded phases (edt_shard.hip) -------------------
+static int64_t record_floats(int64_t sx, int64_t ylen) {
+  return ylen * sx + 2 * ceil_div(ylen, kBandRows) * sx;
+}
+
+struct RecordPlan {
+  float *F = nullptr;                                      // pass 1 output of the slab (XY phase)
+  uint32_t *nz_y = nullptr, *ys_y = nullptr, *zs_y = nullptr;  // y-packed planes of the slab
+  uint32_t *nz_z = nullptr, *rs_z = nullptr;               // z-packed planes (Z phase)
+  BandScatter *table = nullptr;
+  size_t bytes = 0;
+};
+
+// sized for either phase on an (sx, sy, sz) block
+static RecordPlan make_record_plan(int64_t sx, int64_t sy, int64_t sz, void *ws) {
+  RecordPlan p;
+  Carver c(ws);
+  const size_t wy = (size_t)(sx * ceil_div(sy, kBandRows) * sz);
+  const size_t wz = (size_t)(sx * ceil_div(sz, kBandRows) * sy);
+  p.F = c.take<float>((size_t)(sx * sy * sz));
+  p.nz_y = c.take<uint32_t>(wy);
+  p.ys_y = c.take<uint32_t>(wy);
+  p.zs_y = c.take<uint32_t>(wy);
+  p.nz_z = c.take<uint32_t>(wz);
+  p.rs_z = c.take<uint32_t>(wz);
+  p.table = c.take<BandScatter>(1);
+  p.bytes = align_up(c.off, 256) + 256;
+  return p;
+}
+
 }  // namespace edt_amd
 
 using namespace edt_amd;
@@ -639,6 +669,114 @@ int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx
   EDT_HIP_TRY(hipMemcpyAsync(d_partial, p.bufB, (size_t)(sx * sy_local * sz) * sizeof(float),
                              hipMemcpyDeviceToDevice, stream));
   return EDT_OK;
+}
+
+int edt_hip_shard_records_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
+  if (dtype_size(dtype) == 0 || sx < 1 || sy < 1 || sz < 1) return 0;
+  if (g_debug_mode & (32 | 64)) return 0;  // diagnostics: forced fallback kernels
+  // pass 1 by the register-resident row kernel, both column passes by the wave kernel
+  return (sx <= 1024 && sy <= 1024 && sz <= 1024) ? 1 : 0;
+}
+
+size_t edt_hip_shard_record_floats(int64_t sx, int64_t y_rows) {
+  if (sx < 0 || y_rows < 0) return 0;
+  return (size_t)record_floats(sx, y_rows);
+}
+
+size_t edt_hip_shard_records_workspace_bytes(int dtype, int64_t sx, int64_t sy, int64_t sz) {
+  if (check_shape(dtype, 3, sx, sy, sz) != EDT_OK) return 0;
+  if (sx == 0 || sy == 0 || sz == 0) return 256;
+  return make_record_plan(sx, sy, sz, nullptr).bytes;
+}
+
+int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, int dtype, int64_t sx,
+                                    int64_t sy, int64_t sz_local, float wx, float wy, int flags,
+                                    int nparts, const int64_t *y_splits, void *const *d_blocks,
+                                    void *d_workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape(dtype, 3, sx, sy, sz_local);
+  if (rc != EDT_OK) return rc;
+  if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
+  if (!d_labels || !y_splits || !d_blocks || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
+  if (!edt_hip_shard_records_supported(dtype, sx, sy, sz_local)) {
+    set_error("slab records need sx, sy <= 1024 (use edt_hip_shard_xy_device)");
+    return EDT_ERR_UNSUPPORTED;
+  }
+  if (y_splits[0] != 0 || y_splits[nparts] != sy) { set_error("y_splits must run from 0 to sy"); return EDT_ERR_BAD_ARG; }
+  for (int h = 0; h < nparts; ++h) {
+    if (y_splits[h + 1] <= y_splits[h] || (y_splits[h] % kBandRows) != 0) {
+      set_error("y_splits must be increasing multiples of 32 (the last one is sy)");
+      return EDT_ERR_BAD_ARG;
+    }
+    if (!d_blocks[h]) { set_error("null destination block"); return EDT_ERR_BAD_ARG; }
+  }
+  RecordPlan p = make_record_plan(sx, sy, sz_local, d_workspace);
+  if (!d_workspace || workspace_bytes < p.bytes) {
+    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
+    return EDT_ERR_BAD_ARG;
+  }
+  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  const AxisGeom gy = make_geom_y(sx, sy, sz_local);
+  // destination map: every 32-row band of y lies inside one part
+  BandScatter sc;
+  bool aligned = (sx % 4) == 0;
+  for (int b = 0, h = 0; b < 32; ++b) {
+    if (b >= gy.nbands) { sc.rows[b] = nullptr; sc.bits[b] = nullptr; sc.ostride[b] = 0; sc.plane[b] = 0; continue; }
+    while ((int64_t)b * kBandRows >= y_splits[h + 1]) ++h;
+    const int64_t ys = y_splits[h], ylen = y_splits[h + 1] - ys, words = ceil_div(ylen, kBandRows);
+    float *blk = static_cast<float *>(d_blocks[h]);
+    sc.rows[b] = blk + ((int64_t)b * kBandRows - ys) * sx;
+    sc.bits[b] = reinterpret_cast<uint32_t *>(blk + ylen * sx) + ((int64_t)b - ys / kBandRows) * sx;
+    sc.ostride[b] = record_floats(sx, ylen);
+    sc.plane[b] = words * sx;
+    aligned = aligned && (reinterpret_cast<uintptr_t>(blk) % 16) == 0;
+  }
+  if (!aligned && (sx % 4) == 0) { set_error("destination blocks must be 16-byte aligned"); return EDT_ERR_BAD_ARG; }
+  {
+    ScopedPass t("x_pass", stream);
+    rc = launch_row_pass_wave(dtype, d_labels, p.F, p.nz_y, p.ys_y, p.zs_y, sx, sy, sz_local, wx, bb,
+                              bb ? 0 : 1, stream, d_halo);
+    if (rc != EDT_OK) return rc;
+  }
+  {
+    ScopedPass t("pack_bits", stream);
+    rc = launch_pack_record_bits(p.nz_y, p.zs_y, sc, p.table, sx, gy.nbands, sz_local, stream);
+    if (rc != EDT_OK) return rc;
+  }
+  ScopedPass t("y_pass", stream);
+  return launch_column_pass_wave(p.F, p.nz_y, p.ys_y, gy, wy, bb, 0, stream, p.table);
+}
+
+int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz,
+                                   int flags, void *d_workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
+  if (rc != EDT_OK) return rc;
+  if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
+  if (!d_records) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
+  if (!edt_hip_shard_records_supported(EDT_U8, sx, sy_local, sz)) {
+    set_error("slab records need sx, sz <= 1024 (use edt_hip_shard_z_device)");
+    return EDT_ERR_UNSUPPORTED;
+  }
+  RecordPlan p = make_record_plan(sx, sy_local, sz, d_workspace);
+  if (!d_workspace || workspace_bytes < p.bytes) {
+    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
+    return EDT_ERR_BAD_ARG;
+  }
+  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
+  const int64_t rec = record_floats(sx, sy_local), words = ceil_div(sy_local, kBandRows);
+  const uint32_t *nz_y = reinterpret_cast<const uint32_t *>(d_records + sy_local * sx);
+  {
+    ScopedPass t("z_bits", stream);
+    rc = launch_bits_transpose_yz(nz_y, nz_y + words * sx, p.nz_z, p.rs_z, sx, sy_local, sz, stream, rec);
+    if (rc != EDT_OK) return rc;
+  }
+  AxisGeom gz;  // z-columns of the record buffer: consecutive z are one record apart
+  gz.sx = sx; gz.n = sz; gz.stride = rec; gz.nouter = sy_local; gz.outer_stride = sx;
+  gz.nbands = ceil_div(sz, kBandRows);
+  ScopedPass t("z_pass", stream);
+  return launch_column_pass_wave(d_records, p.nz_z, p.rs_z, gz, wz, bb, epi, stream);
 }
 
 int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, int64_t count,

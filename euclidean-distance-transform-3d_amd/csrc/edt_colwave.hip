@@ -81,11 +81,11 @@ struct XFuse {
   int flim;      // bit pattern of FLT_MAX (tofinite) or +inf
 };
 
-template <int CW, bool BB, bool XF>
+template <int CW, bool BB, bool XF, bool SC>
 __global__ void __launch_bounds__(2048 / CW, 4)
 k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
                    const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x,
-                   int epi, int dbg, int aligned16, XFuse xf) {
+                   int epi, int dbg, int aligned16, XFuse xf, const BandScatter *__restrict__ scatter) {
   using namespace edt_lane;
   constexpr int NBP = 64 / CW;  // bands per column handled by a wave (power of two)
   constexpr int W = 32 / CW;    // waves per workgroup
@@ -226,8 +226,30 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     for (int r = 0; r < 32; ++r) own[r * 32] = f[r];
   }
   __syncthreads();
-  if (IO::kGran == 4 && aligned16) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  if constexpr (SC) {
+    // Z-sharded path: the rows leave for the slab records of their destination (one look-up per
+    // band; a band never straddles two destinations).  Same granules as the in-place stores.
+    if (IO::kGran == 4 && aligned16) {
+      for (int i = wave; i < NBP * 4; i += W) {
+        const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+        if (row < n && gc < cols_left) {
+          const int b = row >> 5;
+          float *dst = scatter->rows[b] + o * scatter->ostride[b] + (int64_t)(row & 31) * st + x0 + gc;
+          *reinterpret_cast<v4f *>(dst) = *reinterpret_cast<const v4f *>(tile + io_lds_word<4>(i, lane));
+        }
+      }
+    } else {
+      for (int i = wave; i < NBP * 16; i += W) {
+        const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+        if (row < n && gc < cols_left) {
+          const int b = row >> 5;
+          scatter->rows[b][o * scatter->ostride[b] + (int64_t)(row & 31) * st + x0 + gc] =
+              tile[io_lds_word<1>(i, lane)];
+        }
+      }
+    }
+  } else if (IO::kGran == 4 && aligned16) {
     for (int i = wave; i < NBP * 4; i += W) {
       const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
       if (row < n && gc < cols_left) {
@@ -251,15 +273,16 @@ bool column_pass_wave_supported(const AxisGeom &g) {
   return g.nbands >= 1 && g.nbands <= 32;
 }
 
-template <int CW, bool BB, bool XF>
-static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
-                           int epi, const XFuse &xf, hipStream_t stream) {
+template <int CW, bool BB, bool XF, bool SC>
+static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
+                           int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
+                           bool scatter_aligned) {
   constexpr int NBP = 64 / CW;
   size_t lds = (size_t)NBP * 32 * 32 * sizeof(float) + 2 * (size_t)NBP * 32 * sizeof(uint32_t);
   if (XF) lds += (size_t)33 * NBP * sizeof(edt_lane::XRowMeta) + (size_t)(xf.idx_inf + 1) * sizeof(float);
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
-    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF>),
+    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF, SC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -268,41 +291,56 @@ static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, con
   if (tiles <= 0) return EDT_OK;
   // 16-byte granules need 16-byte aligned rows; otherwise the tile moves float by float
   const int aligned16 = (g.sx % 4) == 0 && (g.stride % 4) == 0 && (g.outer_stride % 4) == 0 &&
-                        (reinterpret_cast<uintptr_t>(F) % 16) == 0;
+                        (reinterpret_cast<uintptr_t>(F) % 16) == 0 && (scatter == nullptr || scatter_aligned);
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF>), dim3((unsigned)tiles), dim3(2048 / CW), lds, stream,
-                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), aligned16, xf);
+  hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF, SC>), dim3((unsigned)tiles), dim3(2048 / CW), lds, stream,
+                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), aligned16, xf, scatter);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }
 
+template <int CW, bool BB, bool XF>
+static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
+                           int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
+                           bool scatter_aligned) {
+  // the scattering epilogue (Z-sharded path) is a compile-time variant of the unfused kernel
+  if constexpr (!XF) {
+    if (scatter != nullptr)
+      return launch_wave_cbx_sc<CW, BB, false, true>(F, nz, rs, g, w, epi, xf, stream, scatter, scatter_aligned);
+  }
+  return launch_wave_cbx_sc<CW, BB, XF, false>(F, nz, rs, g, w, epi, xf, stream, nullptr, false);
+}
+
 template <int CW>
 static int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
-                         int bb, int epi, const XFuse *xf, hipStream_t stream) {
+                         int bb, int epi, const XFuse *xf, hipStream_t stream, const BandScatter *scatter,
+                         bool sc_al) {
   // the border rule and the fused pass 1 are compile-time variants, the epilogue a run-time one
   const XFuse none = {nullptr, nullptr, 0, 0, 0};
   if (xf)
-    return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream)
-              : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream);
-  return bb ? launch_wave_cbx<CW, true, false>(F, nz, rs, g, w, epi, none, stream)
-            : launch_wave_cbx<CW, false, false>(F, nz, rs, g, w, epi, none, stream);
+    return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al)
+              : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al);
+  return bb ? launch_wave_cbx<CW, true, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al)
+            : launch_wave_cbx<CW, false, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al);
 }
 
 static int launch_wave_any(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
-                           int bb, int epi, const XFuse *xf, hipStream_t stream) {
+                           int bb, int epi, const XFuse *xf, hipStream_t stream,
+                           const BandScatter *sc = nullptr, bool sc_al = false) {
   const int64_t NB = g.nbands;
-  if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, xf, stream);
-  if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream);
-  if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream);
-  if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream);
-  if (NB <= 32 && xf == nullptr) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, nullptr, stream);
+  if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
+  if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
+  if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
+  if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
+  if (NB <= 32 && xf == nullptr) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, nullptr, stream, sc, sc_al);
   set_error("axis too long for the wave column pass");
   return EDT_ERR_UNSUPPORTED;
 }
 
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                            float w, int bb, int epi, hipStream_t stream) {
-  return launch_wave_any(F, nz, rs, g, w, bb, epi, nullptr, stream);
+                            float w, int bb, int epi, hipStream_t stream, const BandScatter *scatter) {
+  // (the caller of the scattering variant guarantees 16-byte aligned destinations when sx % 4 == 0)
+  return launch_wave_any(F, nz, rs, g, w, bb, epi, nullptr, stream, scatter, scatter != nullptr);
 }
 
 // First column pass with pass 1 fused in: F is only written.  `meta` = row records of k_row_bits,

@@ -58,6 +58,17 @@ struct AxisGeom {
   int64_t nbands;        // ceil(n / 32): bit-words per column
 };
 
+// Destination map of a column pass that scatters its rows into per-destination "slab records"
+// (the Z-sharded path, edt_hip.h: edt_hip_shard_xy_records_device): one entry per 32-row band of
+// the scan axis.  Every band lies inside one destination block, so a lane (= one band of one
+// column) needs a single look-up.
+struct BandScatter {
+  float *rows[32];      // where row 32*band of outer index 0, column 0 goes
+  uint32_t *bits[32];   // where the nz word of that band, outer index 0, column 0 goes
+  int64_t ostride[32];  // 4-byte elements between consecutive outer indices in that destination
+  int64_t plane[32];    // words between the nz and the zs plane of one outer index
+};
+
 // epilogue of the last pass (fused tofinite/toinfinite/sqrt: src/edt.hpp:39-53, :599-601)
 enum : int { kEpiToInf = 1, kEpiSqrt = 2 };
 

@@ -57,6 +57,11 @@ int launch_zflags(int dtype, const void *labels, const void *halo, uint8_t *flag
                   int64_t szl, hipStream_t stream);
 int launch_bits_from_flags(const uint8_t *flags, uint32_t *nz, uint32_t *rs, const AxisGeom &g,
                            hipStream_t stream);
+// y-packed planes [z][band][x] of a slab -> the bit part of the slab records; also publishes the
+// destination map in device memory for the scattering column pass
+int launch_pack_record_bits(const uint32_t *nz_y, const uint32_t *zs_y, const BandScatter &sc,
+                            BandScatter *d_table, int64_t sx, int64_t nby, int64_t szl,
+                            hipStream_t stream);
 // ---- LDS-tiled column pass: edt_tiled.hip ---------------------------------------------------
 bool column_pass_tiled_supported(const AxisGeom &g);
 int launch_column_pass_tiled(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
@@ -66,15 +71,19 @@ bool row_pass_tiled_supported(int64_t sx);
 int launch_row_pass_tiled(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                           uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
                           int to_finite, hipStream_t stream);
+// in_zstride: words between consecutive z of the y-packed planes (0 = dense, nby * sx)
 int launch_bits_transpose_yz(const uint32_t *nz_y, const uint32_t *zs_y, uint32_t *nz_z,
-                             uint32_t *rs_z, int64_t sx, int64_t sy, int64_t sz, hipStream_t stream);
+                             uint32_t *rs_z, int64_t sx, int64_t sy, int64_t sz, hipStream_t stream,
+                             int64_t in_zstride = 0);
 }  // namespace edt_amd
 
 namespace edt_amd {
 // ---- wave-autonomous LDS-tiled column pass: edt_colwave.hip -----------------------------------
 bool column_pass_wave_supported(const AxisGeom &g);
+// scatter != nullptr (device table): the rows are written to the slab records instead of F
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                            float w, int bb, int epi, hipStream_t stream);
+                            float w, int bb, int epi, hipStream_t stream,
+                            const BandScatter *scatter = nullptr);
 // the same with pass 1 fused in (F is write-only): needs the row records + T of edt_rowwave.hip
 int launch_column_pass_wave_xfused(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                                    float w, int bb, int epi, const void *meta, const float *ttab,
@@ -84,9 +93,10 @@ int launch_column_pass_wave_xfused(float *F, const uint32_t *nz, const uint32_t 
 namespace edt_amd {
 // ---- register-resident pass 1 (rows up to 512 voxels): edt_rowwave.hip -------------------------
 bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz);
+// halo: the xy-slice below slice 0 (Z-sharded slabs), or nullptr = slice 0 starts every z-run
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                         int to_finite, hipStream_t stream);
+                         int to_finite, hipStream_t stream, const void *halo = nullptr);
 // bit planes + per-row run records only (pass 1 is then rebuilt inside the first column pass);
 // `ttab` receives T[0..sx+2].  Scratch sizes: row_records_bytes / (sx+3)*4.
 size_t row_records_bytes(int64_t sx, int64_t sy, int64_t sz);

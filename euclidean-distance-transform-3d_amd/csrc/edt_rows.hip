@@ -262,7 +262,8 @@ __device__ __forceinline__ void transpose32(uint32_t (&a)[32]) {
 __global__ void k_bits_transpose_yz(const uint32_t *__restrict__ nz_y,
                                     const uint32_t *__restrict__ zs_y,
                                     uint32_t *__restrict__ nz_z, uint32_t *__restrict__ rs_z,
-                                    int64_t sx, int64_t sy, int64_t sz, int64_t nby, int64_t nbz) {
+                                    int64_t sx, int64_t sy, int64_t sz, int64_t nby, int64_t nbz,
+                                    int64_t in_zstride) {
   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t total = sx * nby * nbz;
   if (idx >= total) return;
@@ -275,7 +276,7 @@ __global__ void k_bits_transpose_yz(const uint32_t *__restrict__ nz_y,
     const int64_t z = zb * 32 + t;
     a[t] = 0; b[t] = 0;
     if (z < sz) {
-      const int64_t w = (z * nby + yb) * sx + x;
+      const int64_t w = z * in_zstride + yb * sx + x;
       a[t] = nz_y[w];
       b[t] = zs_y[w];
     }
@@ -296,13 +297,14 @@ __global__ void k_bits_transpose_yz(const uint32_t *__restrict__ nz_y,
 
 int launch_bits_transpose_yz(const uint32_t *nz_y, const uint32_t *zs_y, uint32_t *nz_z,
                              uint32_t *rs_z, int64_t sx, int64_t sy, int64_t sz,
-                             hipStream_t stream) {
+                             hipStream_t stream, int64_t in_zstride) {
   const int64_t nby = ceil_div(sy, kBandRows), nbz = ceil_div(sz, kBandRows);
   const int64_t total = sx * nby * nbz;
   if (total <= 0) return EDT_OK;
   const int threads = 256;
   hipLaunchKernelGGL(k_bits_transpose_yz, dim3((unsigned)ceil_div(total, threads)), dim3(threads), 0,
-                     stream, nz_y, zs_y, nz_z, rs_z, sx, sy, sz, nby, nbz);
+                     stream, nz_y, zs_y, nz_z, rs_z, sx, sy, sz, nby, nbz,
+                     in_zstride > 0 ? in_zstride : nby * sx);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }

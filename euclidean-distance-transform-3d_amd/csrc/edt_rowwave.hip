@@ -78,7 +78,7 @@ template <typename T, int NC, bool HAS_Z, bool FULL>
 __global__ void __launch_bounds__(kRowWaves * 64)
 k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t *__restrict__ nz_y,
                 uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, float w,
-                int bb, int to_finite, int nby, int ngroups, int xcd_sched) {
+                int bb, int to_finite, int nby, int ngroups, int xcd_sched, const T *__restrict__ halo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *Ttab = reinterpret_cast<float *>(smem);  // [sx + 3]: T[0..sx+1], then +inf
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -124,7 +124,9 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
     const T *base = labels + ((int64_t)z * sy + y0) * sx;  // row y0 of this slice
     float *obase = out + ((int64_t)z * sy + y0) * sx;
     const rsrc_t rs_lab = make_rsrc(base);
-    const rsrc_t rs_bel = make_rsrc((HAS_Z && z > 0) ? base - sxy : base);
+    // the slice below: inside the volume, or -- for slice 0 of a Z-sharded slab -- the halo slice
+    const rsrc_t rs_bel = make_rsrc((HAS_Z && z > 0) ? base - sxy
+                                    : (HAS_Z && halo != nullptr) ? halo + (int64_t)y0 * sx : base);
     const rsrc_t rs_out = make_rsrc(obase);
 
     uint32_t xs[NC], xl[NC];  // per-lane BYTE offsets inside a row
@@ -260,7 +262,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
       if (FULL || x < sx) {
         // row 0 of the volume starts a run along y, slice 0 starts every run along z
         const uint32_t ys = (__brev(ysw[c]) >> sh) | (y0 == 0 ? 1u : 0u);
-        const uint32_t zs = z == 0 ? (0xFFFFFFFFu >> sh) : (__brev(zsw[c]) >> sh);
+        const uint32_t zs = (z == 0 && halo == nullptr) ? (0xFFFFFFFFu >> sh) : (__brev(zsw[c]) >> sh);
         nz_y[wbase + x] = __brev(nzw[c]) >> sh;
         ys_y[wbase + x] = ys;
         if (HAS_Z) zs_y[wbase + x] = zs;
@@ -491,7 +493,7 @@ bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
 template <typename T, int NC>
 static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                               uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                              int to_finite, hipStream_t stream) {
+                              int to_finite, hipStream_t stream, const void *halo) {
   const int64_t nby = ceil_div(sy, kBandRows);
   const int64_t ngroups = nby * sz;
   if (ngroups <= 0) return EDT_OK;
@@ -503,7 +505,7 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
 #define LAUNCH(Z, F)                                                                                      \
   hipLaunchKernelGGL((k_row_pass_wave<T, NC, Z, F>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds, stream,  \
                      (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb, to_finite, \
-                     (int)nby, (int)ngroups, xcd_sched)
+                     (int)nby, (int)ngroups, xcd_sched, (const T *)halo)
   const bool full = sx == 64 * NC;
   if (zs_y != nullptr) { if (full) LAUNCH(true, true); else LAUNCH(true, false); }
   else { if (full) LAUNCH(false, true); else LAUNCH(false, false); }
@@ -515,9 +517,9 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
 template <typename T>
 static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                              uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                             int to_finite, hipStream_t stream) {
+                             int to_finite, hipStream_t stream, const void *halo) {
   const int64_t nc = ceil_div(sx, 64);
-#define GO(N) return launch_row_wave_tn<T, N>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream)
+#define GO(N) return launch_row_wave_tn<T, N>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo)
   if (nc <= 1) GO(1);
   if (nc <= 2) GO(2);
   if (nc <= 4) GO(4);
@@ -528,9 +530,9 @@ static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uin
 
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                         int to_finite, hipStream_t stream) {
+                         int to_finite, hipStream_t stream, const void *halo) {
 #define ROW_WAVE(T) \
-  return launch_row_wave_t<T>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream)
+  return launch_row_wave_t<T>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo)
   switch (dtype) {
     case EDT_U8: case EDT_BOOL: ROW_WAVE(uint8_t);
     case EDT_U16: ROW_WAVE(uint16_t);

@@ -87,4 +87,49 @@ int launch_bits_from_flags(const uint8_t *flags, uint32_t *nz, uint32_t *rs, con
   return EDT_OK;
 }
 
+// ---- slab records (the fast Z-sharded path) -------------------------------------------------
+// A destination rank h owns the rows [ys_h, ye_h) of every column along y (ys_h a multiple of 32).
+// What it needs from one xy-slice is ONE contiguous record:
+//     [ (ye_h - ys_h) * sx floats : the slice after the X and Y passes                      ]
+//     [ words_h * sx uint32       : foreground bits, 32 rows of y per word (nz plane)       ]
+//     [ words_h * sx uint32       : "starts a run along z" bits, same packing (zs plane)    ]
+// so a slab of szl slices is szl records per destination, and the exchange is one contiguous
+// message per peer that lands where the receiver's Z pass reads it.  The fp32 part is written by
+// the Y pass itself (k_column_pass_wave with a BandScatter table); this kernel moves the two bit
+// planes of pass 1 into place (2 bits per voxel) and publishes the table.
+__global__ void k_pack_record_bits(const uint32_t *__restrict__ nz_y, const uint32_t *__restrict__ zs_y,
+                                   BandScatter sc, BandScatter *__restrict__ d_table, int64_t sx,
+                                   int64_t nby, int64_t szl) {
+  if (blockIdx.x == 0 && threadIdx.x < 32) {
+    const int b = (int)threadIdx.x;
+    d_table->rows[b] = sc.rows[b];
+    d_table->bits[b] = sc.bits[b];
+    d_table->ostride[b] = sc.ostride[b];
+    d_table->plane[b] = sc.plane[b];
+  }
+  const int64_t total = sx * nby * szl;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += step) {
+    const int64_t x = i % sx;
+    const int64_t b = (i / sx) % nby;
+    const int64_t z = i / (sx * nby);
+    uint32_t *dst = sc.bits[b] + z * sc.ostride[b] + x;
+    dst[0] = nz_y[i];
+    dst[sc.plane[b]] = zs_y[i];
+  }
+}
+
+int launch_pack_record_bits(const uint32_t *nz_y, const uint32_t *zs_y, const BandScatter &sc,
+                            BandScatter *d_table, int64_t sx, int64_t nby, int64_t szl,
+                            hipStream_t stream) {
+  const int threads = 256;
+  int64_t blocks = ceil_div(sx * nby * szl, threads);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_pack_record_bits, dim3((unsigned)blocks), dim3(threads), 0, stream, nz_y, zs_y, sc,
+                     d_table, sx, nby, szl);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
 }  // namespace edt_amd

@@ -19,6 +19,18 @@ from the previous rank.
 The numerical work is done by `ops` (default: the HIP kernels through the C ABI); the
 partition / exchange logic here is backend agnostic, which is how the CPU test-suite drives
 it over gloo with a CPU implementation of the two phases.
+
+Fast form ("slab records", include/edt_hip.h): when the extents allow it (all <= 1024, at least
+one 32-row word of y per rank) the y axis is cut at multiples of 32 rows and the XY phase writes,
+for every destination rank, one contiguous record per xy-slice -- that rank's rows after the
+X and Y passes followed by their foreground / z-run-start BITS (4.25 bytes per voxel).  A
+peer's message is then contiguous on both sides (no pack or unpack copies; the rank's own part is
+written straight into its receive buffer), and the slab is processed in z-chunks so that the
+exchange of chunk k runs (on RCCL's stream) under the kernels of chunk k+1:
+
+    for chunk k:   XY kernels(chunk k) -> records            (compute stream)
+                   isend/irecv group(chunk k), not waited    (communication stream)
+    wait all;      Z pass over the gathered records          (compute stream)
 """
 from __future__ import annotations
 
@@ -73,6 +85,33 @@ class HipOps:
             self._stream()))
         return partial, zflags
 
+    # -- slab records (fast form) -------------------------------------------------------------
+    def records_supported(self, code, sx, sy, sz):
+        return bool(self.lib.edt_hip_shard_records_supported(code, sx, sy, sz))
+
+    def record_floats(self, sx, ylen):
+        return int(self.lib.edt_hip_shard_record_floats(sx, ylen))
+
+    def xy_records(self, labels, halo, code, weights, flags, y_splits, blocks):
+        """X and Y passes of a z-chunk; block h receives chunk-many records of destination h."""
+        szl, sy, sx = labels.shape
+        ws = self._workspace(self.lib.edt_hip_shard_records_workspace_bytes(code, sx, sy, szl), labels.device)
+        splits = (ctypes.c_int64 * len(y_splits))(*y_splits)
+        ptrs = (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
+        _lib.check(self.lib.edt_hip_shard_xy_records_device(
+            ctypes.c_void_p(labels.data_ptr()),
+            ctypes.c_void_p(halo.data_ptr()) if halo is not None else None, code, sx, sy, szl,
+            weights[0], weights[1], flags, len(blocks), splits, ptrs, ctypes.c_void_p(ws.data_ptr()),
+            ws.numel(), self._stream()))
+
+    def z_records(self, records, sx, syl, wz, flags):
+        """Z pass in place over the gathered (sz, record_floats) buffer."""
+        sz = records.shape[0]
+        ws = self._workspace(self.lib.edt_hip_shard_records_workspace_bytes(_lib.U8, sx, syl, sz), records.device)
+        _lib.check(self.lib.edt_hip_shard_z_records_device(
+            ctypes.c_void_p(records.data_ptr()), sx, syl, sz, wz, flags, ctypes.c_void_p(ws.data_ptr()),
+            ws.numel(), self._stream()))
+
     def z(self, partial, zflags, wz, flags):
         sz, syl, sx = partial.shape
         ws = self._workspace(self.lib.edt_hip_shard_workspace_bytes(_lib.U8, sx, syl, sz), partial.device)
@@ -90,7 +129,9 @@ class ShardedEDT:
     with ``gather_back=True`` -- its original Z-slab of the result.
     """
 
-    def __init__(self, extents_xyz, code: int, group=None, ops=None):
+    def __init__(self, extents_xyz, code: int, group=None, ops=None, records=None, chunks=None):
+        """records: None = use the slab-record form whenever it applies, False = never (the
+        byte-flag form).  chunks: z-chunks per slab in the record form (default 4 when world > 1)."""
         self.sx, self.sy, self.sz = (int(e) for e in extents_xyz)
         self.code = code
         self.group = group
@@ -99,8 +140,21 @@ class ShardedEDT:
         if self.sz < self.world or self.sy < self.world:
             raise ValueError("need at least one z-slice and one y-row per rank")
         self.zparts = balanced_partition(self.sz, self.world)
-        self.yparts = balanced_partition(self.sy, self.world)
         self.ops = HipOps() if ops is None else ops
+        words = -(-self.sy // 32)
+        can = (records is not False and hasattr(self.ops, "xy_records") and words >= self.world
+               and self.ops.records_supported(code, self.sx, self.sy, self.sz))
+        if records is True and not can:
+            raise ValueError("the slab-record form does not apply to these extents")
+        self.records = bool(can)
+        if self.records:
+            # y is cut at multiples of 32 rows: a bit word never straddles two ranks
+            self.yparts = [(32 * a, min(32 * b, self.sy)) for a, b in balanced_partition(words, self.world)]
+            want = chunks if chunks is not None else (4 if self.world > 1 else 1)
+            self.nchunks = max(1, min(int(want), min(e - s for s, e in self.zparts)))
+            self._send = {}
+        else:
+            self.yparts = balanced_partition(self.sy, self.world)
 
     # -- helpers ----------------------------------------------------------------------------
     def local_z(self):
@@ -174,14 +228,66 @@ class ShardedEDT:
                 dst[:, hys:hye, :].copy_(stage)
         return outs
 
+    def _chunk(self, r, k):
+        """z-range (global indices) of chunk k of rank r's slab; the same rule on every rank."""
+        zs, ze = self.zparts[r]
+        c0, c1 = balanced_partition(ze - zs, self.nchunks)[k]
+        return zs + c0, zs + c1
+
+    def _run_records(self, labels, w, flags, sqrt, halo):
+        """Slab-record form: chunked XY phase with the exchange of chunk k under chunk k+1."""
+        zs, ze = self.local_z()
+        ys, ye = self.local_y()
+        rec = [self.ops.record_floats(self.sx, b - a) for a, b in self.yparts]
+        y_splits = [a for a, _ in self.yparts] + [self.sy]
+        dst = torch.empty((self.sz, rec[self.rank]), dtype=torch.float32, device=labels.device)
+        pending = []
+        for k in range(self.nchunks):
+            c0, c1 = self._chunk(self.rank, k)
+            blocks = []
+            for h in range(self.world):
+                if h == self.rank:
+                    blocks.append(dst[c0:c1])  # own part: straight into the receive buffer
+                    continue
+                key = (k, h)
+                buf = self._send.get(key)
+                if buf is None or buf.shape != (c1 - c0, rec[h]) or buf.device != labels.device:
+                    buf = self._send[key] = torch.empty((c1 - c0, rec[h]), dtype=torch.float32,
+                                                        device=labels.device)
+                blocks.append(buf)
+            self.ops.xy_records(labels[c0 - zs:c1 - zs], halo, self.code, w, flags, y_splits, blocks)
+            halo = labels[c1 - zs - 1]  # the next chunk continues this slab
+            p2p = []
+            for h in range(self.world):
+                if h == self.rank:
+                    continue
+                p2p.append(dist.P2POp(dist.isend, blocks[h], self._global_rank(h), self.group))
+                g0, g1 = self._chunk(h, k)
+                p2p.append(dist.P2POp(dist.irecv, dst[g0:g1], self._global_rank(h), self.group))
+            if p2p:
+                pending.extend(dist.batch_isend_irecv(p2p))
+        for req in pending:
+            req.wait()
+        self.ops.z_records(dst, self.sx, ye - ys, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0))
+        # the result is the float part of every record: a (sz, syl, sx) view with z-stride = record
+        return dst[:, :(ye - ys) * self.sx].view(self.sz, ye - ys, self.sx)
+
     # -- the pipeline -----------------------------------------------------------------------
     def run(self, labels, weights_xyz, black_border=False, sqrt=False, gather_back=False):
+        """Returns this rank's Y-slab of the result (all z, its rows) -- in the slab-record form a
+        VIEW with a z-stride of one record, not a contiguous tensor -- or, with gather_back, its
+        original Z-slab."""
         zs, ze = self.local_z()
         if tuple(labels.shape) != (ze - zs, self.sy, self.sx) or not labels.is_contiguous():
             raise ValueError(f"rank {self.rank}: expected a contiguous ({ze - zs}, {self.sy}, {self.sx}) slab")
         w = tuple(float(np.float32(v)) for v in weights_xyz)
         flags = (_lib.FLAG_BLACK_BORDER if black_border else 0)
         halo = self._halo(labels)
+        if self.records:
+            out = self._run_records(labels, w, flags, sqrt, halo)
+            if gather_back:
+                out = self._reshard([out], to_y=False)[0]
+            return out
         partial, zflags = self.ops.xy(labels, halo, self.code, w, flags)
         partial_y, zflags_y = self._reshard([partial, zflags], to_y=True)
         out = self.ops.z(partial_y, zflags_y, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0))

@@ -149,6 +149,32 @@ int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx
                            int64_t sy_local, int64_t sz, float wz, int flags,
                            void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Slab records: the fast form of the same two phases (sx, sy, sz <= 1024; query with
+ * edt_hip_shard_records_supported, otherwise use the pair above).  The y axis is cut into `nparts`
+ * destination ranges at multiples of 32 rows (y_splits[0] = 0 ... y_splits[nparts] = sy, HOST array).
+ * For destination h and every xy-slice of the slab the XY phase writes ONE contiguous record of
+ * edt_hip_shard_record_floats(sx, ylen_h) 4-byte elements straight into d_blocks[h] (device pointer
+ * to sz_local consecutive records; HOST array of nparts pointers):
+ *     ylen_h * sx floats   the slice after the X and Y passes, rows of that destination only
+ *     words_h * sx uint32  foreground bits, 32 rows of y per word      (words_h = ceil(ylen_h / 32))
+ *     words_h * sx uint32  "label differs from the voxel below in z" bits, same packing
+ * i.e. 4.25 bytes per voxel travel instead of the labels, each peer's message is contiguous on
+ * both sides (no pack / unpack copies), and a rank may hand in its OWN part of the receive buffer
+ * as d_blocks[rank].  A slab can be processed in z-chunks (d_halo of a later chunk = the last
+ * slice of the previous one) so that the exchange of one chunk overlaps the kernels of the next.
+ * The Z phase takes the gathered buffer of sz records (all z, this rank's rows) and leaves the result
+ * in the float part of every record: row (z, y) starts at d_records + z * record_floats + y * sx. */
+int edt_hip_shard_records_supported(int dtype, int64_t sx, int64_t sy, int64_t sz);
+size_t edt_hip_shard_record_floats(int64_t sx, int64_t y_rows);
+size_t edt_hip_shard_records_workspace_bytes(int dtype, int64_t sx, int64_t sy, int64_t sz);
+int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, int dtype, int64_t sx,
+                                    int64_t sy, int64_t sz_local, float wx, float wy, int flags,
+                                    int nparts, const int64_t *y_splits, void *const *d_blocks,
+                                    void *d_workspace, size_t workspace_bytes, void *stream);
+int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_local, int64_t sz,
+                                   float wz, int flags, void *d_workspace, size_t workspace_bytes,
+                                   void *stream);
+
 /* ---- fused helpers on device-resident data ------------------------------------------ */
 /* out[i] = a[i] - b[i]  (src/edt.pyx:156-158, sdf = edt(x) - edt(x == 0)) */
 int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, int64_t count,

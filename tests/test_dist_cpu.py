@@ -53,13 +53,49 @@ class OracleOps:
         return partial
 
 
+    # -- slab records (the fast form of the driver), restated with numpy on top of xy / z ------
+    def records_supported(self, code, sx, sy, sz):
+        return True
+
+    def record_floats(self, sx, ylen):
+        return ylen * sx + 2 * (-(-ylen // 32)) * sx
+
+    def xy_records(self, labels, halo, code, weights, flags, y_splits, blocks):
+        partial, zflags = self.xy(labels, halo, code, weights, flags)
+        p, f = partial.numpy(), zflags.numpy()
+        szl, sy, sx = p.shape
+        for h, blk in enumerate(blocks):
+            ys, ye = y_splits[h], y_splits[h + 1]
+            ylen, words = ye - ys, -(-(ye - ys) // 32)
+            assert ys % 32 == 0 and tuple(blk.shape) == (szl, self.record_floats(sx, ylen))
+            raw = blk.numpy().view(np.uint32)   # shares the tensor's memory
+            raw[:, :ylen * sx] = p[:, ys:ye, :].reshape(szl, -1).view(np.uint32)
+            bits = np.zeros((szl, 2, words, sx), np.uint32)
+            for r in range(ylen):
+                row = f[:, ys + r, :].astype(np.uint32)
+                bits[:, 0, r // 32, :] |= (row & 1) << (r % 32)
+                bits[:, 1, r // 32, :] |= ((row >> 1) & 1) << (r % 32)
+            raw[:, ylen * sx:] = bits.reshape(szl, -1)
+
+    def z_records(self, records, sx, syl, wz, flags):
+        raw = records.numpy().view(np.uint32)
+        sz, words = raw.shape[0], -(-syl // 32)
+        partial = raw[:, :syl * sx].view(np.float32).reshape(sz, syl, sx).copy()
+        bits = raw[:, syl * sx:].reshape(sz, 2, words, sx)
+        zflags = np.zeros((sz, syl, sx), np.uint8)
+        for r in range(syl):
+            zflags[:, r, :] = ((bits[:, 0, r // 32, :] >> (r % 32)) & 1) | (((bits[:, 1, r // 32, :] >> (r % 32)) & 1) << 1)
+        self.z(torch.from_numpy(partial), torch.from_numpy(zflags), wz, flags)
+        raw[:, :syl * sx] = partial.reshape(sz, -1).view(np.uint32)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q):
+def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q, records=None, chunks=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -71,7 +107,8 @@ def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q):
         vol = blocky_labels(shape, nlabels=5, zero_frac=0.15, block=5, rng=rng).astype(np.uint32)
         vol = np.asfortranarray(vol)                      # (sx, sy, sz), x fastest
         zyx = np.ascontiguousarray(vol.T)                  # (sz, sy, sx)
-        plan = edist.ShardedEDT(shape, 2, ops=OracleOps())
+        plan = edist.ShardedEDT(shape, 2, ops=OracleOps(), records=records, chunks=chunks)
+        assert records is None or plan.records == records
         zs, ze = plan.local_z()
         slab = torch.from_numpy(zyx[zs:ze].copy().view(np.int32))
         out = plan.run(slab, an, black_border=bb, sqrt=sqrt, gather_back=gather_back).numpy()
@@ -101,6 +138,29 @@ def test_z_sharded_equals_single_process(world, shape, an, bb, sqrt, gather_back
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, shape, an, bb, sqrt, gather_back, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, "worker crashed"
+    results = dict(q.get(timeout=5) for _ in range(world))
+    assert results == {r: True for r in range(world)}
+
+
+@pytest.mark.parametrize("world,shape,an,bb,sqrt,gather_back,chunks", [
+    (2, (12, 70, 9), (6.0, 6.0, 30.0), True, False, False, 4),     # 3 words of y: 64 + 6 rows
+    (2, (10, 64, 7), (1.0, 2.0, 3.0), False, True, True, 2),
+    (3, (8, 100, 10), (0.5, 0.7, 1.3), False, False, False, 3),    # 4 words: 64 / 32 / 4 rows
+    (3, (9, 97, 3), (4.0, 4.0, 40.0), True, False, True, 1),       # one slice per rank
+])
+def test_slab_record_form_equals_single_process(world, shape, an, bb, sqrt, gather_back, chunks):
+    """The fast form of the driver: y cut at multiples of 32 rows, per-destination records, the
+    slab processed in z-chunks whose exchanges are issued before the next chunk's kernels."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, an, bb, sqrt, gather_back, q, True, chunks))
              for r in range(world)]
     for p in procs:
         p.start()

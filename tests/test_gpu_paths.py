@@ -96,3 +96,64 @@ def test_shard_phases_as_virtual_ranks(edt_gpu, oracle_port, world, shape):
         if sqrt:
             want = np.sqrt(want)
         assert same(got, want), (world, shape, an, bb)
+
+
+_RECORD_CASES = {}
+
+
+def _record_case(shape, oracle_port):
+    """labels + oracle answers of one shape, computed once for all virtual world sizes"""
+    if shape not in _RECORD_CASES:
+        lab = voronoi_labels(shape, nseeds=40, seed=sum(shape), upsample=4, membrane=0.04)
+        runs = [((6.0, 6.0, 30.0), True, False), ((1.0, 1.5, 0.5), False, True)]
+        wants = []
+        for an, bb, sqrt in runs:
+            w = oracle_port.edtsq(lab, an, bb)
+            wants.append(np.sqrt(w) if sqrt else w)
+        _RECORD_CASES[shape] = (lab, runs, wants)
+    return _RECORD_CASES[shape]
+
+
+@pytest.mark.parametrize("world,chunks", [(1, 1), (2, 2), (3, 1), (8, 3)])
+@pytest.mark.parametrize("shape", [(96, 280, 24), (512, 96, 20), (1024, 64, 6), (36, 1000, 9), (41, 200, 12)])
+def test_shard_records_as_virtual_ranks(edt_gpu, oracle_port, world, chunks, shape):
+    """The slab-record form of the two phases (edt_hip_shard_xy_records_device /
+    edt_hip_shard_z_records_device): every virtual rank writes its per-destination records chunk by
+    chunk (its own part straight into the receive buffer), the "exchange" is a copy of the other
+    blocks, and each destination runs the Z pass over the gathered records."""
+    import torch
+    from edt import _lib
+    from edt.distributed import HipOps, balanced_partition
+
+    sx, sy, sz = shape
+    words = -(-sy // 32)
+    if sz < world or words < world:
+        pytest.skip("fewer slices / y-words than ranks")
+    dev = torch.device("cuda", 0)
+    ops = HipOps()
+    assert ops.records_supported(_lib.U32, sx, sy, sz)
+    lab, runs, wants = _record_case(shape, oracle_port)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev)  # (sz, sy, sx), x fastest
+    zparts = balanced_partition(sz, world)
+    yparts = [(32 * a, min(32 * b, sy)) for a, b in balanced_partition(words, world)]
+    y_splits = [a for a, _ in yparts] + [sy]
+    rec = [ops.record_floats(sx, b - a) for a, b in yparts]
+    for (an, bb, sqrt), want in zip(runs, wants):
+        flags = _lib.FLAG_BLACK_BORDER if bb else 0
+        dst = [torch.full((sz, rec[h]), float("nan"), dtype=torch.float32, device=dev) for h in range(world)]
+        for r, (zs, ze) in enumerate(zparts):
+            halo = t[zs - 1] if r > 0 else None  # the previous rank's last slice
+            for c0, c1 in balanced_partition(ze - zs, min(chunks, ze - zs)):
+                blocks = [dst[h][zs + c0:zs + c1] if h == r else
+                          torch.empty((c1 - c0, rec[h]), dtype=torch.float32, device=dev) for h in range(world)]
+                ops.xy_records(t[zs + c0:zs + c1], halo, _lib.U32, an, flags, y_splits, blocks)
+                for h in range(world):
+                    if h != r:
+                        dst[h][zs + c0:zs + c1].copy_(blocks[h])  # the exchange
+                halo = t[zs + c1 - 1]
+        outs = []
+        for h, (ys, ye) in enumerate(yparts):
+            ops.z_records(dst[h], sx, ye - ys, an[2], flags | (_lib.FLAG_SQRT if sqrt else 0))
+            outs.append(dst[h][:, :(ye - ys) * sx].reshape(sz, ye - ys, sx))
+        got = torch.cat(outs, 1).cpu().numpy().T
+        assert same(got, want), (world, shape, an, bb)

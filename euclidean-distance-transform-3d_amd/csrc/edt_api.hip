@@ -566,6 +566,7 @@ int edt_hip_set_debug_mode(int mode) {
 int edt_hip_set_profiling(int enabled) {
   std::lock_guard<std::mutex> lock(g_log_mutex);
   g_log.enabled = enabled != 0;
+  log_begin_call();  // the shard phases append to the log (several calls make one step): start clean
   return EDT_OK;
 }
 
@@ -710,6 +711,7 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
     }
     if (!d_blocks[h]) { set_error("null destination block"); return EDT_ERR_BAD_ARG; }
   }
+  if (g_log.enabled && g_log.used > 2048) log_begin_call();  // nobody is reading the log
   RecordPlan p = make_record_plan(sx, sy, sz_local, d_workspace);
   if (!d_workspace || workspace_bytes < p.bytes) {
     set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");

@@ -131,9 +131,10 @@ def sdf(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tens
 def pass_times():
     """Durations (ms) of the kernels of the last profiled call, as ``[(name, ms), ...]``."""
     lib = _lib.load()
-    buf = (ctypes.c_float * 16)()
-    n = lib.edt_hip_get_pass_times(ctypes.cast(buf, ctypes.c_void_p), 16)
-    return [(lib.edt_hip_get_pass_name(i).decode(), float(buf[i])) for i in range(min(n, 16))]
+    cap = 256  # (the sharded phases log several calls per step)
+    buf = (ctypes.c_float * cap)()
+    n = lib.edt_hip_get_pass_times(ctypes.cast(buf, ctypes.c_void_p), cap)
+    return [(lib.edt_hip_get_pass_name(i).decode(), float(buf[i])) for i in range(min(n, cap))]
 
 
 def set_profiling(enabled: bool) -> None:

@@ -150,9 +150,18 @@ class ShardedEDT:
         if self.records:
             # y is cut at multiples of 32 rows: a bit word never straddles two ranks
             self.yparts = [(32 * a, min(32 * b, self.sy)) for a, b in balanced_partition(words, self.world)]
+            import os
+            if chunks is None and os.environ.get("EDT_SHARD_CHUNKS"):
+                chunks = int(os.environ["EDT_SHARD_CHUNKS"])
             want = chunks if chunks is not None else (4 if self.world > 1 else 1)
             self.nchunks = max(1, min(int(want), min(e - s for s, e in self.zparts)))
             self._send = {}
+            # how a chunk travels: "alltoall" = one dist.all_to_all per chunk (RCCL), "p2p" = a batch
+            # of isend / irecv (any backend; gloo has no list all_to_all).  EDT_SHARD_EXCHANGE overrides.
+            default = "alltoall" if dist.get_backend(group) == "nccl" else "p2p"
+            self._exchange = os.environ.get("EDT_SHARD_EXCHANGE", default)
+            if self._exchange not in ("alltoall", "p2p"):
+                raise ValueError("EDT_SHARD_EXCHANGE must be 'alltoall' or 'p2p'")
         else:
             self.yparts = balanced_partition(self.sy, self.world)
 
@@ -257,15 +266,23 @@ class ShardedEDT:
                 blocks.append(buf)
             self.ops.xy_records(labels[c0 - zs:c1 - zs], halo, self.code, w, flags, y_splits, blocks)
             halo = labels[c1 - zs - 1]  # the next chunk continues this slab
-            p2p = []
-            for h in range(self.world):
-                if h == self.rank:
-                    continue
-                p2p.append(dist.P2POp(dist.isend, blocks[h], self._global_rank(h), self.group))
-                g0, g1 = self._chunk(h, k)
-                p2p.append(dist.P2POp(dist.irecv, dst[g0:g1], self._global_rank(h), self.group))
-            if p2p:
-                pending.extend(dist.batch_isend_irecv(p2p))
+            recv = [dst[slice(*self._chunk(h, k))] for h in range(self.world)]
+            if self._exchange == "alltoall":  # (also at world 1: a no-op that keeps the dry run honest)
+                # one collective call per chunk (RCCL runs it as a group of sends / receives; every
+                # peer pair has its own xGMI link); the own part is already in place -> empty entries
+                empty = dst[0:0]
+                ins = [empty if h == self.rank else blocks[h] for h in range(self.world)]
+                outs = [empty if h == self.rank else recv[h] for h in range(self.world)]
+                pending.append(dist.all_to_all(outs, ins, group=self.group, async_op=True))
+            else:
+                p2p = []
+                for h in range(self.world):
+                    if h == self.rank:
+                        continue
+                    p2p.append(dist.P2POp(dist.isend, blocks[h], self._global_rank(h), self.group))
+                    p2p.append(dist.P2POp(dist.irecv, recv[h], self._global_rank(h), self.group))
+                if p2p:
+                    pending.extend(dist.batch_isend_irecv(p2p))
         for req in pending:
             req.wait()
         self.ops.z_records(dst, self.sx, ye - ys, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0))
@@ -336,6 +353,19 @@ def bench_main(args, rank, world, dev):
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
+    # per-kernel durations of one more step (hipEvents inside the library, this rank's stream)
+    from . import device
+    acc = {}
+    for _ in range(3):
+        device.set_profiling(True)
+        step()
+        torch.cuda.synchronize()
+        for name, ms in device.pass_times():
+            acc.setdefault(name, []).append(ms)
+    device.set_profiling(False)
+    kernel_ms = {k: float(np.sum(v)) / 3 for k, v in acc.items()}  # chunks of a step add up
+    dist.barrier()
+
     # correctness of the timed output: closed form of the all-ones box on this rank's y-slab
     ys, ye = plan.local_y()
     idx = [torch.arange(e, device=dev, dtype=torch.float64) for e in ext]
@@ -347,6 +377,17 @@ def bench_main(args, rank, world, dev):
 
     if rank == 0:
         vox = ext[0] * ext[1] * ext[2]
+        # roofline of the dominant kernel ON ONE RANK: its algorithmic bytes (X reads
+        # labels + writes fp32; Y and Z read labels + read / write fp32) over its summed duration
+        bpv = {"x_pass": 4 + 4, "y_pass": 4 + 8, "z_pass": 4 + 8}
+        roofline = None
+        if any(k in kernel_ms for k in bpv):
+            dom = max((k for k in kernel_ms if k in bpv), key=lambda k: kernel_ms[k])
+            achieved = bpv[dom] * (vox / world) / (kernel_ms[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                        "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                        "note": "per rank; the exchange is not a kernel of this library and is not listed"}
         print(json.dumps({
             "metric": "Mvox/s edt3dsq 512^3 uint32", "value": round(vox / (elapsed / args.steps) / 1e6, 1),
             "unit": "Mvox/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -356,6 +397,9 @@ def bench_main(args, rank, world, dev):
             "config": {"workload": f"one {ext[0]}x{ext[1]}x{ext[2]} uint32 volume ({args.size}^3 voxels per GPU), "
                                    f"anisotropy {an}, black_border={bb}, Z-sharded over {world} GPUs, "
                                    "one all-to-all (Z-slabs -> Y-slabs) before the z pass",
+                       "form": "slab records" if plan.records else "byte flags",
+                       "chunks": getattr(plan, "nchunks", 1),
                        "output_verified": bool(ok.item())},
+            "roofline": roofline,
         }))
     dist.destroy_process_group()

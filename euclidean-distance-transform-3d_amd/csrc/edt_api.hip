@@ -786,6 +786,14 @@ int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, in
   return launch_subtract(d_a, d_b, d_out, count, (hipStream_t)stream);
 }
 
+int edt_hip_select_label_device(const void *d_labels, int dtype, const float *d_dt, const void *key,
+                                float *d_out, int64_t count, void *stream) {
+  if (count < 0 || dtype_size(dtype) == 0) { set_error("bad argument"); return EDT_ERR_BAD_ARG; }
+  if (count == 0) return EDT_OK;
+  if (!d_labels || !d_dt || !d_out || !key) { set_error("null pointer"); return EDT_ERR_BAD_ARG; }
+  return launch_select_label(dtype, d_labels, d_dt, d_out, key, count, (hipStream_t)stream);
+}
+
 int edt_hip_is_background_device(const void *d_labels, int dtype, uint8_t *d_mask, int64_t count,
                                  void *stream) {
   return launch_is_background(dtype, d_labels, d_mask, count, (hipStream_t)stream);

@@ -346,4 +346,50 @@ int launch_is_background(int dtype, const void *labels, uint8_t *mask, int64_t c
   return EDT_OK;
 }
 
+// each(): the distance transform restricted to ONE label (src/edt.pyx:950-994 builds this image on
+// the host from run lists: zeros + transfer_run_voxels, src/edt_voxel_graph.hpp:290-310).  One
+// streaming pass: 4 voxels per lane so that the fp32 side moves in 16-byte pieces.
+template <typename T>
+__global__ void k_select_label(const T *__restrict__ labels, const float *__restrict__ dt,
+                               float *__restrict__ out, T key, int64_t count) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < count; i += step) {
+    if (i + 4 <= count && (reinterpret_cast<uintptr_t>(dt + i) % 16) == 0 &&
+        (reinterpret_cast<uintptr_t>(out + i) % 16) == 0) {
+      const float4 v = *reinterpret_cast<const float4 *>(dt + i);
+      float4 r;
+      r.x = labels[i] == key ? v.x : 0.0f;
+      r.y = labels[i + 1] == key ? v.y : 0.0f;
+      r.z = labels[i + 2] == key ? v.z : 0.0f;
+      r.w = labels[i + 3] == key ? v.w : 0.0f;
+      *reinterpret_cast<float4 *>(out + i) = r;
+    } else {
+      for (int64_t j = i; j < count && j < i + 4; ++j) out[j] = labels[j] == key ? dt[j] : 0.0f;
+    }
+  }
+}
+
+int launch_select_label(int dtype, const void *labels, const float *dt, float *out, const void *key,
+                        int64_t count, hipStream_t stream) {
+  if (count <= 0) return EDT_OK;
+  const int threads = 256;
+  int64_t blocks = ceil_div(ceil_div(count, 4), threads);
+  if (blocks > 16384) blocks = 16384;
+#define LAUNCH_SEL(T)                                                                         \
+  hipLaunchKernelGGL(k_select_label<T>, dim3((unsigned)blocks), dim3(threads), 0, stream,     \
+                     (const T *)labels, dt, out, *(const T *)key, count)
+  switch (dtype) {
+    case EDT_U8: case EDT_BOOL: LAUNCH_SEL(uint8_t); break;
+    case EDT_U16: LAUNCH_SEL(uint16_t); break;
+    case EDT_U32: LAUNCH_SEL(uint32_t); break;
+    case EDT_U64: LAUNCH_SEL(uint64_t); break;
+    case EDT_F32: LAUNCH_SEL(float); break;
+    case EDT_F64: LAUNCH_SEL(double); break;
+    default: set_error("unknown dtype"); return EDT_ERR_BAD_ARG;
+  }
+#undef LAUNCH_SEL
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
 }  // namespace edt_amd

@@ -43,6 +43,8 @@ int launch_column_pass_serial(const float *fin, float *fout, const uint32_t *nz,
 int launch_subtract(const float *a, const float *b, float *out, int64_t count, hipStream_t stream);
 int launch_is_background(int dtype, const void *labels, uint8_t *mask, int64_t count,
                          hipStream_t stream);
+int launch_select_label(int dtype, const void *labels, const float *dt, float *out, const void *key,
+                        int64_t count, hipStream_t stream);
 
 }  // namespace edt_amd
 

@@ -231,27 +231,94 @@ def _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim):
 
 
 # ----------------------------------------------------------------------------------------
-# each(): per-label views of a distance transform (reference: src/edt.pyx:950-994).
-# Host-side convenience on top of the DT; not part of the GPU hot path.
+# Run utilities and each(): per-label views of a distance transform (reference:
+# src/edt.pyx:847-994, src/edt_voxel_graph.hpp:238-310).  Host-side conveniences on top of the DT
+# with the reference's semantics (runs are half-open [start, end) ranges of the array's memory
+# order); the device-resident counterpart of each() is edt.device.each / select_label.
 # ----------------------------------------------------------------------------------------
+def _flat(arr: np.ndarray) -> np.ndarray:
+    """1-D view in memory order (src/edt.pyx:851-877: in-place reshape of a contiguous array)."""
+    if arr.flags.f_contiguous and not arr.flags.c_contiguous:
+        return arr.reshape(-1, order="F")
+    return arr.reshape(-1)
+
+
+def runs(labels):
+    """``{label: [(start, end), ...]}`` -- where each label lies (src/edt_voxel_graph.hpp:238-268)."""
+    flat = _flat(np.asarray(labels))
+    out = {}
+    if flat.size == 0:
+        return out
+    cuts = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+    starts = np.concatenate(([0], cuts))
+    ends = np.concatenate((cuts, [flat.size]))
+    for s, e, v in zip(starts.tolist(), ends.tolist(), flat[starts].tolist()):
+        out.setdefault(v, []).append((s, e))
+    return dict(sorted(out.items()))  # std::map iterates in key order
+
+
+def _check_runs(rns, voxels):
+    for s, e in rns:
+        if s < 0 or e > voxels or e < 0 or s >= e:
+            raise RuntimeError("Invalid run.")  # src/edt_voxel_graph.hpp:277-283
+
+
+def draw(label, runs, image):
+    """Write ``label`` into ``image`` along ``runs`` (set_run_voxels, src/edt_voxel_graph.hpp:270-288).
+    Like the reference (src/edt.pyx:895-913) it returns the FLAT view of the image it wrote through."""
+    flat = _flat(image)
+    _check_runs(runs, flat.size)
+    for s, e in runs:
+        flat[s:e] = label
+    return flat
+
+
+def transfer(runs, src, dest):
+    """Copy ``src`` to ``dest`` along ``runs`` (transfer_run_voxels, src/edt_voxel_graph.hpp:290-310);
+    returns the flat view of ``dest`` (src/edt.pyx:915-935)."""
+    fs, fd = _flat(src), _flat(dest)
+    assert fs.size == fd.size
+    _check_runs(runs, fs.size)
+    for s, e in runs:
+        fd[s:e] = fs[s:e]
+    return fd
+
+
+def erase(runs, image):
+    """Zero ``image`` along ``runs`` (src/edt.pyx:937-947)."""
+    return draw(0, runs, image)
+
+
 def each(labels, dt, in_place=False):
-    """Iterate ``(label, image)`` where image is ``dt`` restricted to that label."""
+    """Iterate ``(label, image)`` where image is ``dt`` restricted to that label
+    (src/edt.pyx:950-994; ``in_place`` reuses one read-only image)."""
     labels = np.asarray(labels)
     dt = np.asarray(dt)
+    all_runs = runs(labels)
     order = "F" if labels.flags.f_contiguous else "C"
-    keys = [k for k in np.unique(labels) if k != 0]
 
     class ImageIterator:
         def __len__(self):
-            return len(keys)
+            return len(all_runs) - int(0 in all_runs)
 
         def __iter__(self):
-            for key in keys:
+            for key, rns in all_runs.items():
+                if key == 0:
+                    continue
                 img = np.zeros(labels.shape, dtype=np.float32, order=order)
-                sel = labels == key
-                img[sel] = dt[sel]
-                if in_place:
-                    img.setflags(write=0)
+                transfer(rns, dt, img)
                 yield (key, img)
 
-    return ImageIterator()
+    class InPlaceImageIterator(ImageIterator):
+        def __iter__(self):
+            img = np.zeros(labels.shape, dtype=np.float32, order=order)
+            for key, rns in all_runs.items():
+                if key == 0:
+                    continue
+                transfer(rns, dt, img)
+                img.setflags(write=0)
+                yield (key, img)
+                img.setflags(write=1)
+                erase(rns, img)
+
+    return InPlaceImageIterator() if in_place else ImageIterator()

@@ -61,6 +61,7 @@ SIGNATURES = {
     "edt_hip_shard_xy_records_device": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _f, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "edt_hip_shard_z_records_device": (_i, [_vp, _i64, _i64, _i64, _f, _i, _vp, _sz, _vp]),
     "edt_hip_subtract_device": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "edt_hip_select_label_device": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _vp]),
     "edt_hip_is_background_device": (_i, [_vp, _i, _vp, _i64, _vp]),
 }
 

@@ -128,6 +128,50 @@ def sdf(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tens
     return dt
 
 
+_NP_OF_CODE = {_lib.U8: np.uint8, _lib.BOOL: np.uint8, _lib.U16: np.uint16, _lib.U32: np.uint32,
+               _lib.U64: np.uint64, _lib.F32: np.float32, _lib.F64: np.float64}
+
+
+def select_label(labels: torch.Tensor, dt: torch.Tensor, key, out: torch.Tensor = None) -> torch.Tensor:
+    """``dt`` where ``labels == key``, 0 elsewhere -- the image :func:`edt.each` yields for one label,
+    as one streaming kernel (edt_hip_select_label_device)."""
+    if labels.shape != dt.shape or dt.dtype != torch.float32:
+        raise ValueError("dt must be a float32 tensor of the labels' shape")
+    labels, dt = labels.contiguous(), dt.contiguous()
+    if out is None:
+        out = torch.empty_like(dt)
+    code = dtype_code(labels.dtype)
+    # the key in the labels' own representation (signed labels are compared as their bit patterns)
+    if labels.dtype in (torch.int8, torch.int16, torch.int32, torch.int64):
+        signed = {torch.int8: np.int8, torch.int16: np.int16, torch.int32: np.int32, torch.int64: np.int64}
+        host = np.array([key], dtype=signed[labels.dtype]).view(_NP_OF_CODE[code])
+    else:
+        host = np.array([key], dtype=_NP_OF_CODE[code])
+    _lib.check(_lib.load().edt_hip_select_label_device(
+        ctypes.c_void_p(labels.data_ptr()), code, ctypes.c_void_p(dt.data_ptr()),
+        ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(out.data_ptr()), labels.numel(), _stream_ptr()))
+    return out
+
+
+def each(labels: torch.Tensor, dt: torch.Tensor, in_place: bool = False):
+    """Device-resident :func:`edt.each` (reference: src/edt.pyx:950-994): an iterable of
+    ``(label, image)`` with ``image = dt`` restricted to that label, zeros elsewhere; the label 0 is
+    skipped.  ``in_place=True`` reuses ONE output tensor for every label (the reference's read-only
+    in-place image).  The DT never leaves the device: one streaming kernel per label."""
+    keys = [k for k in torch.unique(labels).tolist() if k != 0]
+
+    class ImageIterator:
+        def __len__(self):
+            return len(keys)
+
+        def __iter__(self):
+            shared = torch.empty_like(dt, dtype=torch.float32) if in_place else None
+            for key in keys:
+                yield key, select_label(labels, dt, key, out=shared)
+
+    return ImageIterator()
+
+
 def pass_times():
     """Durations (ms) of the kernels of the last profiled call, as ``[(name, ms), ...]``."""
     lib = _lib.load()

@@ -183,6 +183,12 @@ int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, in
 int edt_hip_is_background_device(const void *d_labels, int dtype, uint8_t *d_mask, int64_t count,
                                  void *stream);
 
+/* out[i] = (labels[i] == *key) ? dt[i] : 0 -- the image edt.each() yields for one label
+ * (src/edt.pyx:950-994: zeros + transfer of the label's runs, src/edt_voxel_graph.hpp:290-310), as one
+ * streaming kernel on device-resident data.  `key` is a HOST pointer to one value of the label dtype. */
+int edt_hip_select_label_device(const void *d_labels, int dtype, const float *d_dt, const void *key,
+                                float *d_out, int64_t count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

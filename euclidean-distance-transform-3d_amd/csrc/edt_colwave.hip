@@ -82,51 +82,68 @@ struct XFuse {
 };
 
 template <int CW, bool BB, bool XF, bool SC>
-__global__ void __launch_bounds__(2048 / CW, 4)
+__global__ void __launch_bounds__(64 * edt_lane::TileGeom<CW>::kCols / CW, 4)
 k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
                    const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x,
                    int epi, int dbg, int aligned16, XFuse xf, const BandScatter *__restrict__ scatter) {
   using namespace edt_lane;
   constexpr int NBP = 64 / CW;  // bands per column handled by a wave (power of two)
-  constexpr int W = 32 / CW;    // waves per workgroup
+  using TG = TileGeom<CW>;
+  constexpr int TC = TG::kCols;  // columns of the tile (32, or 16 for the 1024-row wave shape)
+  constexpr int W = TC / CW;     // waves per workgroup
   using IO = TileIO<CW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *tile = reinterpret_cast<float *>(smem);                           // [NBP*32][32]
-  uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * 32 * 32);    // [NBP][32]
-  uint32_t *rsp = alive + NBP * 32;                                        // [NBP][32]
+  float *tile = reinterpret_cast<float *>(smem);                                   // [NBP*32][TC] (+ band padding)
+  uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * TG::kBandFloats);    // [NBP][TC]
+  uint32_t *rsp = alive + NBP * TG::kBandWords;                                    // [NBP][TC]
   // XF only: row records, one spare slot per band so that the bands of a half-wave read
   // different banks ([33*NBP] x 16 B), then the table T ([sx+3] floats)
-  XRowMeta *xrec = reinterpret_cast<XRowMeta *>(rsp + NBP * 32);
+  XRowMeta *xrec = reinterpret_cast<XRowMeta *>(rsp + NBP * TG::kBandWords);
   float *xT = reinterpret_cast<float *>(xrec + 33 * NBP);
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
   const int n = (int)g.n;
   const int NB = (int)g.nbands;
-  const int64_t xt = blockIdx.x % tiles_x, o = blockIdx.x / tiles_x;
-  const int64_t x0 = xt * 32;
+  int64_t tile_id = blockIdx.x;
+  if constexpr (CW == 2) {
+    // 16-column tiles: tiles 2k and 2k+1 share their 128-byte lines.  Workgroup b runs on XCD b % 8
+    // (observed placement, used for speed only): give both halves of a pair to ONE XCD, back to
+    // back, so that the second half finds the lines in that XCD's L2.  (The grid is a multiple of 16.)
+    const int64_t x = tile_id & 7, j = tile_id >> 3;
+    if (!(dbg & 0x400)) tile_id = ((j >> 1) * 8 + x) * 2 + (j & 1);  // (diagnostics: bit 10 = plain order)
+    if (tile_id >= (int64_t)tiles_x * g.nouter) return;
+  }
+  const int64_t xt = tile_id % tiles_x, o = tile_id / tiles_x;
+  const int64_t x0 = xt * TC;
   const int64_t st = g.stride;
   float *Ftile = F + x0 + o * g.outer_stride;
   const int cols_left = (int)(g.sx - x0);  // columns of this tile that exist
 
+  // cache policy of the tile fill: streaming (nt) for whole-line tiles; the 16-column tiles must leave
+  // their lines in L2 for the workgroup that takes the other half
+  constexpr int kLoadAux = CW == 2 ? 0 : EDT_TILE_LOAD_AUX;
   if constexpr (!XF) {
     // ---- phase 0: the whole tile, HBM -> LDS --------------------------------------------
     // one instruction = 64 lanes x G floats = 2*G rows of 128 B, all rows in one band
     if (IO::kGran == 4 && aligned16) {
-      for (int i = wave; i < NBP * 4; i += W) {
+      // (direct global->LDS loads: tools/tileprobe.hip shows the same fill through VGPRs 7 % faster in
+      // isolation, but inside this kernel it costs 0.035 ms -- the loading workgroup then competes
+      // for issue slots with the one that is computing on the same CU; measured and rejected)
+      for (int i = wave; i < IO::count(NBP, 4); i += W) {
         const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
         if (row < n && gc < cols_left)
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + gc),
-              (__attribute__((address_space(3))) void *)(tile + i * 256), 16, 0, EDT_TILE_LOAD_AUX);
+              (__attribute__((address_space(3))) void *)(tile + io_lds_word<CW, 4>(i, 0)), 16, 0, kLoadAux);
       }
     } else {
-      for (int i = wave; i < NBP * 16; i += W) {
+      for (int i = wave; i < IO::count(NBP, 1); i += W) {
         const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
         if (row < n && gc < cols_left)
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + gc),
-              (__attribute__((address_space(3))) void *)(tile + i * 64), 4, 0, EDT_TILE_LOAD_AUX);
+              (__attribute__((address_space(3))) void *)(tile + io_lds_word<CW, 1>(i, 0)), 4, 0, kLoadAux);
       }
     }
   } else {
@@ -164,7 +181,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   if constexpr (!XF) {
     const float *own = tile + addr_tile<CW>(L.colc, L.row0);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) f[r] = own[r * 32];
+    for (int r = 0; r < 32; ++r) f[r] = own[r * TC];
   } else {
     // pass 1 rebuilt from the row records (edt_colwave_lane.h: xpass_value), published in the tile
     // for the hull look-ups of the other lanes of this wave
@@ -176,7 +193,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
       float v = 0.0f;
       if (L.row0 + r < n) v = xpass_value(rec[r], h, cbase, L.colc, xT, xf.idx_inf, xf.flim, (L.nzw >> r) & 1u);
       f[r] = v;
-      own[r * 32] = v;
+      own[r * TC] = v;
     }
     wave_sync();
   }
@@ -222,8 +239,10 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   // ---- results -> LDS (in place) -> HBM ------------------------------------------------------
   {
     float *own = tile + addr_tile<CW>(L.colc, L.row0);
+    if (!(dbg & 0x200)) {  // (diagnostics: bit 9 leaves the tile as it was loaded)
 #pragma unroll
-    for (int r = 0; r < 32; ++r) own[r * 32] = f[r];
+      for (int r = 0; r < 32; ++r) own[r * TC] = f[r];
+    }
   }
   __syncthreads();
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -231,36 +250,36 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     // Z-sharded path: the rows leave for the slab records of their destination (one look-up per
     // band; a band never straddles two destinations).  Same granules as the in-place stores.
     if (IO::kGran == 4 && aligned16) {
-      for (int i = wave; i < NBP * 4; i += W) {
+      for (int i = wave; i < IO::count(NBP, 4); i += W) {
         const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
         if (row < n && gc < cols_left) {
           const int b = row >> 5;
           float *dst = scatter->rows[b] + o * scatter->ostride[b] + (int64_t)(row & 31) * st + x0 + gc;
-          *reinterpret_cast<v4f *>(dst) = *reinterpret_cast<const v4f *>(tile + io_lds_word<4>(i, lane));
+          *reinterpret_cast<v4f *>(dst) = *reinterpret_cast<const v4f *>(tile + io_lds_word<CW, 4>(i, lane));
         }
       }
     } else {
-      for (int i = wave; i < NBP * 16; i += W) {
+      for (int i = wave; i < IO::count(NBP, 1); i += W) {
         const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
         if (row < n && gc < cols_left) {
           const int b = row >> 5;
           scatter->rows[b][o * scatter->ostride[b] + (int64_t)(row & 31) * st + x0 + gc] =
-              tile[io_lds_word<1>(i, lane)];
+              tile[io_lds_word<CW, 1>(i, lane)];
         }
       }
     }
   } else if (IO::kGran == 4 && aligned16) {
-    for (int i = wave; i < NBP * 4; i += W) {
+    for (int i = wave; i < IO::count(NBP, 4); i += W) {
       const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
       if (row < n && gc < cols_left) {
-        const v4f v = *reinterpret_cast<const v4f *>(tile + io_lds_word<4>(i, lane));
+        const v4f v = *reinterpret_cast<const v4f *>(tile + io_lds_word<CW, 4>(i, lane));
         EDT_TILE_STORE(reinterpret_cast<v4f *>(Ftile + (int64_t)row * st + gc), v);
       }
     }
   } else {
-    for (int i = wave; i < NBP * 16; i += W) {
+    for (int i = wave; i < IO::count(NBP, 1); i += W) {
       const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
-      if (row < n && gc < cols_left) Ftile[(int64_t)row * st + gc] = tile[io_lds_word<1>(i, lane)];
+      if (row < n && gc < cols_left) Ftile[(int64_t)row * st + gc] = tile[io_lds_word<CW, 1>(i, lane)];
     }
   }
 }
@@ -278,7 +297,9 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
                            int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
                            bool scatter_aligned) {
   constexpr int NBP = 64 / CW;
-  size_t lds = (size_t)NBP * 32 * 32 * sizeof(float) + 2 * (size_t)NBP * 32 * sizeof(uint32_t);
+  using TG = edt_lane::TileGeom<CW>;
+  constexpr int TC = TG::kCols;
+  size_t lds = (size_t)NBP * TG::kBandFloats * sizeof(float) + 2 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
   if (XF) lds += (size_t)33 * NBP * sizeof(edt_lane::XRowMeta) + (size_t)(xf.idx_inf + 1) * sizeof(float);
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
@@ -286,14 +307,15 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  const int64_t tiles_x = ceil_div(g.sx, 32);
-  const int64_t tiles = tiles_x * g.nouter;
+  const int64_t tiles_x = ceil_div(g.sx, TC);
+  int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;
+  if (CW == 2) tiles = ceil_div(tiles, 16) * 16;  // the pair-per-XCD mapping permutes blocks of 16
   // 16-byte granules need 16-byte aligned rows; otherwise the tile moves float by float
   const int aligned16 = (g.sx % 4) == 0 && (g.stride % 4) == 0 && (g.outer_stride % 4) == 0 &&
                         (reinterpret_cast<uintptr_t>(F) % 16) == 0 && (scatter == nullptr || scatter_aligned);
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF, SC>), dim3((unsigned)tiles), dim3(2048 / CW), lds, stream,
+  hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF, SC>), dim3((unsigned)tiles), dim3(64 * TC / CW), lds, stream,
                      F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), aligned16, xf, scatter);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;

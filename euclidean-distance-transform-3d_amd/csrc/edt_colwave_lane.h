@@ -43,7 +43,18 @@
 
 namespace edt_lane {
 
-constexpr int kTileCols = 32;  // columns of a workgroup tile = floats per LDS tile row
+// Geometry of the workgroup tile per wave shape.  Axes up to 512 rows (CW >= 4): 32 columns, i.e.
+// whole 128-byte lines per row, at most 64 KiB of fp32 -> two workgroups per CU.  1024-row axes
+// (CW = 2): a 32-column tile would fill the LDS of a CU (128 KiB) and leave ONE workgroup per CU,
+// whose compute phase nothing overlaps (measured: 0.35 ms per pass against 0.23 ms for 512 rows, the
+// memory phases alone 0.245 ms); so those use 16-column tiles (64-byte row pieces, 64.5 KiB), two
+// workgroups per CU, the two halves of a line handled back to back on one XCD (edt_colwave.hip).
+template <int CW>
+struct TileGeom {
+  static constexpr int kCols = CW == 2 ? 16 : 32;                    // floats per LDS tile row
+  static constexpr int kBandFloats = CW == 2 ? 32 * 16 + 4 : 32 * 32;  // LDS floats per band of 32 rows
+  static constexpr int kBandWords = CW == 2 ? 18 : 32;               // bit-plane words per band
+};
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // w = 2*w + cond: one add-with-carry whose carry-in is the wave-wide compare mask.  Being a
@@ -83,16 +94,27 @@ enum : int { kLaneEpiToInf = 1, kLaneEpiSqrt = 2 };
 enum : int { kStPop = 0, kStBridgeCall, kStBridgeStep, kStOwnRow, kStGeneralRow, kStResync, kStPrologueStep,
              kStAdvance, kStFindNext, kStFindNextLds, kStFresh, kStKinds };
 
-// LDS addressing of one lane.  The fp32 tile is row-major [row][32]; the 16-byte granule
-// that holds the lane's column is XOR-rotated by its band so that the 32 lanes of a
+// LDS addressing of one lane.  32-column tiles: the fp32 tile is row-major [row][32]; the 16-byte
+// granule that holds the lane's column is XOR-rotated by its band so that the 32 lanes of a
 // half-wave (32/CW bands x CW columns) read 32 different banks when each reads "its" row.
 // The bit planes ([band][32] words) use the same rotation.
+// 16-column tiles (CW = 2): rows are 16 floats, no rotation (so that 16-byte granules stay whole);
+// instead every band is followed by 4 floats of padding, which spreads "every lane reads its own
+// row r" (2 columns x 32 bands) over 16 banks -- a 4-way conflict on 64 accesses per lane and tile,
+// cheap next to what the rotation would cost in 4-byte tile traffic -- and the bit planes use 18
+// words per band (2-way, the minimum for 64 lanes).
 template <int CW>
-EDT_LANE int addr_swz(int band) { return (band * CW) & 31; }  // rotate by one wave's columns per band
+EDT_LANE int addr_swz(int band) { return CW == 2 ? 0 : (band * CW) & 31; }  // rotate by one wave's columns per band
 template <int CW>
-EDT_LANE int addr_tile(int colc, int row) { return (row << 5) + (colc ^ addr_swz<CW>(row >> 5)); }
+EDT_LANE int addr_tile(int colc, int row) {
+  if (CW == 2) return (row >> 5) * TileGeom<CW>::kBandFloats + ((row & 31) << 4) + colc;
+  return (row << 5) + (colc ^ addr_swz<CW>(row >> 5));
+}
 template <int CW>
-EDT_LANE int addr_word(int colc, int band) { return (band << 5) + (colc ^ addr_swz<CW>(band)); }
+EDT_LANE int addr_word(int colc, int band) {
+  if (CW == 2) return band * TileGeom<CW>::kBandWords + colc;
+  return (band << 5) + (colc ^ addr_swz<CW>(band));
+}
 
 struct Lane {
   float *tile;           // LDS fp32 tile of the workgroup
@@ -175,14 +197,29 @@ EDT_LANE float xpass_value(const XRowMeta &m, int h, int cbase, int col, const f
 // 1024-row axes and volumes whose x extent is not a multiple of 4.
 template <int CW>
 struct TileIO {
-  static constexpr int kGran = CW >= 4 ? 4 : 1;  // widest granule this wave shape allows
+  static constexpr int kGran = 4;  // widest granule the wave shape allows (rotation / rows are multiples of 4)
+  // wave-wide instructions that move the whole tile with granules of G floats
+  static constexpr int count(int NBP, int G) { return NBP * TileGeom<CW>::kCols / (2 * G); }
 };
 template <int CW, int G>
-EDT_LANE int io_row(int i, int lane) { return (64 * G / 32) * i + (lane * G) / 32; }
+EDT_LANE int io_row(int i, int lane) {
+  return (64 * G / TileGeom<CW>::kCols) * i + (lane * G) / TileGeom<CW>::kCols;
+}
 template <int CW, int G>
-EDT_LANE int io_gcol(int i, int lane) { return ((lane * G) & 31) ^ addr_swz<CW>(io_row<CW, G>(i, lane) >> 5); }
-template <int G>
-EDT_LANE int io_lds_word(int i, int lane) { return (i * 64 + lane) * G; }
+EDT_LANE int io_gcol(int i, int lane) {
+  return ((lane * G) & (TileGeom<CW>::kCols - 1)) ^ addr_swz<CW>(io_row<CW, G>(i, lane) >> 5);
+}
+// LDS word of lane `lane` of instruction i: linear in the lane (global_load_lds writes lane l at
+// base + l * 4 * G bytes); an instruction never straddles a band, so the band padding of the
+// 16-column tiles only moves the instruction's base
+template <int CW, int G>
+EDT_LANE int io_lds_word(int i, int lane) {
+  if (CW == 2) {
+    const int row = (64 * G / 16) * i;  // first row of the instruction
+    return (row >> 5) * TileGeom<CW>::kBandFloats + ((row & 31) << 4) + lane * G;
+  }
+  return (i * 64 + lane) * G;
+}
 
 // per-band inputs of that scan
 EDT_LANE int band_last_start(uint32_t rsw, int row0) { return rsw ? row0 + 31 - clz32(rsw) : -1; }

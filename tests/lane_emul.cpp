@@ -34,27 +34,29 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
                int64_t stride, int64_t x0, float w, int epi, const XRowMeta *meta = nullptr,
                const float *Ttab = nullptr, int idx_inf = 0, int flim = 0) {
   constexpr int NBP = 64 / CW;
-  constexpr int W = 32 / CW;
+  using TG = TileGeom<CW>;
+  constexpr int TC = TG::kCols;
+  constexpr int W = TC / CW;
   using IO = TileIO<CW>;
-  std::vector<float> tile((size_t)NBP * 32 * 32, -12345.0f);
-  std::vector<uint32_t> alive((size_t)NBP * 32, 0), rsp((size_t)NBP * 32, 0);
+  std::vector<float> tile((size_t)NBP * TG::kBandFloats, -12345.0f);
+  std::vector<uint32_t> alive((size_t)NBP * TG::kBandWords, 0), rsp((size_t)NBP * TG::kBandWords, 0);
   const int cols_left = (int)(sx - x0);
   // phase 0: the swizzled fill, exactly as the kernel addresses it (16-byte granules when the rows
   // are 16-byte aligned and the wave shape allows, single floats otherwise)
   const bool gran4 = IO::kGran == 4 && sx % 4 == 0;
   if (gran4) {
-    for (int i = 0; i < NBP * 4; ++i)
+    for (int i = 0; i < IO::count(NBP, 4); ++i)
       for (int lane = 0; lane < 64; ++lane) {
         const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
         if (row < n && gc < cols_left)
-          std::memcpy(&tile[(size_t)io_lds_word<4>(i, lane)], F + x0 + (int64_t)row * stride + gc, 16);
+          std::memcpy(&tile[(size_t)io_lds_word<CW, 4>(i, lane)], F + x0 + (int64_t)row * stride + gc, 16);
       }
   } else {
-    for (int i = 0; i < NBP * 16; ++i)
+    for (int i = 0; i < IO::count(NBP, 1); ++i)
       for (int lane = 0; lane < 64; ++lane) {
         const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
         if (row < n && gc < cols_left)
-          std::memcpy(&tile[(size_t)io_lds_word<1>(i, lane)], F + x0 + (int64_t)row * stride + gc, 4);
+          std::memcpy(&tile[(size_t)io_lds_word<CW, 1>(i, lane)], F + x0 + (int64_t)row * stride + gc, 4);
       }
   }
   struct PerLane { Lane L; float f[32]; uint32_t aw, flat; Hull1 H; };
@@ -104,13 +106,13 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
           v = xpass_value(meta[row], (int)((x0 >> 5) & 1), (int)(x0 & ~63), P.L.colc, Ttab, idx_inf, flim,
                           (P.L.nzw >> r) & 1u);
         P.f[r] = v;
-        own[r * 32] = v;
+        own[r * TC] = v;
       }
     }
   } else {
     for (auto &P : lanes) {
       const float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
-      for (int r = 0; r < 32; ++r) P.f[r] = own[r * 32];
+      for (int r = 0; r < 32; ++r) P.f[r] = own[r * TC];
     }
   }
   auto lane_of = [&](int colc, int band) -> PerLane * {
@@ -159,21 +161,21 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
 #endif
   for (auto &P : lanes) {
     float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
-    for (int r = 0; r < 32; ++r) own[r * 32] = P.f[r];
+    for (int r = 0; r < 32; ++r) own[r * TC] = P.f[r];
   }
   if (gran4) {
-    for (int i = 0; i < NBP * 4; ++i)
+    for (int i = 0; i < IO::count(NBP, 4); ++i)
       for (int lane = 0; lane < 64; ++lane) {
         const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
         if (row < n && gc < cols_left)
-          std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<4>(i, lane)], 16);
+          std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<CW, 4>(i, lane)], 16);
       }
   } else {
-    for (int i = 0; i < NBP * 16; ++i)
+    for (int i = 0; i < IO::count(NBP, 1); ++i)
       for (int lane = 0; lane < 64; ++lane) {
         const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
         if (row < n && gc < cols_left)
-          std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<1>(i, lane)], 4);
+          std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<CW, 1>(i, lane)], 4);
       }
   }
 }
@@ -182,7 +184,7 @@ template <int CW>
 void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n, int NB, int64_t stride,
              float w, int bb, int epi, const XRowMeta *meta = nullptr, const float *Ttab = nullptr,
              int idx_inf = 0, int flim = 0) {
-  for (int64_t x0 = 0; x0 < sx; x0 += 32) {
+  for (int64_t x0 = 0; x0 < sx; x0 += TileGeom<CW>::kCols) {
     const XRowMeta *m = meta ? meta + (x0 >> 6) * n : nullptr;  // records are [chunk][row]
     if (bb) tile_pass<CW, true>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim);
     else tile_pass<CW, false>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim);

@@ -23,7 +23,7 @@ static int g_grouping = 0, g_cw = 4;
 extern "C" void lane_stats_grouping(int mode, int cw) { g_grouping = mode; g_cw = cw; }
 static int wave_of(int id) {
   if (g_grouping == 0) return id / 64;
-  const int per_tile = 32 * (64 / g_cw);            // lanes per tile
+  const int per_tile = (g_cw == 2 ? 16 : 32) * (64 / g_cw);  // lanes per tile (TileGeom)
   const int tile = id / per_tile, in = id % per_tile;
   const int wave = in / 64, lane = in % 64;
   const int band = lane / g_cw;                       // lane = c + cw*b inside the kernel's wave

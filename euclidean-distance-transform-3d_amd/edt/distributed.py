@@ -61,12 +61,14 @@ class HipOps:
 
     def __init__(self):
         self.lib = _lib.load()
-        self._ws = None
+        self._ws = {}
 
-    def _workspace(self, nbytes, device):
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        return self._ws
+    def _workspace(self, nbytes, device, slot=0):
+        """Scratch of one stream of work (`slot`): calls that may overlap use different slots."""
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = self._ws[slot] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return ws
 
     @staticmethod
     def _stream():
@@ -92,10 +94,11 @@ class HipOps:
     def record_floats(self, sx, ylen):
         return int(self.lib.edt_hip_shard_record_floats(sx, ylen))
 
-    def xy_records(self, labels, halo, code, weights, flags, y_splits, blocks):
+    def xy_records(self, labels, halo, code, weights, flags, y_splits, blocks, slot=0):
         """X and Y passes of a z-chunk; block h receives chunk-many records of destination h."""
         szl, sy, sx = labels.shape
-        ws = self._workspace(self.lib.edt_hip_shard_records_workspace_bytes(code, sx, sy, szl), labels.device)
+        ws = self._workspace(self.lib.edt_hip_shard_records_workspace_bytes(code, sx, sy, szl), labels.device,
+                             slot)
         splits = (ctypes.c_int64 * len(y_splits))(*y_splits)
         ptrs = (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
         _lib.check(self.lib.edt_hip_shard_xy_records_device(
@@ -156,6 +159,8 @@ class ShardedEDT:
             want = chunks if chunks is not None else (4 if self.world > 1 else 1)
             self.nchunks = max(1, min(int(want), min(e - s for s, e in self.zparts)))
             self._send = {}
+            self._streams = None
+            self._nstreams = int(os.environ.get("EDT_SHARD_STREAMS", "2"))
             # how a chunk travels: "alltoall" = one dist.all_to_all per chunk (RCCL), "p2p" = a batch
             # of isend / irecv (any backend; gloo has no list all_to_all).  EDT_SHARD_EXCHANGE overrides.
             default = "alltoall" if dist.get_backend(group) == "nccl" else "p2p"
@@ -251,43 +256,67 @@ class ShardedEDT:
         y_splits = [a for a, _ in self.yparts] + [self.sy]
         dst = torch.empty((self.sz, rec[self.rank]), dtype=torch.float32, device=labels.device)
         pending = []
+        # On the GPU consecutive chunks alternate between two side streams (each with its own scratch):
+        # pass 1 of chunk k+1 fills the tail of chunk k's Y pass, and every exchange is ordered after
+        # exactly the kernels that produced its blocks.
+        side = None
+        if labels.is_cuda and self.nchunks > 1 and self._nstreams > 1:
+            main = torch.cuda.current_stream(labels.device)
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(labels.device) for _ in range(self._nstreams)]
+            side = self._streams
+            for st in side:
+                st.wait_stream(main)
         for k in range(self.nchunks):
-            c0, c1 = self._chunk(self.rank, k)
-            blocks = []
-            for h in range(self.world):
-                if h == self.rank:
-                    blocks.append(dst[c0:c1])  # own part: straight into the receive buffer
-                    continue
-                key = (k, h)
-                buf = self._send.get(key)
-                if buf is None or buf.shape != (c1 - c0, rec[h]) or buf.device != labels.device:
-                    buf = self._send[key] = torch.empty((c1 - c0, rec[h]), dtype=torch.float32,
-                                                        device=labels.device)
-                blocks.append(buf)
-            self.ops.xy_records(labels[c0 - zs:c1 - zs], halo, self.code, w, flags, y_splits, blocks)
-            halo = labels[c1 - zs - 1]  # the next chunk continues this slab
-            recv = [dst[slice(*self._chunk(h, k))] for h in range(self.world)]
-            if self._exchange == "alltoall":  # (also at world 1: a no-op that keeps the dry run honest)
-                # one collective call per chunk (RCCL runs it as a group of sends / receives; every
-                # peer pair has its own xGMI link); the own part is already in place -> empty entries
-                empty = dst[0:0]
-                ins = [empty if h == self.rank else blocks[h] for h in range(self.world)]
-                outs = [empty if h == self.rank else recv[h] for h in range(self.world)]
-                pending.append(dist.all_to_all(outs, ins, group=self.group, async_op=True))
+            if side is not None:
+                with torch.cuda.stream(side[k % len(side)]):
+                    self._records_chunk(k, labels, halo, w, flags, rec, y_splits, dst, pending, k % len(side))
             else:
-                p2p = []
-                for h in range(self.world):
-                    if h == self.rank:
-                        continue
-                    p2p.append(dist.P2POp(dist.isend, blocks[h], self._global_rank(h), self.group))
-                    p2p.append(dist.P2POp(dist.irecv, recv[h], self._global_rank(h), self.group))
-                if p2p:
-                    pending.extend(dist.batch_isend_irecv(p2p))
+                self._records_chunk(k, labels, halo, w, flags, rec, y_splits, dst, pending, None)
+            halo = labels[self._chunk(self.rank, k)[1] - zs - 1]  # the next chunk continues this slab
+        if side is not None:
+            for st in side:
+                main.wait_stream(st)
         for req in pending:
             req.wait()
         self.ops.z_records(dst, self.sx, ye - ys, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0))
         # the result is the float part of every record: a (sz, syl, sx) view with z-stride = record
         return dst[:, :(ye - ys) * self.sx].view(self.sz, ye - ys, self.sx)
+
+    def _records_chunk(self, k, labels, halo, w, flags, rec, y_splits, dst, pending, slot):
+        """XY phase of chunk k and the enqueue (not the wait) of its exchange, on the current stream."""
+        zs = self.local_z()[0]
+        c0, c1 = self._chunk(self.rank, k)
+        blocks = []
+        for h in range(self.world):
+            if h == self.rank:
+                blocks.append(dst[c0:c1])  # own part: straight into the receive buffer
+                continue
+            key = (k, h)
+            buf = self._send.get(key)
+            if buf is None or buf.shape != (c1 - c0, rec[h]) or buf.device != labels.device:
+                buf = self._send[key] = torch.empty((c1 - c0, rec[h]), dtype=torch.float32,
+                                                    device=labels.device)
+            blocks.append(buf)
+        kw = {} if slot is None else {"slot": slot}
+        self.ops.xy_records(labels[c0 - zs:c1 - zs], halo, self.code, w, flags, y_splits, blocks, **kw)
+        recv = [dst[slice(*self._chunk(h, k))] for h in range(self.world)]
+        if self._exchange == "alltoall":  # (also at world 1: a no-op that keeps the dry run honest)
+            # one collective call per chunk (RCCL runs it as a group of sends / receives; every
+            # peer pair has its own xGMI link); the own part is already in place -> empty entries
+            empty = dst[0:0]
+            ins = [empty if h == self.rank else blocks[h] for h in range(self.world)]
+            outs = [empty if h == self.rank else recv[h] for h in range(self.world)]
+            pending.append(dist.all_to_all(outs, ins, group=self.group, async_op=True))
+        else:
+            p2p = []
+            for h in range(self.world):
+                if h == self.rank:
+                    continue
+                p2p.append(dist.P2POp(dist.isend, blocks[h], self._global_rank(h), self.group))
+                p2p.append(dist.P2POp(dist.irecv, recv[h], self._global_rank(h), self.group))
+            if p2p:
+                pending.extend(dist.batch_isend_irecv(p2p))
 
     # -- the pipeline -----------------------------------------------------------------------
     def run(self, labels, weights_xyz, black_border=False, sqrt=False, gather_back=False):

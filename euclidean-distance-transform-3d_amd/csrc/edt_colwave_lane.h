@@ -424,11 +424,41 @@ EDT_LANE void phase2_merge(const Lane &L, int half) {
   const int run_hi = above ? R + ctz32(above) - 1 : L.hi_out;
   const int Rhi = run_hi < ghi ? run_hi : ghi;
 
+  // The walk almost always stays inside the two bit words that meet at the boundary (a handful of
+  // steps against 32 rows per word), so those two words live in registers: a step is then bit
+  // arithmetic plus ONE LDS read (the height of the new neighbour) instead of a read-modify-write of
+  // the alive plane followed by a dependent search through it.  Only a walk that leaves the two
+  // words goes back to the plane.  (No other lane touches these words in this round: the groups of
+  // the merging lanes of a column are disjoint.)
+  const int wl0 = R - 32;  // first row of the left word
+  uint32_t wl = L.alive[addr_word<CW>(L.colc, L.band - 1)];
+  uint32_t wr = L.alive[addr_word<CW>(L.colc, L.band)];
+  const uint32_t lmask = Llo > wl0 ? 0xFFFFFFFFu << (Llo - wl0) : 0xFFFFFFFFu;        // rows >= Llo
+  const uint32_t rmask = Rhi < R + 31 ? 0xFFFFFFFFu >> (31 - (Rhi - R)) : 0xFFFFFFFFu;  // rows <= Rhi
+  auto prev_of = [&](int q) -> int {  // hull vertex below q inside [Llo, q)
+    if (q >= wl0) {
+      const uint32_t m = wl & lmask & ~(0xFFFFFFFFu << (q - wl0));
+      if (m) return wl0 + 31 - clz32(m);
+      if (Llo >= wl0) return -1;
+      return prev_set<CW>(L.alive, L.colc, wl0, Llo);
+    }
+    return prev_set<CW>(L.alive, L.colc, q, Llo);
+  };
+  auto next_of = [&](int q) -> int {  // hull vertex above q inside (q, Rhi]
+    if (q <= R + 31) {
+      const uint32_t m = wr & rmask & (0xFFFFFFFEu << (q - R));
+      if (m) return R + ctz32(m);
+      if (Rhi <= R + 31) return -1;
+      return next_set<CW>(L.alive, L.colc, R + 31, Rhi);
+    }
+    return next_set<CW>(L.alive, L.colc, q, Rhi);
+  };
+
   int u = R - 1;  // last vertex of the left hull (always alive)
   int v = R;      // first vertex of the right hull (always alive)
   double Fu = ldF<CW>(L, u), Fv = ldF<CW>(L, v);
-  int up = prev_set<CW>(L.alive, L.colc, u, Llo);
-  int vn = next_set<CW>(L.alive, L.colc, v, Rhi);
+  int up = prev_of(u);
+  int vn = next_of(v);
   double Fup = up >= 0 ? ldF<CW>(L, up) : 0.0;
   double Fvn = vn >= 0 ? ldF<CW>(L, vn) : 0.0;
   EDT_STAT(kStBridgeCall, half, 1);
@@ -436,22 +466,26 @@ EDT_LANE void phase2_merge(const Lane &L, int half) {
     EDT_STAT(kStBridgeStep, half, 1);
     const double nuv = edge_num(u, Fu, v, Fv, w2);
     if (up >= 0 && nuv * (double)(u - up) <= edge_num(up, Fup, u, Fu, w2) * (double)(v - u)) {
-      L.alive[addr_word<CW>(L.colc, u >> 5)] &= ~(1u << (u & 31));
+      if (u >= wl0) wl &= ~(1u << (u - wl0));
+      else L.alive[addr_word<CW>(L.colc, u >> 5)] &= ~(1u << (u & 31));
       u = up;
       Fu = Fup;
-      up = prev_set<CW>(L.alive, L.colc, u, Llo);
+      up = prev_of(u);
       Fup = up >= 0 ? ldF<CW>(L, up) : 0.0;
     } else if (vn >= 0 &&
                edge_num(v, Fv, vn, Fvn, w2) * (double)(v - u) <= nuv * (double)(vn - v)) {
-      L.alive[addr_word<CW>(L.colc, v >> 5)] &= ~(1u << (v & 31));
+      if (v <= R + 31) wr &= ~(1u << (v - R));
+      else L.alive[addr_word<CW>(L.colc, v >> 5)] &= ~(1u << (v & 31));
       v = vn;
       Fv = Fvn;
-      vn = next_set<CW>(L.alive, L.colc, v, Rhi);
+      vn = next_of(v);
       Fvn = vn >= 0 ? ldF<CW>(L, vn) : 0.0;
     } else {
       break;
     }
   }
+  L.alive[addr_word<CW>(L.colc, L.band - 1)] = wl;
+  L.alive[addr_word<CW>(L.colc, L.band)] = wr;
 }
 
 EDT_LANE float finish_f(float m, int epi) {

@@ -106,7 +106,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   const int n = (int)g.n;
   const int NB = (int)g.nbands;
   int64_t tile_id = blockIdx.x;
-  if constexpr (CW == 2) {
+  if constexpr (CW <= 2) {
     // 16-column tiles: tiles 2k and 2k+1 share their 128-byte lines.  Workgroup b runs on XCD b % 8
     // (observed placement, used for speed only): give both halves of a pair to ONE XCD, back to
     // back, so that the second half finds the lines in that XCD's L2.  (The grid is a multiple of 16.)
@@ -122,7 +122,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 
   // cache policy of the tile fill: streaming (nt) for whole-line tiles; the 16-column tiles must leave
   // their lines in L2 for the workgroup that takes the other half
-  constexpr int kLoadAux = CW == 2 ? 0 : EDT_TILE_LOAD_AUX;
+  constexpr int kLoadAux = CW <= 2 ? 0 : EDT_TILE_LOAD_AUX;
   if constexpr (!XF) {
     // ---- phase 0: the whole tile, HBM -> LDS --------------------------------------------
     // one instruction = 64 lanes x G floats = 2*G rows of 128 B, all rows in one band
@@ -288,8 +288,8 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 // launcher
 // ---------------------------------------------------------------------------------------
 bool column_pass_wave_supported(const AxisGeom &g) {
-  // rows in VGPRs: one band per lane, at most 32 bands per column (n <= 1024)
-  return g.nbands >= 1 && g.nbands <= 32;
+  // rows in VGPRs: one band per lane, at most 64 bands per column (n <= 2048)
+  return g.nbands >= 1 && g.nbands <= 64;
 }
 
 template <int CW, bool BB, bool XF, bool SC>
@@ -310,7 +310,7 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   const int64_t tiles_x = ceil_div(g.sx, TC);
   int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;
-  if (CW == 2) tiles = ceil_div(tiles, 16) * 16;  // the pair-per-XCD mapping permutes blocks of 16
+  if (CW <= 2) tiles = ceil_div(tiles, 16) * 16;  // the pair-per-XCD mapping permutes blocks of 16
   // 16-byte granules need 16-byte aligned rows; otherwise the tile moves float by float
   const int aligned16 = (g.sx % 4) == 0 && (g.stride % 4) == 0 && (g.outer_stride % 4) == 0 &&
                         (reinterpret_cast<uintptr_t>(F) % 16) == 0 && (scatter == nullptr || scatter_aligned);
@@ -355,6 +355,7 @@ static int launch_wave_any(float *F, const uint32_t *nz, const uint32_t *rs, con
   if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
   if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
   if (NB <= 32 && xf == nullptr) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, nullptr, stream, sc, sc_al);
+  if (NB <= 64 && xf == nullptr) return launch_wave_c<1>(F, nz, rs, g, w, bb, epi, nullptr, stream, sc, sc_al);
   set_error("axis too long for the wave column pass");
   return EDT_ERR_UNSUPPORTED;
 }

@@ -51,9 +51,9 @@ namespace edt_lane {
 // workgroups per CU, the two halves of a line handled back to back on one XCD (edt_colwave.hip).
 template <int CW>
 struct TileGeom {
-  static constexpr int kCols = CW == 2 ? 16 : 32;                    // floats per LDS tile row
-  static constexpr int kBandFloats = CW == 2 ? 32 * 16 + 4 : 32 * 32;  // LDS floats per band of 32 rows
-  static constexpr int kBandWords = CW == 2 ? 18 : 32;               // bit-plane words per band
+  static constexpr int kCols = CW <= 2 ? 16 : 32;                    // floats per LDS tile row
+  static constexpr int kBandFloats = CW <= 2 ? 32 * 16 + 4 : 32 * 32;  // LDS floats per band of 32 rows
+  static constexpr int kBandWords = CW <= 2 ? 18 : 32;               // bit-plane words per band
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -104,15 +104,15 @@ enum : int { kStPop = 0, kStBridgeCall, kStBridgeStep, kStOwnRow, kStGeneralRow,
 // cheap next to what the rotation would cost in 4-byte tile traffic -- and the bit planes use 18
 // words per band (2-way, the minimum for 64 lanes).
 template <int CW>
-EDT_LANE int addr_swz(int band) { return CW == 2 ? 0 : (band * CW) & 31; }  // rotate by one wave's columns per band
+EDT_LANE int addr_swz(int band) { return CW <= 2 ? 0 : (band * CW) & 31; }  // rotate by one wave's columns per band
 template <int CW>
 EDT_LANE int addr_tile(int colc, int row) {
-  if (CW == 2) return (row >> 5) * TileGeom<CW>::kBandFloats + ((row & 31) << 4) + colc;
+  if (CW <= 2) return (row >> 5) * TileGeom<CW>::kBandFloats + ((row & 31) << 4) + colc;
   return (row << 5) + (colc ^ addr_swz<CW>(row >> 5));
 }
 template <int CW>
 EDT_LANE int addr_word(int colc, int band) {
-  if (CW == 2) return band * TileGeom<CW>::kBandWords + colc;
+  if (CW <= 2) return band * TileGeom<CW>::kBandWords + colc;
   return (band << 5) + (colc ^ addr_swz<CW>(band));
 }
 
@@ -214,7 +214,7 @@ EDT_LANE int io_gcol(int i, int lane) {
 // 16-column tiles only moves the instruction's base
 template <int CW, int G>
 EDT_LANE int io_lds_word(int i, int lane) {
-  if (CW == 2) {
+  if (CW <= 2) {
     const int row = (64 * G / 16) * i;  // first row of the instruction
     return (row >> 5) * TileGeom<CW>::kBandFloats + ((row & 31) << 4) + lane * G;
   }

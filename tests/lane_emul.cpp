@@ -198,7 +198,7 @@ void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n
 extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t sx, int64_t n, float w,
                                      int bb, int epi) {
   const int NB = (int)((n + 31) / 32);
-  if (NB < 1 || NB > 32) return -1;
+  if (NB < 1 || NB > 64) return -1;
   std::vector<uint32_t> nz((size_t)NB * sx, 0), rs((size_t)NB * sx, 0);
   for (int64_t x = 0; x < sx; ++x)
     for (int64_t y = 0; y < n; ++y) {
@@ -211,7 +211,8 @@ extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t s
   else if (NB <= 4) pass_cw<16>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
   else if (NB <= 8) pass_cw<8>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
   else if (NB <= 16) pass_cw<4>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
-  else pass_cw<2>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  else if (NB <= 32) pass_cw<2>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  else pass_cw<1>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
   return 0;
 }
 

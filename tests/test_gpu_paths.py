@@ -49,10 +49,12 @@ def test_kernel_families_agree_with_the_oracle(edt_gpu, oracle_port, mode, name)
 
 
 def test_axes_beyond_the_wave_kernels(edt_gpu, oracle_port):
-    """Rows / axes of 513..1024 voxels still take the wave kernels (16 chunks per row, 2-column waves);
-    beyond 1024 the LDS-staged row kernel and the workgroup-phased column kernel take over."""
+    """Rows of 513..1024 voxels still take the register-resident row kernel (16 chunks per row) and axes of
+    513..2048 rows the wave column kernel (2- and 1-column waves on 16-column tiles); beyond that the
+    LDS-staged row kernel and the workgroup-phased column kernel take over."""
     rng = np.random.default_rng(5)
-    for shape in ((1030, 40, 24), (48, 1040, 12), (40, 36, 1100), (1024, 64, 8), (600, 700, 3)):
+    for shape in ((1030, 40, 24), (48, 1040, 12), (40, 36, 1100), (1024, 64, 8), (600, 700, 3),
+                  (20, 2048, 6), (36, 9, 1500), (17, 2049, 3), (33, 5, 2100)):
         lab = np.asfortranarray(blocky_labels(shape, nlabels=4, zero_frac=0.1, block=int(rng.integers(5, 60)),
                                               rng=rng).astype(np.uint32))
         for an, bb in (((6, 6, 30), True), ((1, 1, 1), False)):

@@ -56,7 +56,7 @@ def x_pass(oracle, labels_yx, wx, bb):
 
 
 CASES = []
-for n, sx in ((1024, 32), (900, 36), (513, 8), (512, 64), (500, 36), (300, 37), (64, 3), (700, 65), (33, 1), (257, 40), (256, 32), (130, 96), (128, 8), (100, 44), (64, 32),
+for n, sx in ((2048, 16), (1500, 20), (1025, 5), (1024, 32), (900, 36), (513, 8), (512, 64), (500, 36), (300, 37), (64, 3), (700, 65), (33, 1), (257, 40), (256, 32), (130, 96), (128, 8), (100, 44), (64, 32),
               (33, 64), (32, 4), (17, 12), (1, 8), (2, 4)):
     for kind in ("ones", "blocky", "noise", "membrane"):
         CASES.append((n, sx, kind))

@@ -676,7 +676,7 @@ int edt_hip_shard_records_supported(int dtype, int64_t sx, int64_t sy, int64_t s
   if (dtype_size(dtype) == 0 || sx < 1 || sy < 1 || sz < 1) return 0;
   if (g_debug_mode & (32 | 64)) return 0;  // diagnostics: forced fallback kernels
   // pass 1 by the register-resident row kernel, both column passes by the wave kernel
-  return (sx <= 1024 && sy <= 1024 && sz <= 1024) ? 1 : 0;
+  return (sx <= 1024 && sy <= 2048 && sz <= 2048) ? 1 : 0;
 }
 
 size_t edt_hip_shard_record_floats(int64_t sx, int64_t y_rows) {
@@ -700,7 +700,7 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
   if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
   if (!d_labels || !y_splits || !d_blocks || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
   if (!edt_hip_shard_records_supported(dtype, sx, sy, sz_local)) {
-    set_error("slab records need sx, sy <= 1024 (use edt_hip_shard_xy_device)");
+    set_error("slab records need sx <= 1024 and sy <= 2048 (use edt_hip_shard_xy_device)");
     return EDT_ERR_UNSUPPORTED;
   }
   if (y_splits[0] != 0 || y_splits[nparts] != sy) { set_error("y_splits must run from 0 to sy"); return EDT_ERR_BAD_ARG; }
@@ -722,7 +722,7 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
   // destination map: every 32-row band of y lies inside one part
   BandScatter sc;
   bool aligned = (sx % 4) == 0;
-  for (int b = 0, h = 0; b < 32; ++b) {
+  for (int b = 0, h = 0; b < BandScatter::kBands; ++b) {
     if (b >= gy.nbands) { sc.rows[b] = nullptr; sc.bits[b] = nullptr; sc.ostride[b] = 0; sc.plane[b] = 0; continue; }
     while ((int64_t)b * kBandRows >= y_splits[h + 1]) ++h;
     const int64_t ys = y_splits[h], ylen = y_splits[h + 1] - ys, words = ceil_div(ylen, kBandRows);
@@ -757,7 +757,7 @@ int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_loca
   if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
   if (!d_records) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   if (!edt_hip_shard_records_supported(EDT_U8, sx, sy_local, sz)) {
-    set_error("slab records need sx, sz <= 1024 (use edt_hip_shard_z_device)");
+    set_error("slab records need sx <= 1024 and sz <= 2048 (use edt_hip_shard_z_device)");
     return EDT_ERR_UNSUPPORTED;
   }
   RecordPlan p = make_record_plan(sx, sy_local, sz, d_workspace);

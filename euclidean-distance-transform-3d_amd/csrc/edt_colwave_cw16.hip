@@ -1,0 +1,8 @@
+// edt_colwave_cw16.hip -- the column-pass kernels of the wave shape CW = 16 (4 bands per column) in their
+// own translation unit / device code object (see edt_colwave_kernel.h).
+#include "edt_colwave_kernel.h"
+
+namespace edt_amd {
+template int launch_wave_c<16>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int,
+                               const XFuse *, hipStream_t, const BandScatter *, bool);
+}  // namespace edt_amd

@@ -1,0 +1,340 @@
+#pragma once
+// edt_colwave_kernel.h -- wave-autonomous LDS-tiled column pass (passes 2 and 3) for gfx950: the kernel
+// template and its per-wave-shape launcher.  Included by edt_colwave_cw*.hip, ONE translation unit (= one
+// device code object) per wave shape CW: the kernel is ~85 KB of code, more than the instruction cache,
+// and its speed turned out to depend on where the loader places it (adding the CW = 1 variants to a
+// common code object moved the CW = 4 kernel and cost the 512-row y pass 10 %); separate code objects
+// keep the placement of each shape independent of the others (and the build parallel).
+//
+// Work decomposition
+//   workgroup = one tile of 32 adjacent columns (128 contiguous bytes per row, so every global
+//               access is a full cache line) x the WHOLE scan axis, staged once in LDS by
+//               direct global->LDS loads (global_load_lds_dwordx4: no VGPR round trip);
+//   wave      = CW = 64/NBP of those columns x all NBP bands (a band = 32 rows): the hull
+//               build, the hull merges and the evaluation of a column only involve lanes of
+//               ONE wave, so after the tile has landed the waves run without any workgroup
+//               barrier and hide each other's LDS/fp64 latencies (the previous design,
+//               edt_tiled.hip, synchronised 1024 threads four times per tile while most of
+//               them idled in the merge rounds);
+//   lane      = (column c, band b): its 32 rows live in VGPRs for the whole kernel.
+// The tile is read from HBM exactly once and written exactly once (8 B/voxel of traffic
+// against 12 B/voxel in the reference's data-movement model, which re-reads the labels).
+//
+// LDS image: fp32 tile [rows][32], the columns of a wave XOR-rotated by CW columns per band
+// (edt_colwave_lane.h: addr_tile) so that "every lane reads its own row" is bank-conflict free;
+// because global_load_lds writes LDS linearly (lane i -> base + 16*i, or 4*i for the 2-column waves
+// of 1024-row axes and for rows that are not 16-byte aligned), the rotation is applied to the
+// per-lane SOURCE address, and again when the results are streamed back.
+// Axes: up to 1024 rows (NBP = 2..32 bands per column, CW = 32..2 columns per wave).
+#include "edt_common.h"
+#include "edt_kernels.h"
+
+#pragma clang fp contract(off)
+
+// cache policy of the streamed tile (read once, written once): experiment knobs
+#ifndef EDT_TILE_LOAD_AUX
+#define EDT_TILE_LOAD_AUX 2  // nt: ~5 % faster tile fill than the default policy (measured)
+#endif
+#ifdef EDT_TILE_STORE_NT
+#define EDT_TILE_STORE(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define EDT_TILE_STORE(p, v) (*(p) = (v))
+#endif
+
+#define EDT_LANE __device__ __forceinline__
+#include "edt_colwave_lane.h"
+
+namespace edt_amd {
+
+namespace {
+
+__device__ __forceinline__ void wave_sync() {
+  // lanes of one wave exchange data through LDS: the hardware executes a wave's LDS
+  // instructions in order, the fence keeps the compiler from reordering them
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Run structure across the bands of a column: lane = c + CW*band, so "the bands below / above"
+// are the lanes CW, 2*CW, ... away.  Exclusive prefix max of the last run start, exclusive
+// suffix min of the first run start (Hillis-Steele over lane shuffles, log2(NBP) steps each).
+template <int CW>
+__device__ __forceinline__ void scan_runs(edt_lane::Lane &L, int lane) {
+  int x = __shfl_up(edt_lane::band_last_start(L.rsw, L.row0), CW);
+  if (lane < CW) x = -1;
+  int y = __shfl_down(edt_lane::band_first_start(L.rsw, L.row0, L.n) - 1, CW);
+  if (lane >= 64 - CW) y = L.n - 1;
+#pragma unroll
+  for (int d = CW; d < 64; d <<= 1) {
+    const int tx = __shfl_up(x, d);
+    const int ty = __shfl_down(y, d);
+    if (lane >= d) x = tx > x ? tx : x;
+    if (lane + d < 64) y = ty < y ? ty : y;
+  }
+  L.lo_in = x;
+  L.hi_out = y;
+}
+
+}  // namespace
+
+template <int CW, bool BB, bool XF, bool SC>
+__global__ void __launch_bounds__(64 * edt_lane::TileGeom<CW>::kCols / CW, 4)
+k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
+                   const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x,
+                   int epi, int dbg, int aligned16, XFuse xf, const BandScatter *__restrict__ scatter) {
+  using namespace edt_lane;
+  constexpr int NBP = 64 / CW;  // bands per column handled by a wave (power of two)
+  using TG = TileGeom<CW>;
+  constexpr int TC = TG::kCols;  // columns of the tile (32, or 16 for the 1024-row wave shape)
+  constexpr int W = TC / CW;     // waves per workgroup
+  using IO = TileIO<CW>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *tile = reinterpret_cast<float *>(smem);                                   // [NBP*32][TC] (+ band padding)
+  uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * TG::kBandFloats);    // [NBP][TC]
+  uint32_t *rsp = alive + NBP * TG::kBandWords;                                    // [NBP][TC]
+  // XF only: row records, one spare slot per band so that the bands of a half-wave read
+  // different banks ([33*NBP] x 16 B), then the table T ([sx+3] floats)
+  XRowMeta *xrec = reinterpret_cast<XRowMeta *>(rsp + NBP * TG::kBandWords);
+  float *xT = reinterpret_cast<float *>(xrec + 33 * NBP);
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int n = (int)g.n;
+  const int NB = (int)g.nbands;
+  int64_t tile_id = blockIdx.x;
+  if constexpr (CW <= 2) {
+    // 16-column tiles: tiles 2k and 2k+1 share their 128-byte lines.  Workgroup b runs on XCD b % 8
+    // (observed placement, used for speed only): give both halves of a pair to ONE XCD, back to
+    // back, so that the second half finds the lines in that XCD's L2.  (The grid is a multiple of 16.)
+    const int64_t x = tile_id & 7, j = tile_id >> 3;
+    if (!(dbg & 0x400)) tile_id = ((j >> 1) * 8 + x) * 2 + (j & 1);  // (diagnostics: bit 10 = plain order)
+    if (tile_id >= (int64_t)tiles_x * g.nouter) return;
+  }
+  const int64_t xt = tile_id % tiles_x, o = tile_id / tiles_x;
+  const int64_t x0 = xt * TC;
+  const int64_t st = g.stride;
+  float *Ftile = F + x0 + o * g.outer_stride;
+  const int cols_left = (int)(g.sx - x0);  // columns of this tile that exist
+
+  // cache policy of the tile fill: streaming (nt) for whole-line tiles; the 16-column tiles must leave
+  // their lines in L2 for the workgroup that takes the other half
+  constexpr int kLoadAux = CW <= 2 ? 0 : EDT_TILE_LOAD_AUX;
+  if constexpr (!XF) {
+    // ---- phase 0: the whole tile, HBM -> LDS --------------------------------------------
+    // one instruction = 64 lanes x G floats = 2*G rows of 128 B, all rows in one band
+    if (IO::kGran == 4 && aligned16) {
+      // (direct global->LDS loads: tools/tileprobe.hip shows the same fill through VGPRs 7 % faster in
+      // isolation, but inside this kernel it costs 0.035 ms -- the loading workgroup then competes
+      // for issue slots with the one that is computing on the same CU; measured and rejected)
+      for (int i = wave; i < IO::count(NBP, 4); i += W) {
+        const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+        if (row < n && gc < cols_left)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + gc),
+              (__attribute__((address_space(3))) void *)(tile + io_lds_word<CW, 4>(i, 0)), 16, 0, kLoadAux);
+      }
+    } else {
+      for (int i = wave; i < IO::count(NBP, 1); i += W) {
+        const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+        if (row < n && gc < cols_left)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(Ftile + (int64_t)row * st + gc),
+              (__attribute__((address_space(3))) void *)(tile + io_lds_word<CW, 1>(i, 0)), 4, 0, kLoadAux);
+      }
+    }
+  } else {
+    // ---- phase 0 (fused pass 1): the row records of this tile's chunk and the table T -> LDS ----
+    const XRowMeta *recs = static_cast<const XRowMeta *>(xf.meta) + ((int64_t)o * xf.nchunks + (x0 >> 6)) * n;
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) xrec[i + (i >> 5)] = recs[i];
+    for (int i = (int)threadIdx.x; i < xf.idx_inf + 1; i += (int)blockDim.x) xT[i] = xf.ttab[i];
+  }
+
+  Lane L;
+  L.tile = tile;
+  L.alive = alive;
+  L.rsp = rsp;
+  L.colc = wave * CW + (lane % CW);
+  L.band = lane / CW;
+  L.row0 = L.band * 32;
+  L.n = n;
+  L.w2 = (double)(w * w);  // fp32 product widened (src/edt.hpp:181, :258)
+  L.nzw = 0;
+  L.rsw = 0;
+  const bool active = L.colc < cols_left && L.band < NB;
+  if (active) {
+    const int64_t widx = (o * g.nbands + L.band) * g.sx + x0 + L.colc;
+    L.nzw = nzbits[widx];
+    L.rsw = rsbits[widx];
+  }
+  rsp[addr_word<CW>(L.colc, L.band)] = L.rsw;
+  scan_runs<CW>(L, lane);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- own rows -> registers ---------------------------------------------------------------
+  float f[32];
+  if constexpr (!XF) {
+    const float *own = tile + addr_tile<CW>(L.colc, L.row0);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) f[r] = own[r * TC];
+  } else {
+    // pass 1 rebuilt from the row records (edt_colwave_lane.h: xpass_value), published in the tile
+    // for the hull look-ups of the other lanes of this wave
+    float *own = tile + addr_tile<CW>(L.colc, L.row0);
+    const int h = (int)((x0 >> 5) & 1), cbase = (int)(x0 & ~(int64_t)63);
+    const XRowMeta *rec = xrec + L.row0 + L.band;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      float v = 0.0f;
+      if (L.row0 + r < n) v = xpass_value(rec[r], h, cbase, L.colc, xT, xf.idx_inf, xf.flim, (L.nzw >> r) & 1u);
+      f[r] = v;
+      own[r * TC] = v;
+    }
+    wave_sync();
+  }
+
+  // ---- phase 1 / 2 / 3 (wave-local) ----------------------------------------------------------
+  // (dbg: diagnostics only -- bit1 skips the hull build, bit2 the merges, bit3 the evaluation)
+  const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
+  Hull1 H;
+  if (dbg & 2) { H.aw = L.nzw; H.flat = 0; H.nb0 = H.nb1 = H.nb31 = 0.0; }
+  else H = phase1_hull<CW>(L, f, fprev);
+  uint32_t aw = H.aw;
+  const uint32_t flat = H.flat;
+  alive[addr_word<CW>(L.colc, L.band)] = aw;
+  wave_sync();
+  if (!(dbg & 4)) {
+    // the merge rounds change nothing for a wave whose band boundaries are all quiet
+    uint32_t prev_aw = __shfl_up(aw, CW), prev_rs = __shfl_up(L.rsw, CW);
+    const double prev_nb31 = __shfl_up(H.nb31, CW);
+    if (lane < CW) { prev_aw = 0; prev_rs = 0; }
+    const bool quiet = boundary_quiet(L, H, prev_aw, prev_rs, prev_nb31);
+    if (__ballot(!quiet) != 0ull || (dbg & 32)) {
+#pragma unroll
+      for (int half = 1; half < NBP; half <<= 1) {
+        phase2_merge<CW>(L, half);
+        wave_sync();
+      }
+    }
+  }
+  aw = alive[addr_word<CW>(L.colc, L.band)];
+  {
+    // self-owned rows need bit 31 of the band below and bit 0 of the band above
+    uint32_t prev31 = __shfl_up(aw >> 31, CW);
+    uint32_t next0 = __shfl_down((L.nzw & 1u) | ((L.rsw & 1u) << 1) | ((aw & 1u) << 2) | ((flat & 1u) << 3), CW);
+    if (lane < CW) prev31 = 0;
+    if (lane >= 64 - CW) next0 = 0;
+    L.own = own_mask(L.nzw, L.rsw, aw, flat, prev31, next0 & 1u, (next0 >> 1) & 1u, (next0 >> 2) & 1u,
+                     (next0 >> 3) & 1u);
+    if (dbg & 16) L.own = 0;  // diagnostics: no self-owned shortcut
+  }
+  if (!(dbg & 8)) phase3_eval<CW, BB>(L, aw, f, epi);
+  wave_sync();  // every lane of the wave is done reading the tile
+
+  // ---- results -> LDS (in place) -> HBM ------------------------------------------------------
+  {
+    float *own = tile + addr_tile<CW>(L.colc, L.row0);
+    if (!(dbg & 0x200)) {  // (diagnostics: bit 9 leaves the tile as it was loaded)
+#pragma unroll
+      for (int r = 0; r < 32; ++r) own[r * TC] = f[r];
+    }
+  }
+  __syncthreads();
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  if constexpr (SC) {
+    // Z-sharded path: the rows leave for the slab records of their destination (one look-up per
+    // band; a band never straddles two destinations).  Same granules as the in-place stores.
+    if (IO::kGran == 4 && aligned16) {
+      for (int i = wave; i < IO::count(NBP, 4); i += W) {
+        const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+        if (row < n && gc < cols_left) {
+          const int b = row >> 5;
+          float *dst = scatter->rows[b] + o * scatter->ostride[b] + (int64_t)(row & 31) * st + x0 + gc;
+          *reinterpret_cast<v4f *>(dst) = *reinterpret_cast<const v4f *>(tile + io_lds_word<CW, 4>(i, lane));
+        }
+      }
+    } else {
+      for (int i = wave; i < IO::count(NBP, 1); i += W) {
+        const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+        if (row < n && gc < cols_left) {
+          const int b = row >> 5;
+          scatter->rows[b][o * scatter->ostride[b] + (int64_t)(row & 31) * st + x0 + gc] =
+              tile[io_lds_word<CW, 1>(i, lane)];
+        }
+      }
+    }
+  } else if (IO::kGran == 4 && aligned16) {
+    for (int i = wave; i < IO::count(NBP, 4); i += W) {
+      const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+      if (row < n && gc < cols_left) {
+        const v4f v = *reinterpret_cast<const v4f *>(tile + io_lds_word<CW, 4>(i, lane));
+        EDT_TILE_STORE(reinterpret_cast<v4f *>(Ftile + (int64_t)row * st + gc), v);
+      }
+    }
+  } else {
+    for (int i = wave; i < IO::count(NBP, 1); i += W) {
+      const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+      if (row < n && gc < cols_left) Ftile[(int64_t)row * st + gc] = tile[io_lds_word<CW, 1>(i, lane)];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------
+template <int CW, bool BB, bool XF, bool SC>
+static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
+                           int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
+                           bool scatter_aligned) {
+  constexpr int NBP = 64 / CW;
+  using TG = edt_lane::TileGeom<CW>;
+  constexpr int TC = TG::kCols;
+  size_t lds = (size_t)NBP * TG::kBandFloats * sizeof(float) + 2 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
+  if (XF) lds += (size_t)33 * NBP * sizeof(edt_lane::XRowMeta) + (size_t)(xf.idx_inf + 1) * sizeof(float);
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF, SC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const int64_t tiles_x = ceil_div(g.sx, TC);
+  int64_t tiles = tiles_x * g.nouter;
+  if (tiles <= 0) return EDT_OK;
+  if (CW <= 2) tiles = ceil_div(tiles, 16) * 16;  // the pair-per-XCD mapping permutes blocks of 16
+  // 16-byte granules need 16-byte aligned rows; otherwise the tile moves float by float
+  const int aligned16 = (g.sx % 4) == 0 && (g.stride % 4) == 0 && (g.outer_stride % 4) == 0 &&
+                        (reinterpret_cast<uintptr_t>(F) % 16) == 0 && (scatter == nullptr || scatter_aligned);
+  if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF, SC>), dim3((unsigned)tiles), dim3(64 * TC / CW), lds, stream,
+                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), aligned16, xf, scatter);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+template <int CW, bool BB, bool XF>
+static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
+                           int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
+                           bool scatter_aligned) {
+  // the scattering epilogue (Z-sharded path) is a compile-time variant of the unfused kernel
+  if constexpr (!XF) {
+    if (scatter != nullptr)
+      return launch_wave_cbx_sc<CW, BB, false, true>(F, nz, rs, g, w, epi, xf, stream, scatter, scatter_aligned);
+  }
+  return launch_wave_cbx_sc<CW, BB, XF, false>(F, nz, rs, g, w, epi, xf, stream, nullptr, false);
+}
+
+template <int CW>
+int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
+                         int bb, int epi, const XFuse *xf, hipStream_t stream, const BandScatter *scatter,
+                         bool sc_al) {
+  // the border rule and the fused pass 1 are compile-time variants, the epilogue a run-time one
+  const XFuse none = {nullptr, nullptr, 0, 0, 0};
+  if (xf)
+    return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al)
+              : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al);
+  return bb ? launch_wave_cbx<CW, true, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al)
+            : launch_wave_cbx<CW, false, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al);
+}
+
+}  // namespace edt_amd

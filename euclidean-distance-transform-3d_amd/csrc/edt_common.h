@@ -63,10 +63,11 @@ struct AxisGeom {
 // the scan axis.  Every band lies inside one destination block, so a lane (= one band of one
 // column) needs a single look-up.
 struct BandScatter {
-  float *rows[32];      // where row 32*band of outer index 0, column 0 goes
-  uint32_t *bits[32];   // where the nz word of that band, outer index 0, column 0 goes
-  int64_t ostride[32];  // 4-byte elements between consecutive outer indices in that destination
-  int64_t plane[32];    // words between the nz and the zs plane of one outer index
+  static constexpr int kBands = 64;  // axes of up to 2048 rows
+  float *rows[kBands];      // where row 32*band of outer index 0, column 0 goes
+  uint32_t *bits[kBands];   // where the nz word of that band, outer index 0, column 0 goes
+  int64_t ostride[kBands];  // 4-byte elements between consecutive outer indices in that destination
+  int64_t plane[kBands];    // words between the nz and the zs plane of one outer index
 };
 
 // epilogue of the last pass (fused tofinite/toinfinite/sqrt: src/edt.hpp:39-53, :599-601)

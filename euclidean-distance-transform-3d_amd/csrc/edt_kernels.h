@@ -80,6 +80,16 @@ int launch_bits_transpose_yz(const uint32_t *nz_y, const uint32_t *zs_y, uint32_
 }  // namespace edt_amd
 
 namespace edt_amd {
+// Arguments of the fused pass 1 (XF kernels of edt_colwave_kernel.h): the per-row run records written by
+// k_row_records ([outer][chunk][row], 16 B each: edt_lane::XRowMeta), the table T of sequential fp32 sums
+// of wx, and its limits.
+struct XFuse {
+  const void *meta;
+  const float *ttab;
+  int nchunks;   // 64-voxel chunks per row
+  int idx_inf;   // index of the +inf entry of T (= sx + 2)
+  int flim;      // bit pattern of FLT_MAX (tofinite) or +inf
+};
 // ---- wave-autonomous LDS-tiled column pass: edt_colwave.hip -----------------------------------
 bool column_pass_wave_supported(const AxisGeom &g);
 // scatter != nullptr (device table): the rows are written to the slab records instead of F

@@ -100,7 +100,7 @@ int launch_bits_from_flags(const uint8_t *flags, uint32_t *nz, uint32_t *rs, con
 __global__ void k_pack_record_bits(const uint32_t *__restrict__ nz_y, const uint32_t *__restrict__ zs_y,
                                    BandScatter sc, BandScatter *__restrict__ d_table, int64_t sx,
                                    int64_t nby, int64_t szl) {
-  if (blockIdx.x == 0 && threadIdx.x < 32) {
+  if (blockIdx.x == 0 && threadIdx.x < BandScatter::kBands) {
     const int b = (int)threadIdx.x;
     d_table->rows[b] = sc.rows[b];
     d_table->bits[b] = sc.bits[b];

@@ -149,7 +149,7 @@ int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx
                            int64_t sy_local, int64_t sz, float wz, int flags,
                            void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* Slab records: the fast form of the same two phases (sx, sy, sz <= 1024; query with
+/* Slab records: the fast form of the same two phases (sx <= 1024, sy and sz <= 2048; query with
  * edt_hip_shard_records_supported, otherwise use the pair above).  The y axis is cut into `nparts`
  * destination ranges at multiples of 32 rows (y_splits[0] = 0 ... y_splits[nparts] = sy, HOST array).
  * For destination h and every xy-slice of the slab the XY phase writes ONE contiguous record of

@@ -102,26 +102,18 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   const int n = (int)g.n;
   const int NB = (int)g.nbands;
   int64_t tile_id = blockIdx.x;
-  if constexpr (CW <= 2) {
-    // 16-column tiles: tiles 2k and 2k+1 share their 128-byte lines.  Workgroup b runs on XCD b % 8
-    // (observed placement, used for speed only): give both halves of a pair to ONE XCD, back to
-    // back, so that the second half finds the lines in that XCD's L2.  (The grid is a multiple of 16.)
+  // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, used for speed only).  XCD x
+  // takes the outer indices congruent to x (mod 8) and walks all x-tiles of one outer index back to
+  // back, so the tiles that share DRAM pages (the rows of one slice in the Y pass are 2 KiB apart, a
+  // tile takes 128 bytes of each) are in flight together on one XCD: Y pass of 512^3 0.231 -> 0.214 ms
+  // in back-to-back A/B runs, and no more slow mode; the Z pass is indifferent.  For the 16-column
+  // tiles it also puts the two halves of every 128-byte line back to back on one XCD (the second
+  // half is an L2 hit).  The grid is rounded up to whole groups of 8 outer indices; debug bit 11
+  // restores the plain order.
+  if (!(dbg & 0x800)) {
     const int64_t x = tile_id & 7, j = tile_id >> 3;
-    if (!(dbg & 0x400)) tile_id = ((j >> 1) * 8 + x) * 2 + (j & 1);  // (diagnostics: bit 10 = plain order)
+    tile_id = ((j / tiles_x) * 8 + x) * tiles_x + (j % tiles_x);
     if (tile_id >= (int64_t)tiles_x * g.nouter) return;
-  }
-  if constexpr (CW > 2) {
-    // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, used for speed only).  XCD x
-    // takes the outer indices congruent to x (mod 8) and walks all x-tiles of one outer index back to
-    // back, so the tiles that share DRAM pages (the rows of one slice in the Y pass are 2 KiB apart, a
-    // tile takes 128 bytes of each) are in flight together on one XCD: Y pass of 512^3 0.231 -> 0.214 ms
-    // in back-to-back A/B runs, and no more slow mode; the Z pass is indifferent.  (The grid is rounded
-    // up to whole groups of 8 outer indices; debug bit 11 restores the plain order.)
-    if (!(dbg & 0x800)) {
-      const int64_t x = tile_id & 7, j = tile_id >> 3;
-      tile_id = ((j / tiles_x) * 8 + x) * tiles_x + (j % tiles_x);
-      if (tile_id >= (int64_t)tiles_x * g.nouter) return;
-    }
   }
   const int64_t xt = tile_id % tiles_x, o = tile_id / tiles_x;
   const int64_t x0 = xt * TC;
@@ -314,8 +306,7 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   const int64_t tiles_x = ceil_div(g.sx, TC);
   int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;
-  if (CW <= 2) tiles = ceil_div(tiles, 16) * 16;  // the pair-per-XCD mapping permutes blocks of 16
-  else if (!(debug_mode() & 0x800)) tiles = tiles_x * (ceil_div(g.nouter, 8) * 8);  // XCD-aware order
+  if (!(debug_mode() & 0x800)) tiles = tiles_x * (ceil_div(g.nouter, 8) * 8);  // XCD-aware order
   // 16-byte granules need 16-byte aligned rows; otherwise the tile moves float by float
   const int aligned16 = (g.sx % 4) == 0 && (g.stride % 4) == 0 && (g.outer_stride % 4) == 0 &&
                         (reinterpret_cast<uintptr_t>(F) % 16) == 0 && (scatter == nullptr || scatter_aligned);

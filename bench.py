@@ -111,13 +111,19 @@ def main():
 
     _lib.load()
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if os.environ.get("EDT_BENCH_ONE_GPU") == "1":  # dry run of the N > 1 leg: every rank on cuda:0 (with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     n = args.size
     if world > 1 or os.environ.get("EDT_BENCH_FORCE_SHARDED") == "1":  # (the env var: 1-rank dry run of the N > 1 leg)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("EDT_BENCH_BACKEND", "nccl")  # "gloo": dry run, transfers staged through the host
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         from edt import distributed as edist
         return edist.bench_main(args, rank, world, dev)
 

@@ -27,6 +27,11 @@
 
 #pragma clang fp contract(off)
 
+// cache policy of the result stores (experiment knob; 0 = default, 2 = nt)
+#ifndef EDT_ROW_STORE_AUX
+#define EDT_ROW_STORE_AUX 0
+#endif
+
 namespace edt_amd {
 
 namespace {
@@ -182,7 +187,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const int x = c * 64 + lane;
-          if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, 0);
+          if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, EDT_ROW_STORE_AUX);
         }
       }
       // ---- next row's loads (the last row reloads itself: those hits cost nothing) ---------------
@@ -249,7 +254,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int x = c * 64 + lane;
-        if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, 0);
+        if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, EDT_ROW_STORE_AUX);
       }
     }
 

@@ -124,6 +124,20 @@ class HipOps:
         return partial
 
 
+class _Transfers:
+    """Point-to-point transfers in flight (+ the copies that finish host-staged receives)."""
+
+    def __init__(self, reqs, post):
+        self.reqs, self.post = reqs, post
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
+        for dst, buf in self.post:
+            dst.copy_(buf)
+        self.reqs, self.post = [], []
+
+
 class ShardedEDT:
     """Distributed squared EDT of one volume of x-fastest extents ``(sx, sy, sz)``.
 
@@ -144,6 +158,7 @@ class ShardedEDT:
             raise ValueError("need at least one z-slice and one y-row per rank")
         self.zparts = balanced_partition(self.sz, self.world)
         self.ops = HipOps() if ops is None else ops
+        self._stage = dist.get_backend(group) == "gloo"   # device tensors travel through host copies
         words = -(-self.sy // 32)
         can = (records is not False and hasattr(self.ops, "xy_records") and words >= self.world
                and self.ops.records_supported(code, self.sx, self.sy, self.sz))
@@ -180,18 +195,33 @@ class ShardedEDT:
     def _global_rank(self, r):
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
+    def _p2p(self, sends, recvs):
+        """One group of point-to-point transfers: sends / recvs are lists of (tensor, peer rank).
+        A backend that cannot move device memory (gloo) is served through host copies -- slow, but it
+        lets the whole multi-process driver run with the real kernels on a single GPU (tests)."""
+        ops, post = [], []
+        for t, peer in sends:
+            buf = t.contiguous()
+            if self._stage and buf.is_cuda:
+                buf = buf.cpu()
+            ops.append(dist.P2POp(dist.isend, buf, self._global_rank(peer), self.group))
+        for t, peer in recvs:
+            buf = t
+            if self._stage and t.is_cuda:
+                buf = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+                post.append((t, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(peer), self.group))
+        return _Transfers(dist.batch_isend_irecv(ops) if ops else [], post)
+
     def _halo(self, labels):
         """One-slice label halo: receive the previous rank's last slice, send ours onward."""
-        ops, halo = [], None
+        sends, recvs, halo = [], [], None
         if self.rank + 1 < self.world:
-            ops.append(dist.P2POp(dist.isend, labels[-1].contiguous(), self._global_rank(self.rank + 1),
-                                  self.group))
+            sends.append((labels[-1], self.rank + 1))
         if self.rank > 0:
             halo = torch.empty_like(labels[0])
-            ops.append(dist.P2POp(dist.irecv, halo, self._global_rank(self.rank - 1), self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            recvs.append((halo, self.rank - 1))
+        self._p2p(sends, recvs).wait()
         return halo
 
     def _reshard(self, slab_list, to_y: bool):
@@ -202,7 +232,7 @@ class ShardedEDT:
         """
         ys, ye = self.yparts[self.rank]
         zs, ze = self.zparts[self.rank]
-        outs, ops, keep = [], [], []
+        outs, sends, recvs, keep = [], [], [], []
         for src in slab_list:
             if to_y:
                 dst = torch.empty((self.sz, ye - ys, self.sx), dtype=src.dtype, device=src.device)
@@ -224,22 +254,16 @@ class ShardedEDT:
                     else:
                         dst[:, hys:hye, :].copy_(send)
                     continue
-                send = send.contiguous()
-                keep.append(send)
-                ops.append(dist.P2POp(dist.isend, send, self._global_rank(h), self.group))
+                sends.append((send, h))
                 if to_y:
-                    ops.append(dist.P2POp(dist.irecv, recv, self._global_rank(h), self.group))
+                    recvs.append((recv, h))
                 else:
                     stage = torch.empty((ze - zs, hye - hys, self.sx), dtype=src.dtype, device=src.device)
                     keep.append((stage, dst, hys, hye))
-                    ops.append(dist.P2POp(dist.irecv, stage, self._global_rank(h), self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for item in keep:
-            if isinstance(item, tuple):
-                stage, dst, hys, hye = item
-                dst[:, hys:hye, :].copy_(stage)
+                    recvs.append((stage, h))
+        self._p2p(sends, recvs).wait()
+        for stage, dst, hys, hye in keep:
+            dst[:, hys:hye, :].copy_(stage)
         return outs
 
     def _chunk(self, r, k):
@@ -309,14 +333,8 @@ class ShardedEDT:
             outs = [empty if h == self.rank else recv[h] for h in range(self.world)]
             pending.append(dist.all_to_all(outs, ins, group=self.group, async_op=True))
         else:
-            p2p = []
-            for h in range(self.world):
-                if h == self.rank:
-                    continue
-                p2p.append(dist.P2POp(dist.isend, blocks[h], self._global_rank(h), self.group))
-                p2p.append(dist.P2POp(dist.irecv, recv[h], self._global_rank(h), self.group))
-            if p2p:
-                pending.extend(dist.batch_isend_irecv(p2p))
+            peers = [h for h in range(self.world) if h != self.rank]
+            pending.append(self._p2p([(blocks[h], h) for h in peers], [(recv[h], h) for h in peers]))
 
     # -- the pipeline -----------------------------------------------------------------------
     def run(self, labels, weights_xyz, black_border=False, sqrt=False, gather_back=False):

@@ -159,3 +159,30 @@ def test_shard_records_as_virtual_ranks(edt_gpu, oracle_port, world, chunks, sha
             outs.append(dst[h][:, :(ye - ys) * sx].reshape(sz, ye - ys, sx))
         got = torch.cat(outs, 1).cpu().numpy().T
         assert same(got, want), (world, shape, an, bb)
+
+
+def test_device_entry_point_is_graph_capturable(edt_gpu, oracle_port):
+    """edt_hip_edtsq_device only enqueues kernels on the caller's stream (no allocation, no synchronisation):
+    a whole transform can be captured into a hipGraph and replayed (launch-bound small volumes)."""
+    import torch
+    from edt import device
+
+    dev = torch.device("cuda", 0)
+    lab = voronoi_labels((96, 80, 72), nseeds=40, seed=4, upsample=4, membrane=0.04)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev)
+    out = torch.empty(t.shape, dtype=torch.float32, device=dev)
+    plan = device.Plan(lab.shape, 2, dev)
+    an = (6.0, 6.0, 30.0)
+    plan.run(t, an, black_border=False, out=out)  # warm-up: lazy code-object loads, function attributes
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            plan.run(t, an, black_border=False, out=out)
+    want = oracle_port.edtsq(lab, an, False)
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert same(out.cpu().numpy().T, want)

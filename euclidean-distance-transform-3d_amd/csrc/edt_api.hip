@@ -786,6 +786,48 @@ int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, in
   return launch_subtract(d_a, d_b, d_out, count, (hipStream_t)stream);
 }
 
+// Voxel-graph transform on device-resident data: workspace = [2x uint8 volume | its fp32 transform |
+// the ordinary workspace of the 2x volume]
+size_t edt_hip_voxel_graph_workspace_bytes(int ndim, int64_t sx, int64_t sy, int64_t sz) {
+  if (check_shape(EDT_U8, ndim, sx, sy, sz) != EDT_OK || ndim < 2) return 0;
+  if (sx == 0 || sy == 0 || sz == 0) return 256;
+  const int64_t X = 2 * sx, Y = 2 * sy, Z = (ndim == 3) ? 2 * sz : 1;
+  const size_t big = (size_t)(X * Y * Z);
+  return align_up(big, 256) + align_up(big * sizeof(float), 256) + edt_hip_workspace_bytes(EDT_U8, ndim, X, Y, Z) + 256;
+}
+
+int edt_hip_edtsq_voxel_graph_device(const void *d_labels, int dtype, const uint8_t *d_graph, int ndim,
+                                     int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
+                                     int flags, float *d_output, void *d_workspace, size_t workspace_bytes,
+                                     void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape(dtype, ndim, sx, sy, sz);
+  if (rc != EDT_OK) return rc;
+  if (ndim < 2) { set_error("voxel_graph needs a 2-D or 3-D volume"); return EDT_ERR_BAD_ARG; }
+  if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
+  if (!d_labels || !d_graph || !d_output) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
+  const size_t need = edt_hip_voxel_graph_workspace_bytes(ndim, sx, sy, sz);
+  if (!d_workspace || workspace_bytes < need) {
+    set_error("workspace too small: need " + std::to_string(need) + " bytes");
+    return EDT_ERR_BAD_ARG;
+  }
+  const int64_t X = 2 * sx, Y = 2 * sy, Z = (ndim == 3) ? 2 * sz : 1;
+  const size_t big = (size_t)(X * Y * Z);
+  Carver c(d_workspace);
+  uint8_t *d_big = c.take<uint8_t>(big);
+  float *d_bigdt = c.take<float>(big);
+  const size_t wbytes = edt_hip_workspace_bytes(EDT_U8, ndim, X, Y, Z);
+  void *d_ws = c.take<unsigned char>(wbytes);
+  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  rc = launch_vg_expand(dtype, d_labels, d_graph, d_big, sx, sy, sz, ndim, bb, stream);
+  if (rc != EDT_OK) return rc;
+  // half voxel size on the 2x grid (src/edt_voxel_graph.hpp:96-101, :189-193)
+  rc = run_device(d_big, EDT_U8, ndim, X, Y, Z, wx / 2, wy / 2, wz / 2, bb ? EDT_FLAG_BLACK_BORDER : 0,
+                  d_bigdt, d_ws, wbytes, stream);
+  if (rc != EDT_OK) return rc;
+  return launch_vg_gather(d_bigdt, d_output, sx, sy, sz, ndim, stream);
+}
+
 int edt_hip_select_label_device(const void *d_labels, int dtype, const float *d_dt, const void *key,
                                 float *d_out, int64_t count, void *stream) {
   if (count < 0 || dtype_size(dtype) == 0) { set_error("bad argument"); return EDT_ERR_BAD_ARG; }

@@ -128,6 +128,30 @@ def sdf(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tens
     return dt
 
 
+def edtsq_voxel_graph(labels: torch.Tensor, voxel_graph: torch.Tensor, anisotropy=None,
+                      black_border=False) -> torch.Tensor:
+    """Squared EDT with a voxel connectivity graph (reference: edt.edtsq(..., voxel_graph=g),
+    src/edt.pyx:736-845) on device tensors: a 2-D or 3-D labels tensor and a uint8 graph of the same shape
+    (C order; bit layout of the reference).  Everything stays in HBM (edt_hip_edtsq_voxel_graph_device)."""
+    if labels.dim() not in (2, 3) or voxel_graph.shape != labels.shape or voxel_graph.dtype != torch.uint8:
+        raise TypeError("voxel_graph needs a 2-D or 3-D volume and a uint8 graph of the same shape")
+    lib = _lib.load()
+    labels, voxel_graph = labels.contiguous(), voxel_graph.contiguous()
+    ndim = labels.dim()
+    an = (1.0,) * ndim if anisotropy is None else tuple(float(a) for a in anisotropy)
+    # a C-ordered tensor (z, y, x) is the x-fastest volume with extents and weights reversed
+    ext = tuple(labels.shape[::-1]) + (1,) * (3 - ndim)
+    w = an[::-1] + (1.0,) * (3 - ndim)
+    out = torch.empty(labels.shape, dtype=torch.float32, device=labels.device)
+    nbytes = lib.edt_hip_voxel_graph_workspace_bytes(ndim, ext[0], ext[1], ext[2])
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=labels.device)
+    _lib.check(lib.edt_hip_edtsq_voxel_graph_device(
+        ctypes.c_void_p(labels.data_ptr()), dtype_code(labels.dtype), ctypes.c_void_p(voxel_graph.data_ptr()),
+        ndim, ext[0], ext[1], ext[2], w[0], w[1], w[2], _lib.FLAG_BLACK_BORDER if black_border else 0,
+        ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr()))
+    return out
+
+
 _NP_OF_CODE = {_lib.U8: np.uint8, _lib.BOOL: np.uint8, _lib.U16: np.uint16, _lib.U32: np.uint32,
                _lib.U64: np.uint64, _lib.F32: np.float32, _lib.F64: np.float64}
 

@@ -183,6 +183,16 @@ int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, in
 int edt_hip_is_background_device(const void *d_labels, int dtype, uint8_t *d_mask, int64_t count,
                                  void *stream);
 
+/* pyedt::_edt2dsq_voxel_graph / _edt3dsq_voxel_graph (src/edt_voxel_graph.hpp:54-117, :120-214) on
+ * device-resident data: labels, graph (one byte per voxel, bits as in the host entry points above) and
+ * output live in HBM; enqueue-only on `stream`.  Scratch: edt_hip_voxel_graph_workspace_bytes (it holds the
+ * 2x uint8 volume, its fp32 transform and the ordinary workspace of that volume). */
+size_t edt_hip_voxel_graph_workspace_bytes(int ndim, int64_t sx, int64_t sy, int64_t sz);
+int edt_hip_edtsq_voxel_graph_device(const void *d_labels, int dtype, const uint8_t *d_graph, int ndim,
+                                     int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
+                                     int flags, float *d_output, void *d_workspace, size_t workspace_bytes,
+                                     void *stream);
+
 /* out[i] = (labels[i] == *key) ? dt[i] : 0 -- the image edt.each() yields for one label
  * (src/edt.pyx:950-994: zeros + transfer of the label's runs, src/edt_voxel_graph.hpp:290-310), as one
  * streaming kernel on device-resident data.  `key` is a HOST pointer to one value of the label dtype. */

@@ -249,3 +249,19 @@ def test_cpp_drop_in_header_on_gpu(edt_gpu, tmp_path):
     from test_abi import build_cpp_dropin
     res = subprocess.run([build_cpp_dropin(tmp_path)], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_device_resident_voxel_graph(edt_gpu):
+    """edt.device.edtsq_voxel_graph == the host entry point (which the golden vectors and the oracle pin)."""
+    import torch
+    from edt import device
+    rng = np.random.default_rng(12)
+    for shape, an, bb in (((37, 41, 29), (1.0, 2.0, 3.0), False), ((64, 48, 40), (6.0, 6.0, 30.0), True),
+                          ((70, 55), (2.0, 1.0), True), ((33, 128), (1.0, 1.0), False)):
+        lab = (rng.random(shape) < 0.7).astype(np.uint8) * rng.integers(1, 4, size=shape).astype(np.uint8)
+        g = rng.integers(0, 64, size=shape).astype(np.uint8)
+        g[rng.random(shape) < 0.6] = 0b00111111
+        want = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb, voxel_graph=g)
+        got = device.edtsq_voxel_graph(torch.from_numpy(lab).cuda(), torch.from_numpy(g).cuda(), anisotropy=an,
+                                       black_border=bb).cpu().numpy()
+        assert np.array_equal(got, want, equal_nan=True), (shape, an, bb)

@@ -63,11 +63,12 @@ __device__ __forceinline__ T buf_load(rsrc_t r, uint32_t voff, uint32_t soff) {
 }  // namespace
 
 // FULL: sx == 64*NC exactly, so no lane ever falls off the end of a row (no clamped offsets, no
-// store guards).  Every instruction counts here: measured on MI355X this kernel is bound by the
-// number of instructions a SIMD can issue (~1 per 4-5 cycles over all types, rocprofv3
-// SQ_ACTIVE_INST_ANY ~ 85 % of the kernel time), not by HBM and not by load latency -- hence the
-// wave-uniform fast paths below (a chunk without run starts, a chunk without background, a row
-// without any start) which skip whole groups of per-voxel and scalar instructions.
+// store guards).  The wave-uniform fast paths below (a chunk without run starts, a chunk without
+// background, a row without any start) skip whole groups of per-voxel and scalar instructions: they
+// brought the kernel from its instruction-issue limit (~1 instruction per SIMD per 4-5 cycles over
+// all types, SQ_ACTIVE_INST_ANY ~ 85 %) down to where it now sits on uint32 labels: 1.2 GB at
+// 4.8 TB/s, 88 % of a plain copy on the same box (DESIGN.md 4.1 has the two experiments that show
+// neither fewer VALU instructions nor 16-byte loads move it any further).
 // XCD-aware schedule (see the kernels): worth it when every XCD gets at least one y-band and z is
 // long enough to have neighbours in flight; returns 1 and rounds the grid to 8 workgroup columns.
 static int row_xcd_schedule(int64_t nby, int64_t sz, int64_t *blocks) {

@@ -202,10 +202,22 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   // ---- phase 1 / 2 / 3 (wave-local) ----------------------------------------------------------
   // (dbg: diagnostics only -- bit1 skips the hull build, bit2 the merges, bit3 the evaluation)
   const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
+  // All-flat shortcut (edt_colwave_lane.h: flat_word): a wave whose columns are flat wherever a run
+  // continues needs no hull at all -- every foreground row owns itself.  (debug bit 16 switches it off.)
+  bool all_flat = false;
+  const uint32_t fl0 = (dbg & 2) ? 0u : flat_word(L, f, fprev);
+  if (!(dbg & (2 | 16 | 0x10000))) {
+    const uint32_t need = L.nzw & ~(L.rsw | (L.band == 0 ? 1u : 0u));
+    all_flat = __ballot((fl0 & need) != need) == 0ull;
+  }
+  uint32_t aw = L.nzw;
+  if (all_flat) {
+    L.own = L.nzw;
+  } else {
   Hull1 H;
   if (dbg & 2) { H.aw = L.nzw; H.flat = 0; H.nb0 = H.nb1 = H.nb31 = 0.0; }
-  else H = phase1_hull<CW>(L, f, fprev);
-  uint32_t aw = H.aw;
+  else H = phase1_hull<CW>(L, f, fprev, fl0);
+  aw = H.aw;
   const uint32_t flat = H.flat;
   alive[addr_word<CW>(L.colc, L.band)] = aw;
   wave_sync();
@@ -234,6 +246,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
                      (next0 >> 3) & 1u);
     if (dbg & 16) L.own = 0;  // diagnostics: no self-owned shortcut
   }
+  }  // !all_flat
   if (!(dbg & 8)) phase3_eval<CW, BB>(L, aw, f, epi);
   wave_sync();  // every lane of the wave is done reading the tile
 

@@ -294,18 +294,39 @@ struct Hull1 {
   double nb0, nb1, nb31;  // crossing numerators num(r-1, r) of the band's rows 0, 1 and 31
 };
 
+// The flat bits alone (bit r: |F[r] - F[r-1]| <= w2, exact in fp64; row 0 against the last row of the
+// band below).  If EVERY foreground row of a column that continues a run is flat, every row of the run
+// owns itself: for rows p and j of one run, F[p] - F[j] is a sum of |p-j| steps of at most w2, hence
+// F[p] <= F[j] + w2*|p-j| <= F[j] + w2*(p-j)^2, i.e. no parabola of the run lies below the row's own
+// value -- the envelope is F itself and neither hulls nor merges nor a sweep are needed (the result
+// min(F, border) is what the reference rounds to, bit for bit: the own term is exact).  The kernel
+// tests that wave-wide (`need` = nzw & ~rsw) before it builds any hull.
+EDT_LANE uint32_t flat_word(const Lane &L, const float *f, float fprev) {
+  const double w2 = L.w2;
+  uint32_t fl = 0;  // built most-significant-row first, flipped at the end
+  double Fb = (double)f[0];
+  EDT_SHIFT_IN(fl, fabs(Fb - (double)fprev) <= w2);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int r = 1; r < 32; ++r) {
+    const double Fi = (double)f[r];
+    EDT_SHIFT_IN(fl, fabs(Fi - Fb) <= w2);
+    Fb = Fi;
+  }
+  return brev32(fl);
+}
+
 template <int CW>
-EDT_LANE Hull1 phase1_hull(const Lane &L, const float *f, float fprev) {
+EDT_LANE Hull1 phase1_hull(const Lane &L, const float *f, float fprev, uint32_t flat) {
   const uint32_t rs1 = L.rsw | 1u;  // the band's first row starts a (local) chain
   const uint32_t dis = ~L.nzw | rs1 | (rs1 << 1);
   const double w2 = L.w2, w2x2 = w2 + w2;
   uint32_t aw = L.nzw;
   double nab = -INFINITY, dab = 1.0;
   double Fb = (double)f[0];
-  // flat bit r: |F[r] - F[r-1]| <= w2 (exact in fp64).  Where that holds on both sides of an
-  // alive row, the row's own parabola is the envelope there (see own_mask).
-  uint32_t fl = 0;  // built most-significant-row first, flipped at the end
-  EDT_SHIFT_IN(fl, fabs(Fb - (double)fprev) <= w2);
+  // (`flat`, bit r: |F[r] - F[r-1]| <= w2, comes from flat_word: where it holds on both sides of an
+  // alive row, the row's own parabola is the envelope there, see own_mask)
   double c = w2 * (double)(2 * L.row0 - 1);  // w2*(2*row-1) for row = row0; exact, and so are its updates
   Hull1 H;
   H.nb0 = (Fb - (double)fprev) + c;
@@ -318,7 +339,6 @@ EDT_LANE Hull1 phase1_hull(const Lane &L, const float *f, float fprev) {
     c += w2x2;
     const double Fi = (double)f[r];
     const double t = Fi - Fb;
-    EDT_SHIFT_IN(fl, fabs(t) <= w2);
     double nbi = t + c;
     if (r == 1) H.nb1 = nbi;
     if (r == 31) H.nb31 = nbi;
@@ -357,7 +377,7 @@ EDT_LANE Hull1 phase1_hull(const Lane &L, const float *f, float fprev) {
     dab = dbi;
     Fb = Fi;
   }
-  H.flat = brev32(fl);
+  H.flat = flat;
   H.aw = aw;
   return H;
 }

@@ -120,17 +120,31 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
       if (Q.L.colc == colc && Q.L.band == band) return &Q;
     return nullptr;
   };
+  // the all-flat shortcut of the kernel: a wave whose columns are flat wherever a run continues builds no
+  // hulls at all -- every foreground row owns itself
+  std::vector<char> wave_flat((size_t)W, 1);
+  for (int wave = 0; wave < W; ++wave)
+    for (int lane = 0; lane < 64; ++lane) {
+      PerLane &P = lanes[(size_t)wave * 64 + lane];
+      PerLane *below = lane_of(P.L.colc, P.L.band - 1);
+      const uint32_t fl0 = flat_word(P.L, P.f, below ? below->f[31] : 0.0f);
+      const uint32_t need = P.L.nzw & ~(P.L.rsw | (P.L.band == 0 ? 1u : 0u));
+      if ((fl0 & need) != need) wave_flat[(size_t)wave] = 0;
+    }
+  auto flat_wave_of = [&](const PerLane &P) { return wave_flat[(size_t)(&P - &lanes[0]) / 64] != 0; };
   for (auto &P : lanes) {
+    if (flat_wave_of(P)) { P.aw = P.L.nzw; P.flat = 0; P.H = Hull1(); P.H.aw = P.aw; continue; }
     PerLane *below = lane_of(P.L.colc, P.L.band - 1);  // the kernel gets these through lane shuffles
     const float fprev = below ? below->f[31] : 0.0f;
     EMUL_LANE(P, lanes);
-    P.H = phase1_hull<CW>(P.L, P.f, fprev);
+    P.H = phase1_hull<CW>(P.L, P.f, fprev, flat_word(P.L, P.f, fprev));
     P.aw = P.H.aw;
     P.flat = P.H.flat;
     alive[addr_word<CW>(P.L.colc, P.L.band)] = P.aw;
   }
   // the merge rounds are skipped by a wave whose band boundaries are all quiet
   for (int wave = 0; wave < W; ++wave) {
+    if (wave_flat[(size_t)wave]) continue;
     bool all_quiet = true;
     for (int lane = 0; lane < 64; ++lane) {
       PerLane &P = lanes[(size_t)wave * 64 + lane];
@@ -145,8 +159,10 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
         phase2_merge<CW>(lanes[(size_t)wave * 64 + lane].L, half);
       }
   }
-  for (auto &P : lanes) P.aw = alive[addr_word<CW>(P.L.colc, P.L.band)];
+  for (auto &P : lanes)
+    if (!flat_wave_of(P)) P.aw = alive[addr_word<CW>(P.L.colc, P.L.band)];
   for (auto &P : lanes) {
+    if (flat_wave_of(P)) { P.L.own = P.L.nzw; continue; }
     PerLane *below = lane_of(P.L.colc, P.L.band - 1), *above = lane_of(P.L.colc, P.L.band + 1);
     P.L.own = own_mask(P.L.nzw, P.L.rsw, P.aw, P.flat, below ? below->aw >> 31 : 0u,
                        above ? above->L.nzw & 1u : 0u, above ? above->L.rsw & 1u : 0u,

@@ -19,6 +19,10 @@ __global__ void __launch_bounds__(THREADS) k_tile(float *F, size_t sx, int n, in
     const int x = b & 7, j = b >> 3;
     b = ((j >> 1) * 8 + x) * 2 + (j & 1);
   }
+  if (MAP == 2) {  // XCD x walks the outer indices congruent to x (mod 8), all x-tiles of one back to back
+    const int x = b & 7, j = b >> 3;
+    b = ((j / tiles_x) * 8 + x) * tiles_x + (j % tiles_x);
+  }
   const int xt = b % tiles_x, o = b / tiles_x;
   float *base = F + (size_t)o * ostride + (size_t)xt * TC;  // rows are sx floats apart
   const int g = threadIdx.x % GPR, r0 = threadIdx.x / GPR;
@@ -86,6 +90,17 @@ int main() {
       timeit(k_tile<32, 512, 0, 0>, dim3(cols / 32 * nouter), dim3(512), (size_t)n * 128 + 4096, F, rz, n, cols / 32, 0, oz),
       timeit(k_tile<32, 512, 0, 1>, dim3(cols / 32 * nouter), dim3(512), (size_t)n * 128 + 4096, F, rz, n, cols / 32, 0, oz),
       timeit(k_tile<32, 512, 0, 2>, dim3(cols / 32 * nouter), dim3(512), (size_t)n * 128 + 4096, F, rz, n, cols / 32, 0, oz));
+  }
+  // 512-row axis with the XCD-aware order of the library: 32-column tiles (2 workgroups per CU) against
+  // 16-column tiles (4 per CU), without and with a compute phase
+  {
+    const size_t rs = 512, os = (size_t)512 * 512; const int n = 512, nouter = 512, cols = 512;
+    printf("512-row axis (y pass of 512^3), XCD-aware order\n");
+    for (int delay : {0, 8, 16}) {
+      printf("  delay %2d: 32-col %.3f ms   16-col %.3f ms\n", delay,
+        timeit(k_tile<32, 512, 2, 1>, dim3(cols / 32 * nouter), dim3(512), (size_t)n * 128 + 4096, F, rs, n, cols / 32, delay, os),
+        timeit(k_tile<16, 256, 2, 1>, dim3(cols / 16 * nouter), dim3(256), (size_t)n * 64 + 2048, F, rs, n, cols / 16, delay / 2, os));
+    }
   }
   return 0;
 }

@@ -13,7 +13,12 @@
 namespace edt_amd {
 
 static thread_local std::string g_last_error = "";
-static int g_debug_mode = 0;
+// diagnostics bit mask (edt_hip_set_debug_mode); EDT_HIP_DEBUG_MODE presets it, e.g. 0x4000 = every tile
+// of the wave column pass takes the windowed path, 0x2000 = none does
+static int g_debug_mode = [] {
+  const char *e = std::getenv("EDT_HIP_DEBUG_MODE");
+  return e ? (int)std::strtol(e, nullptr, 0) : 0;
+}();
 
 void set_error(const std::string &msg) { g_last_error = msg; }
 int debug_mode() { return g_debug_mode; }

@@ -4,6 +4,8 @@
 #include "edt_common.h"
 #include "edt_kernels.h"
 
+#include <cstdlib>
+
 namespace edt_amd {
 
 template <int CW>
@@ -15,6 +17,28 @@ extern template int launch_wave_c<8>(float *, const uint32_t *, const uint32_t *
 extern template int launch_wave_c<4>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool);
 extern template int launch_wave_c<2>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool);
 extern template int launch_wave_c<1>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool);
+
+// Largest window of the windowed path (edt_colwave_lane.h: brute_band): a tile takes it when no row can be
+// improved by a row further than this away.  EDT_HIP_WINDOW_LIMIT overrides the default (experiments).
+int window_limit() {
+  static const int v = [] {
+    const char *e = getenv("EDT_HIP_WINDOW_LIMIT");
+    const int t = e ? atoi(e) : 96;
+    return t < 0 ? 0 : (t > 1024 ? 1024 : t);
+  }();
+  return v;
+}
+
+// A tile takes the windowed path only if at least 1/window_flat_div() of its run-continuing rows are not
+// flat (EDT_HIP_WINDOW_FLATDIV overrides; 65536 = flatness is not looked at).
+int window_flat_div() {
+  static const int v = [] {
+    const char *e = getenv("EDT_HIP_WINDOW_FLATDIV");
+    const int t = e ? atoi(e) : 8;
+    return t < 1 ? 1 : (t > 0x10000 ? 0x10000 : t);
+  }();
+  return v;
+}
 
 bool column_pass_wave_supported(const AxisGeom &g) {
   // rows in VGPRs: one band per lane, at most 64 bands per column (n <= 2048)

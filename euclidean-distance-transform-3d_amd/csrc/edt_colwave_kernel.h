@@ -46,6 +46,16 @@
 
 namespace edt_amd {
 
+// arguments of the windowed path of the column kernel
+struct BruteArgs {
+  uint32_t limit_bits;  // a tile takes the path when the bit pattern of its largest field value is <= this; 0 = never
+  int x32;              // candidates are fp32 sums (c_d exactly representable up to the limit)
+  int flat_div;         // ... and when at least 1/flat_div of its run-continuing rows are not flat (0x10000: always)
+  edt_lane::BruteTab tab;
+};
+int window_limit();     // edt_colwave.hip: largest window (rows) the windowed path is used for
+int window_flat_div();  // edt_colwave.hip: ... and the flatness bound of the tile choice
+
 namespace {
 
 __device__ __forceinline__ void wave_sync() {
@@ -81,7 +91,8 @@ template <int CW, bool BB, bool XF, bool SC>
 __global__ void __launch_bounds__(64 * edt_lane::TileGeom<CW>::kCols / CW, 4)
 k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
                    const uint32_t *__restrict__ rsbits, AxisGeom g, float w, int tiles_x,
-                   int epi, int dbg, int aligned16, XFuse xf, const BandScatter *__restrict__ scatter) {
+                   int epi, int dbg, int aligned16, XFuse xf, const BandScatter *__restrict__ scatter,
+                   BruteArgs ba) {
   using namespace edt_lane;
   constexpr int NBP = 64 / CW;  // bands per column handled by a wave (power of two)
   using TG = TileGeom<CW>;
@@ -89,12 +100,17 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   constexpr int W = TC / CW;     // waves per workgroup
   using IO = TileIO<CW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *tile = reinterpret_cast<float *>(smem);                                   // [NBP*32][TC] (+ band padding)
-  uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * TG::kBandFloats);    // [NBP][TC]
+  // LDS image: [one band of padding][the tile: NBP bands][one band of padding][alive][rsp][lohi][1 word]; the
+  // padding bands hold +inf for the windowed path (edt_colwave_lane.h: brute_band), the XF kernels have none
+  constexpr int kPad = XF ? 0 : TG::kBandFloats;
+  float *tile = reinterpret_cast<float *>(smem) + kPad;                            // [NBP*32][TC] (+ band padding)
+  uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * TG::kBandFloats + kPad);  // [NBP][TC]
   uint32_t *rsp = alive + NBP * TG::kBandWords;                                    // [NBP][TC]
+  uint32_t *lohi = rsp + NBP * TG::kBandWords;     // [NBP][TC]: (lo_in + 1) | (hi_out + 1) << 16 (windowed path)
+  uint32_t *tmax = lohi + (XF ? 0 : NBP * TG::kBandWords);  // 1 word: largest field value of the tile
   // XF only: row records, one spare slot per band so that the bands of a half-wave read
   // different banks ([33*NBP] x 16 B), then the table T ([sx+3] floats)
-  XRowMeta *xrec = reinterpret_cast<XRowMeta *>(rsp + NBP * TG::kBandWords);
+  XRowMeta *xrec = reinterpret_cast<XRowMeta *>(tmax + 4);
   float *xT = reinterpret_cast<float *>(xrec + 33 * NBP);
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -173,6 +189,12 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   }
   rsp[addr_word<CW>(L.colc, L.band)] = L.rsw;
   scan_runs<CW>(L, lane);
+  if constexpr (!XF) {
+    // the rows that complete the last band are not part of the column: 0 for the tile maximum below
+    for (int i = (int)threadIdx.x; i < (NB * 32 - n) * TC; i += (int)blockDim.x)
+      tile[addr_tile<CW>(i % TC, n + i / TC)] = 0.0f;
+    if (threadIdx.x < 2) tmax[threadIdx.x] = 0u;
+  }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -199,17 +221,80 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     wave_sync();
   }
 
+  // ---- tiles whose field is small everywhere, and not flat, take the windowed path ---------------------
+  // (a flat field -- large objects away from their boundaries -- would mean large windows where the hull
+  // path has nothing to do at all: every row owns itself)
+  const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
+  const uint32_t fl0 = (dbg & 2) ? 0u : flat_word(L, f, fprev);
+  const uint32_t need = L.nzw & ~(L.rsw | (L.band == 0 ? 1u : 0u));  // rows that continue a run
+  if constexpr (!XF) {
+    if (ba.limit_bits != 0u) {  // (wave-uniform: kernel argument)
+      uint32_t fm = 0;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) fm = max(fm, __float_as_uint(f[r]));  // non-negative floats order like ints
+      if (!active) fm = 0;
+      // tmax[0]: largest field value; tmax[1]: run-continuing rows; tmax[2]: those that are not flat
+      int cnt = (int)__popc(need) | ((int)__popc(need & ~fl0) << 16);
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        fm = max(fm, (uint32_t)__shfl_xor((int)fm, d));
+        cnt += __shfl_xor(cnt, d);
+      }
+      if (lane == 0) {
+        atomicMax(tmax, fm);
+        atomicAdd(tmax + 1, (uint32_t)cnt);
+      }
+      alive[addr_word<CW>(L.colc, L.band)] = L.nzw;
+      lohi[addr_word<CW>(L.colc, L.band)] = (uint32_t)(L.lo_in + 1) | ((uint32_t)(L.hi_out + 1) << 16);
+      __syncthreads();
+      const uint32_t cnts = tmax[1];
+      if (tmax[0] <= ba.limit_bits &&
+          (ba.flat_div == 0x10000 || (cnts >> 16) * (uint32_t)ba.flat_div > (cnts & 0xFFFFu))) {
+        // +inf around the columns: the padding bands and the rows that complete the last band
+        for (int i = (int)threadIdx.x; i < 32 * TC; i += (int)blockDim.x)
+          tile[addr_tile<CW>(i % TC, -32 + i / TC)] = INFINITY;
+        for (int i = (int)threadIdx.x; i < ((NB + 1) * 32 - n) * TC; i += (int)blockDim.x)
+          tile[addr_tile<CW>(i % TC, n + i / TC)] = INFINITY;
+        __syncthreads();
+        BruteLane BL;
+        BL.tile = tile;
+        BL.col = lane % TC;
+        BL.band = wave * (64 / TC) + lane / TC;
+        BL.row0 = BL.band * 32;
+        BL.n = n;
+        BL.nzw = alive[addr_word<CW>(BL.col, BL.band)];
+        BL.rsw = rsp[addr_word<CW>(BL.col, BL.band)];
+        const uint32_t lh = lohi[addr_word<CW>(BL.col, BL.band)];
+        BL.lo_in = (int)(lh & 0xFFFFu) - 1;
+        BL.hi_out = (int)(lh >> 16) - 1;
+        BL.w2 = L.w2;
+        BL.w2f = w * w;
+        const bool colok = BL.col < cols_left;
+        float *dst0;        // row 0 of this band's rows, this lane's column
+        int64_t dstride;
+        if constexpr (SC) {
+          const int b = BL.band < BandScatter::kBands ? BL.band : 0;
+          dst0 = scatter->rows[b] + o * scatter->ostride[b] + x0 + BL.col - (int64_t)BL.row0 * st;
+        } else {
+          dst0 = Ftile + BL.col;
+        }
+        dstride = st;
+        auto store = [&](int row, float v) {
+          if (row < n && colok) dst0[(int64_t)row * dstride] = v;
+        };
+        if (ba.x32) brute_band<CW, BB, true>(BL, ba.tab, epi, store);
+        else brute_band<CW, BB, false>(BL, ba.tab, epi, store);
+        return;
+      }
+    }
+  }
+
   // ---- phase 1 / 2 / 3 (wave-local) ----------------------------------------------------------
   // (dbg: diagnostics only -- bit1 skips the hull build, bit2 the merges, bit3 the evaluation)
-  const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
   // All-flat shortcut (edt_colwave_lane.h: flat_word): a wave whose columns are flat wherever a run
   // continues needs no hull at all -- every foreground row owns itself.  (debug bit 16 switches it off.)
   bool all_flat = false;
-  const uint32_t fl0 = (dbg & 2) ? 0u : flat_word(L, f, fprev);
-  if (!(dbg & (2 | 16 | 0x10000))) {
-    const uint32_t need = L.nzw & ~(L.rsw | (L.band == 0 ? 1u : 0u));
-    all_flat = __ballot((fl0 & need) != need) == 0ull;
-  }
+  if (!(dbg & (2 | 16 | 0x10000))) all_flat = __ballot((fl0 & need) != need) == 0ull;
   uint32_t aw = L.nzw;
   if (all_flat) {
     L.own = L.nzw;
@@ -308,8 +393,28 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   constexpr int NBP = 64 / CW;
   using TG = edt_lane::TileGeom<CW>;
   constexpr int TC = TG::kCols;
-  size_t lds = (size_t)NBP * TG::kBandFloats * sizeof(float) + 2 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
+  size_t lds = (size_t)NBP * TG::kBandFloats * sizeof(float) + 2 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t) + 16;
   if (XF) lds += (size_t)33 * NBP * sizeof(edt_lane::XRowMeta) + (size_t)(xf.idx_inf + 1) * sizeof(float);
+  else lds += 2 * (size_t)TG::kBandFloats * sizeof(float) + (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
+  // the windowed path (edt_colwave_lane.h: brute_band): tiles whose largest field value is at most c_T
+  BruteArgs ba;
+  ba.limit_bits = 0u;
+  ba.x32 = 0;
+  if (!XF && !(debug_mode() & 0x2000) && w > 0.0f && (double)w * (double)w < 1.0e30) {
+    const bool force = (debug_mode() & 0x4000) != 0;
+    const int T = force ? (int)g.n : window_limit();
+    bool x32 = edt_lane::brute_tab_fill(ba.tab, w, T);
+    if (debug_mode() & 0x8000) x32 = false;  // diagnostics: fp64 candidates
+    ba.x32 = x32 ? 1 : 0;
+    const double cT = (double)(w * w) * (double)T * (double)T;
+    float lim = cT < 3.0e38 ? (float)cT : 3.0e38f;
+    if ((double)lim > cT) lim = nextafterf(lim, 0.0f);
+    uint32_t bits;
+    memcpy(&bits, &lim, 4);
+    ba.limit_bits = force ? 0x7f800000u : bits;  // (forced: every tile, whatever it holds)
+    ba.flat_div = force ? 0x10000 : window_flat_div();
+    if (T < 1) ba.limit_bits = 0u;
+  }
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF, SC>),
@@ -325,7 +430,7 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
                         (reinterpret_cast<uintptr_t>(F) % 16) == 0 && (scatter == nullptr || scatter_aligned);
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF, SC>), dim3((unsigned)tiles), dim3(64 * TC / CW), lds, stream,
-                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), aligned16, xf, scatter);
+                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), aligned16, xf, scatter, ba);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }

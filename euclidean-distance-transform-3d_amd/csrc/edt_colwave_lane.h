@@ -678,4 +678,212 @@ EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f, int epi) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The windowed path ("brute"): tiles whose field is small everywhere (many small label runs:
+// dense segmentations) do not build hulls at all.
+//
+// For a foreground row p of the run [a,b] let  B_p = min(F[p], border parabolas)  (the row's own
+// parabola and the two parabolas of height 0 just outside the run, src/edt.hpp:233-242, :310-311).
+// A row j at distance d = |p-j| can only lower the result if  c_d = w2*d^2 < B_p;  such a row lies
+// inside the run (d is smaller than the distance to either border site), and for ANY row j of the
+// column  c_d + F[j] >= c_d >= B_p  otherwise, because F >= 0.  Hence
+//     result[p] = fl32( min( B_p,  min_{1<=d<=R} ( c_d + min(F[p-d], F[p+d]) ) ) )
+// for every R with c_{R+1} >= B_p, with NO label test inside the window: rows of other runs, rows
+// beyond a border and the +inf rows around the tile are harmless candidates.  (fl32 is monotone,
+// so rounding commutes with the min; c_d is exact in fp64.)
+//
+// Mapping: lane = one column, a (64/TC)-th of a wave = the 32 rows of one band, processed as four
+// blocks of 8 rows.  The rows p-R..p+R of a block live in a register window that grows by two LDS
+// reads per step d; a step costs three (fp32) or four (fp64) vector instructions per row, and the
+// loop ends for the whole wave as soon as c_d >= B_p for all of its rows -- adjacent columns share
+// their borders and have similar fields, so the wave-wide window is close to the per-row one
+// (dense 512^3 segmentation: mean window 8 rows per voxel, 15-20 per wave step).
+// Every lane executes the same instructions: no pops, no bridge walks, no per-lane searches.
+//
+// Arithmetic: when c_d is exactly representable in fp32 for every d the path may use (X32; true
+// for anisotropies like 1, 6, 30, 0.5, checked on the host), fl32(fl64(c_d + F)) equals the fp32
+// sum (double rounding is innocuous for sums when the wide format has >= 2p+2 bits), so a
+// candidate is ONE v_add_f32.  Otherwise candidates are formed in fp64 exactly as in the hull path.
+// Non-negative floats order like their bit patterns, so minima of raw LDS values are integer minima.
+// ---------------------------------------------------------------------------------------
+constexpr int kBruteK = 32;  // register window radius = the rows of +inf padding on either side of the tile
+constexpr int kBruteB = 8;   // rows per block
+
+struct BruteTab {
+  float c32[kBruteK + 1];   // c_d rounded towards zero to fp32 (exact when x32): exit test, X32 candidates
+  double c64[kBruteK + 1];  // c_d = w2 * d^2, exact
+};
+
+struct BruteLane {
+  const float *tile;  // LDS tile, row 0 (one band of +inf rows on either side; rows >= n are +inf)
+  int col;            // column inside the workgroup tile
+  int band, row0, n;
+  uint32_t nzw, rsw;  // foreground / run-start bits of the band (0 for a lane without a column)
+  int lo_in, hi_out;  // as in Lane
+  double w2;
+  float w2f;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EDT_ANY(cond) (__ballot(cond) != 0ull)
+#else
+#define EDT_ANY(cond) (cond)
+#endif
+
+EDT_LANE uint32_t f2u(float v) { uint32_t u; memcpy(&u, &v, 4); return u; }
+EDT_LANE float u2f(uint32_t u) { float v; memcpy(&v, &u, 4); return v; }
+EDT_LANE float minpos(float a, float b) {  // min of two non-negative floats (or +inf), no NaN handling
+  const uint32_t ua = f2u(a), ub = f2u(b);
+  return u2f(ua < ub ? ua : ub);
+}
+
+template <int CW, bool BB, bool X32, class Store>
+EDT_LANE void brute_band(const BruteLane &L, const BruteTab &tab, int epi, Store &&store) {
+  constexpr int K = kBruteK, B = kBruteB, TC = TileGeom<CW>::kCols;
+  constexpr int kFar = 1 << 14;
+  const int row0 = L.row0, n = L.n;
+  const uint32_t rsw = L.rsw, nzw = L.nzw;
+  // the lane's column in its own band and in the bands below / above (the band rotation of the tile
+  // differs from band to band; inside a band rows are TC floats apart)
+  const float *A0 = L.tile + addr_tile<CW>(L.col, row0);
+  const float *Am = L.tile + addr_tile<CW>(L.col, row0 - 32);
+  const float *Ap = L.tile + addr_tile<CW>(L.col, row0 + 32);
+  const int nb32 = ((n + 31) >> 5) << 5;  // rows of the tile incl. the +inf rows that complete the last band
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int k0 = 0; k0 < 32; k0 += B) {
+    float w[B + 2 * K];  // w[K + i] = F(row0 + k0 + i); the window grows by one row per side and step
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < B; ++i) w[K + i] = A0[(k0 + i) * TC];
+    // rows below k0 come from this band while d <= k0, from the band below afterwards; likewise above
+    const float *PL0 = A0 + (k0 - K) * TC, *PL1 = Am + (k0 + 32 - K) * TC;
+    const float *PH0 = A0 + (k0 + B - 1) * TC, *PH1 = Ap + (k0 + B - 1 - 32) * TC;
+    // ---- B_p of the block's rows ----
+    int a;  // first row of the run the current row belongs to
+    {
+      const uint32_t m = rsw & ((1u << k0) - 1u);
+      a = m ? row0 + 31 - clz32(m) : L.lo_in;
+    }
+    int dlv[B];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < B; ++i) {
+      const int row = row0 + k0 + i;
+      if ((rsw >> (k0 + i)) & 1u) a = row;
+      dlv[i] = (BB || a > 0) ? row - a + 1 : kFar;
+    }
+    int e;  // first row of the next run
+    {
+      const uint32_t m = k0 + B < 32 ? rsw & (0xFFFFFFFFu << (k0 + B)) : 0u;
+      e = m ? row0 + ctz32(m) : L.hi_out + 1;
+    }
+    float best[B];
+    double best64[B];
+    uint32_t bmax = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = B - 1; i >= 0; --i) {
+      const int row = row0 + k0 + i;
+      const int drv = (BB || e < n) ? e - row : kFar;
+      const int dmi = dlv[i] < drv ? dlv[i] : drv;
+      const float dm = (float)dmi;
+      // fl32(w2 * d^2) is one exact-product fp32 multiply (as in phase3_eval)
+      const float bord = dmi < kFar ? L.w2f * (dm * dm) : INFINITY;
+      float b = minpos(w[K + i], bord);
+      if (!((nzw >> (k0 + i)) & 1u)) b = 0.0f;
+      best[i] = b;
+      if (!X32) best64[i] = (double)b;
+      const uint32_t ub = f2u(b);
+      bmax = ub > bmax ? ub : bmax;
+      if ((rsw >> (k0 + i)) & 1u) e = row;
+    }
+    const float bmaxf = u2f(bmax);
+    // ---- the window, unrolled over the register-resident part ----
+    bool open = true;  // some row of the wave may still improve
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int d = 1; d <= K; ++d) {
+      if (!EDT_ANY(tab.c32[d] < bmaxf)) { open = false; break; }
+      // the two rows that enter the window in this step are needed by the first and the last row of the
+      // block only: those come last, the six rows in between cover the latency of the two reads
+      w[K - d] = (d <= k0 ? PL0 : PL1)[(K - d) * TC];
+      w[K + B - 1 + d] = (d <= 32 - B - k0 ? PH0 : PH1)[d * TC];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int ii = 0; ii < B; ++ii) {
+        const int i = ii < B - 2 ? ii + 1 : (ii == B - 2 ? 0 : B - 1);
+        const float m = minpos(w[K + i - d], w[K + i + d]);
+        // (sums of non-negative terms: integer min again, no canonicalisation of the operands)
+        if (X32) best[i] = minpos(best[i], m + tab.c32[d]);
+        else best64[i] = fmin(best64[i], (double)m + tab.c64[d]);
+      }
+    }
+    // ---- windows beyond the register-resident part (rare): straight from the tile ----
+    if (open) {
+      for (int d = K + 1; d < 4096; ++d) {
+        const double cd = L.w2 * (double)(d * d);  // exact
+        const float cdf = X32 ? (float)cd : u2f(f2u((float)cd) - 1u);  // (not above c_d)
+        if (!EDT_ANY(cdf < bmaxf)) break;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < B; ++i) {
+          int rl = row0 + k0 + i - d, rh = row0 + k0 + i + d;
+          rl = rl < -1 ? -1 : rl;        // row -1 and row nb32 are +inf rows
+          rh = rh > nb32 ? nb32 : rh;
+          const float m = minpos(L.tile[addr_tile<CW>(L.col, rl)], L.tile[addr_tile<CW>(L.col, rh)]);
+          if (X32) best[i] = minpos(best[i], m + cdf);
+          else best64[i] = fmin(best64[i], (double)m + cd);
+        }
+      }
+    }
+    // ---- epilogue (src/edt.hpp:47-53, :599-601) and the rows leave ----
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < B; ++i) {
+      float r = X32 ? best[i] : (float)best64[i];
+      if ((epi & kLaneEpiToInf) && r >= 3.402823466e+38f) r = INFINITY;
+      best[i] = r;
+    }
+    if (epi & kLaneEpiSqrt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int i = 0; i < B; ++i) best[i] = sqrtf(best[i]);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < B; ++i) store(row0 + k0 + i, best[i]);
+  }
+}
+
+// c_d tables of the windowed path and the largest window it may use: `x32` reports whether every c_d
+// up to `want` is exactly representable in fp32 (then candidates are fp32 sums)
+inline bool brute_tab_fill(BruteTab &t, float w, int want) {
+  const double w2 = (double)(w * w);
+  bool x32 = true;
+  for (int d = 1; d <= want; ++d) {
+    const double c = w2 * (double)d * (double)d;
+    if ((double)(float)c != c || !(c < 3.0e38)) x32 = false;
+  }
+  for (int d = 0; d <= kBruteK; ++d) {
+    const double c = w2 * (double)d * (double)d;
+    float f = c < 3.0e38 ? (float)c : 3.0e38f;
+    if ((double)f > c) f = nextafterf(f, 0.0f);
+    t.c32[d] = f;
+    t.c64[d] = c;
+  }
+  return x32;
+}
+
 }  // namespace edt_lane

@@ -32,13 +32,15 @@ namespace {
 template <int CW, bool BB>
 void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t sx, int n, int NB,
                int64_t stride, int64_t x0, float w, int epi, const XRowMeta *meta = nullptr,
-               const float *Ttab = nullptr, int idx_inf = 0, int flim = 0) {
+               const float *Ttab = nullptr, int idx_inf = 0, int flim = 0, int mode = 0) {
   constexpr int NBP = 64 / CW;
   using TG = TileGeom<CW>;
   constexpr int TC = TG::kCols;
   constexpr int W = TC / CW;
   using IO = TileIO<CW>;
-  std::vector<float> tile((size_t)NBP * TG::kBandFloats, -12345.0f);
+  // [one band of padding][the tile][one band of padding], as in the kernel's LDS image
+  std::vector<float> tilebuf((size_t)(NBP + 2) * TG::kBandFloats, -12345.0f);
+  float *const tile = tilebuf.data() + TG::kBandFloats;
   std::vector<uint32_t> alive((size_t)NBP * TG::kBandWords, 0), rsp((size_t)NBP * TG::kBandWords, 0);
   const int cols_left = (int)(sx - x0);
   // phase 0: the swizzled fill, exactly as the kernel addresses it (16-byte granules when the rows
@@ -65,7 +67,7 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
     for (int lane = 0; lane < 64; ++lane) {
       PerLane &P = lanes[(size_t)wave * 64 + lane];
       Lane &L = P.L;
-      L.tile = tile.data(); L.alive = alive.data(); L.rsp = rsp.data();
+      L.tile = tile; L.alive = alive.data(); L.rsp = rsp.data();
       L.colc = wave * CW + (lane % CW);
       L.band = lane / CW;
       L.row0 = L.band * 32;
@@ -98,7 +100,7 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
     // fused pass 1: every lane rebuilds F for its rows from the row records, then publishes them
     // in the LDS tile (the kernel does exactly this instead of the HBM fill)
     for (auto &P : lanes) {
-      float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
+      float *own = tile + addr_tile<CW>(P.L.colc, P.L.row0);
       for (int r = 0; r < 32; ++r) {
         const int row = P.L.row0 + r;
         float v = 0.0f;
@@ -111,8 +113,50 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
     }
   } else {
     for (auto &P : lanes) {
-      const float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
+      const float *own = tile + addr_tile<CW>(P.L.colc, P.L.row0);
       for (int r = 0; r < 32; ++r) P.f[r] = own[r * TC];
+    }
+  }
+  // ---- the windowed path (edt_colwave_lane.h: brute_band) -------------------------------------
+  // mode 0: hulls only; 1 / 2: every tile takes the windowed path (fp32 candidates when exact / fp64
+  // candidates); 3: the kernel's per-tile choice (field small everywhere -> windowed path)
+  if (mode != 0 && meta == nullptr) {
+    BruteTab tab;
+    const int want = mode == 3 ? 64 : n;
+    bool x32 = brute_tab_fill(tab, w, want);
+    if (mode == 2) x32 = false;
+    bool take = true;
+    if (mode == 3) {
+      float fmaxv = 0.0f;
+      for (auto &P : lanes)
+        if (P.L.colc < cols_left)
+          for (int r = 0; r < 32; ++r)
+            if (P.L.row0 + r < n && ((P.L.nzw >> r) & 1u)) fmaxv = std::max(fmaxv, P.f[r]);
+      const double cT = (double)(w * w) * 64.0 * 64.0;
+      take = (double)fmaxv <= cT;
+    }
+    if (take) {
+      // +inf around the column: the padding bands and the rows that complete the last band
+      for (int row = -32; row < (NB + 1) * 32; ++row)
+        if (row < 0 || row >= n)
+          for (int c = 0; c < TC; ++c) tile[addr_tile<CW>(c, row)] = INFINITY;
+      std::vector<float> res((size_t)NBP * 32 * TC, 0.0f);
+      for (int band = 0; band < NBP; ++band)
+        for (int col = 0; col < TC; ++col) {
+          PerLane *P = nullptr;
+          for (auto &Q : lanes)
+            if (Q.L.colc == col && Q.L.band == band) P = &Q;
+          BruteLane BL;
+          BL.tile = tile; BL.col = col; BL.band = band; BL.row0 = band * 32; BL.n = n;
+          BL.nzw = P->L.nzw; BL.rsw = P->L.rsw; BL.lo_in = P->L.lo_in; BL.hi_out = P->L.hi_out;
+          BL.w2 = (double)(w * w); BL.w2f = w * w;
+          auto store = [&](int row, float v) { res[(size_t)row * TC + col] = v; };
+          if (x32) brute_band<CW, BB, true>(BL, tab, epi, store);
+          else brute_band<CW, BB, false>(BL, tab, epi, store);
+        }
+      for (int row = 0; row < n; ++row)
+        for (int c = 0; c < TC && c < cols_left; ++c) F[x0 + (int64_t)row * stride + c] = res[(size_t)row * TC + c];
+      return;
     }
   }
   auto lane_of = [&](int colc, int band) -> PerLane * {
@@ -176,7 +220,7 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
   g_lane_base += (int)lanes.size();
 #endif
   for (auto &P : lanes) {
-    float *own = tile.data() + addr_tile<CW>(P.L.colc, P.L.row0);
+    float *own = tile + addr_tile<CW>(P.L.colc, P.L.row0);
     for (int r = 0; r < 32; ++r) own[r * TC] = P.f[r];
   }
   if (gran4) {
@@ -199,11 +243,11 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
 template <int CW>
 void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n, int NB, int64_t stride,
              float w, int bb, int epi, const XRowMeta *meta = nullptr, const float *Ttab = nullptr,
-             int idx_inf = 0, int flim = 0) {
+             int idx_inf = 0, int flim = 0, int mode = 0) {
   for (int64_t x0 = 0; x0 < sx; x0 += TileGeom<CW>::kCols) {
     const XRowMeta *m = meta ? meta + (x0 >> 6) * n : nullptr;  // records are [chunk][row]
-    if (bb) tile_pass<CW, true>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim);
-    else tile_pass<CW, false>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim);
+    if (bb) tile_pass<CW, true>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim, mode);
+    else tile_pass<CW, false>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim, mode);
   }
 }
 
@@ -211,8 +255,8 @@ void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n
 
 // F: [n][sx] fp32 (row stride = sx), in place.  labels: [n][sx] uint32.  Returns 0, or -1 if the
 // shape is outside what the wave kernel supports.
-extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t sx, int64_t n, float w,
-                                     int bb, int epi) {
+extern "C" int lane_emul_column_pass_mode(const uint32_t *labels, float *F, int64_t sx, int64_t n, float w,
+                                          int bb, int epi, int mode) {
   const int NB = (int)((n + 31) / 32);
   if (NB < 1 || NB > 64) return -1;
   std::vector<uint32_t> nz((size_t)NB * sx, 0), rs((size_t)NB * sx, 0);
@@ -223,13 +267,18 @@ extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t s
       if (lab != 0) nz[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
       if (start) rs[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
     }
-  if (NB <= 2) pass_cw<32>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
-  else if (NB <= 4) pass_cw<16>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
-  else if (NB <= 8) pass_cw<8>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
-  else if (NB <= 16) pass_cw<4>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
-  else if (NB <= 32) pass_cw<2>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
-  else pass_cw<1>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi);
+  if (NB <= 2) pass_cw<32>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
+  else if (NB <= 4) pass_cw<16>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
+  else if (NB <= 8) pass_cw<8>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
+  else if (NB <= 16) pass_cw<4>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
+  else if (NB <= 32) pass_cw<2>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
+  else pass_cw<1>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
   return 0;
+}
+
+extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t sx, int64_t n, float w,
+                                     int bb, int epi) {
+  return lane_emul_column_pass_mode(labels, F, sx, n, w, bb, epi, 0);
 }
 
 // Fused passes 1+2 on a 2-D image: labels [n][sx] uint32 -> out [n][sx] fp32 (no pass-1 buffer at all).

@@ -33,16 +33,22 @@ def emul():
                         "-fPIC", f"-I{CSRC}", src, "-o", so], check=True)
     lib = ctypes.CDLL(so)
     lib.lane_emul_column_pass.restype = ctypes.c_int
+    lib.lane_emul_column_pass_mode.restype = ctypes.c_int
     return lib
 
 
-def column_pass(lib, labels_yx, f_yx, w, bb, epi):
+# how a tile is processed: hulls (mode 0), the windowed path on every tile with fp32 candidates where they
+# are exact (1) or with fp64 candidates (2), or the kernel's own per-tile choice (3)
+MODES = {"hull": 0, "window": 1, "window64": 2, "auto": 3}
+
+
+def column_pass(lib, labels_yx, f_yx, w, bb, epi, mode=0):
     n, sx = labels_yx.shape
     lab = np.ascontiguousarray(labels_yx, dtype=np.uint32)
     f = np.ascontiguousarray(f_yx, dtype=np.float32).copy()
-    rc = lib.lane_emul_column_pass(lab.ctypes.data_as(ctypes.c_void_p), f.ctypes.data_as(ctypes.c_void_p),
-                                   ctypes.c_int64(sx), ctypes.c_int64(n), ctypes.c_float(w),
-                                   ctypes.c_int(int(bb)), ctypes.c_int(epi))
+    rc = lib.lane_emul_column_pass_mode(lab.ctypes.data_as(ctypes.c_void_p), f.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.c_int64(sx), ctypes.c_int64(n), ctypes.c_float(w),
+                                        ctypes.c_int(int(bb)), ctypes.c_int(epi), ctypes.c_int(mode))
     assert rc == 0
     return f
 
@@ -74,17 +80,20 @@ def make_labels(n, sx, kind, rng):
     return lab
 
 
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("n,sx,kind", CASES)
-def test_column_pass_matches_oracle(emul, oracle_port, n, sx, kind):
+def test_column_pass_matches_oracle(emul, oracle_port, n, sx, kind, mode):
+    if mode != "hull" and kind == "ones" and n > 600:
+        pytest.skip("whole-axis windows on every row: minutes in the host emulation, nothing new")
     rng = np.random.default_rng(n * 1000 + sx)
     lab = make_labels(n, sx, kind, rng)
     for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (0.7, 1.3)):
         for bb in (True, False):
             f1 = x_pass(oracle_port, lab, wx, bb)
             want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
-            got = column_pass(emul, lab, f1, wy, bb, 0 if bb else 1)
+            got = column_pass(emul, lab, f1, wy, bb, 0 if bb else 1, MODES[mode])
             assert np.array_equal(got, want), (n, sx, kind, wx, wy, bb)
-            got_sqrt = column_pass(emul, lab, f1, wy, bb, (0 if bb else 1) | 2)
+            got_sqrt = column_pass(emul, lab, f1, wy, bb, (0 if bb else 1) | 2, MODES[mode])
             assert np.array_equal(got_sqrt, np.sqrt(want)), (n, sx, kind, wx, wy, bb, "sqrt")
 
 

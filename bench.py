@@ -4,20 +4,24 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
 For N > 1 it is launched under torch.distributed.run, one rank per GPU (RCCL).
 
-  * N = 1 workload = BASELINE.json configs[1]: 512^3 uint32 single label, anisotropy
+  * N = 1 headline workload = BASELINE.json configs[1]: 512^3 uint32 single label, anisotropy
     (6,6,30), black_border=True, labels and output resident in HBM (no PCIe in the timed region).
-  * N > 1 workload = ONE global volume with 512^3 voxels PER GPU (N=8 -> 1024^3, BASELINE
-    configs[3]), Z-sharded; the X and Y passes are slab-local, ONE all-to-all (RCCL send/recv
-    group over xGMI) re-partitions Z-slabs into Y-slabs before the Z pass.  Weak scaling.
+    The same line carries a `secondary` list: configs[2] (cfg3: 512^3, 2000 labels, black_border=False),
+    its membrane / anisotropic twin (cfg3m) and the 1024^3 segmentation of configs[3] on ONE GPU (cfg4),
+    each with ms_per_step, per-kernel times and the 32 B/voxel whole-job fraction, cfg3 / cfg3m checked
+    bit for bit against the compiled reference on this host.
+  * N > 1 workload = ONE global multi-label volume with 512^3 voxels PER GPU (N=8 -> the 1024^3
+    segmentation of BASELINE configs[3]), Z-sharded; the X and Y passes are slab-local, ONE all-to-all
+    (RCCL send/recv group over xGMI) re-partitions Z-slabs into Y-slabs before the Z pass.  Weak scaling.
   * a "step" = one complete edtsq of the (local part of the) volume.
   * roofline: dominant kernel's ALGORITHMIC bytes (pass X reads labels + writes
     fp32, passes Y/Z read labels + read/write fp32 -> 8 / 12 / 12 B per uint32 voxel) divided
     by its duration measured with hipEvents inside the library on the launch stream.
   * cpu_baseline: the real reference (oracle/_ref, compiled from the reference sources) on
-    this host's cores, whole 512^3 workload, 1 thread and all threads.
+    this host's cores: the headline volume and the cfg3 volume, 1 thread and all threads,
+    1 warm-up + best of 3, CPU model stated.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -32,9 +36,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+PROFILE_TAG = "r02"    # profiles/<tag>_traffic.json holds the PMC-derived HBM bytes per launch
 
 
-def algorithmic_bytes_per_voxel(label_bytes, fused):
+def algorithmic_bytes_per_voxel(label_bytes, fused=False):
     """X reads labels + writes fp32, Y and Z read labels + read/write fp32.  On the fused
     path the bit kernel does pass X's label read and the first column kernel does the rest of X and Y."""
     if fused:
@@ -42,50 +47,301 @@ def algorithmic_bytes_per_voxel(label_bytes, fused):
     return {"x_pass": label_bytes + 4, "y_pass": label_bytes + 8, "z_pass": label_bytes + 8}
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, config="cfg2"):
     """HBM bytes per launch of `kernel` from the PMC passes of the round (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
-    tools/profile_round.sh collects them, profiles/r01_traffic.json holds the per-kernel result."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel)
-    except (OSError, ValueError):
-        return None
+    WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes for gfx950);
+    tools/profile_round.sh collects them, profiles/<tag>_traffic.json holds the per-kernel result."""
+    for tag in (PROFILE_TAG, "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
+        try:
+            with open(path) as f:
+                blob = json.load(f)
+        except (OSError, ValueError):
+            continue
+        entry = blob.get(config, blob) if isinstance(blob.get(config, None), dict) else blob
+        if kernel in entry:
+            return entry[kernel]
+    return None
 
 
-def cpu_baseline(n, anisotropy, bb):
-    """Time the reference CPU implementation on this host (bounded: whole 512^3 job, ~10-20 s)."""
+def cpu_model():
     try:
-        from oracle import harness
-        if harness.have_ref():
-            lib, kind = harness.ref(fast=True), "reference"
-        else:
-            if not harness.have_port():
-                harness.build("port")
-            lib, kind = harness.port(), "port"
-    except Exception as e:  # pragma: no cover
-        return {"value": None, "unit": "Mvox/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
-    cores = os.cpu_count() or 1
-    m = min(n, 512)
-    lab = np.ones((m, m, m), dtype=np.uint32, order="F")
-    vox = lab.size
-    results = {}
-    threads = (1, cores) if kind == "reference" else (1,)
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def reference_lib():
+    """The CPU checker: the compiled reference (oracle/_ref) when it travelled with the tree, else our
+    plain-C restatement.  Test / baseline infrastructure only."""
+    from oracle import harness
+    if harness.have_ref():
+        return harness.ref(fast=True), "reference"
+    if not harness.have_port():
+        harness.build("port")
+    return harness.port(), "port"
+
+
+def time_reference(lib, kind, lab, anisotropy, bb, threads):
+    """1 warm-up + best of 3 per thread count; returns ({threads: Mvox/s}, last output)."""
+    code = 2 if lab.dtype.itemsize == 4 else 0
+    sx, sy, sz = lab.shape
+    res, out = {}, None
     for p in threads:
         best = float("inf")
-        for _ in range(2):
+        for it in range(4):
             t0 = time.perf_counter()
-            lib.raw3d(lab, 2, m, m, m, anisotropy, bb, parallel=p) if kind == "reference" else \
-                lib.raw3d(lab, 2, m, m, m, anisotropy, bb)
-            best = min(best, time.perf_counter() - t0)
-        results[p] = vox / best / 1e6
-    top = max(results, key=lambda k: results[k])
-    return {
-        "value": round(results[top], 2), "unit": "Mvox/s", "cores": int(top), "kind": kind,
-        "sample": f"whole {m}^3 uint32 volume, anisotropy {anisotropy}, best of 2; "
-                  + ", ".join(f"{p} thread(s): {v:.1f} Mvox/s" for p, v in results.items()),
-    }
+            out = (lib.raw3d(lab, code, sx, sy, sz, anisotropy, bb, parallel=p) if kind == "reference"
+                   else lib.raw3d(lab, code, sx, sy, sz, anisotropy, bb))
+            dt = time.perf_counter() - t0
+            if it > 0:
+                best = min(best, dt)
+            if it == 1 and dt > 12.0:  # a slow single-thread pass: one timed run is enough
+                break
+        res[p] = lab.size / best / 1e6
+    return res, out
+
+
+class DeviceRun:
+    """One configuration resident on the device: labels, output, plan."""
+
+    def __init__(self, name, n, dev):
+        from edt import device
+        from synth import config_volume
+        self.name, self.n, self.dev = name, n, dev
+        if name == "cfg4" and n >= 768:
+            # the 4 GiB label volume is built on the device from the coarse grid (no 4 GiB host array)
+            from synth import voronoi_coarse
+            c = n // 4
+            coarse = voronoi_coarse((c, c, c), max(8, int(round(16000 * (n / 1024.0) ** 3))), seed=1)
+            t = torch.from_numpy(np.ascontiguousarray(coarse.T).view(np.int32)).to(dev)
+            for ax in range(3):
+                t = t.repeat_interleave(4, dim=ax)
+            self.labels, self.lab_np = t.contiguous(), None
+            self.an, self.bb, self.label_bytes = (1.0, 1.0, 1.0), False, 4
+            shape = (n, n, n)
+        else:
+            lab_np, an, bb = config_volume(name, n)
+            self.lab_np, self.an, self.bb = lab_np, an, bb
+            self.label_bytes = lab_np.dtype.itemsize
+            shape = lab_np.shape
+            # (sx,sy,sz) Fortran array == contiguous tensor of shape (sz,sy,sx): no copy of the bytes
+            self.labels = torch.from_numpy(
+                np.ascontiguousarray(lab_np.T).view(np.int32 if self.label_bytes == 4 else np.uint8)).to(dev)
+        self.vox = shape[0] * shape[1] * shape[2]
+        self.out = torch.empty(shape[::-1], dtype=torch.float32, device=dev)
+        self.plan = device.Plan(shape, 2 if self.label_bytes == 4 else 0, dev)
+
+    def step(self, generic=False):
+        self.plan.run(self.labels, self.an, black_border=self.bb, sqrt=False, out=self.out, force_generic=generic)
+
+    def measure(self, steps, warmup, generic=False):
+        from edt import device
+        for _ in range(warmup):
+            self.step(generic)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(generic)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        ms = elapsed / steps * 1e3
+        # per-kernel durations with hipEvents on the launch stream (separate profiled steps)
+        device.set_profiling(True)
+        acc = {}
+        for _ in range(max(3, min(steps, 10))):
+            self.step(generic)
+            torch.cuda.synchronize()
+            for name, t in device.pass_times():
+                acc.setdefault(name, []).append(t)
+        device.set_profiling(False)
+        kernels = {k: float(np.mean(v)) for k, v in acc.items()}
+        bpv = algorithmic_bytes_per_voxel(self.label_bytes, "x_bits" in kernels)
+        whole = sum(bpv.values()) * self.vox / (ms * 1e-3) / 1e9
+        return {
+            "ms_per_step": round(ms, 4), "mvox_per_s": round(self.vox / (ms * 1e-3) / 1e6, 1),
+            "kernel_ms": {k: round(v, 4) for k, v in kernels.items()},
+            "whole_job_algorithmic_GBs": round(whole, 1), "whole_job_frac": round(whole / HBM_PEAK_GBS, 4),
+        }, kernels, bpv
+
+
+# ------------------------------------------------------------------------------------------
+# the N > 1 leg: one process per GPU, the volume Z-sharded (edt/distributed.py)
+# ------------------------------------------------------------------------------------------
+def slab_labels(ext, zs, ze, dev, kind="cfg4"):
+    """This rank's Z-slab [zs, ze) of the global benchmark volume, built on the device.
+
+    cfg4 (BASELINE configs[3]): nearest-seed segmentation, 16 000 seeds per 1024^3 voxels on a grid four
+    times coarser (seed 1), up-sampled x4 -- every rank queries only the coarse slices its slab needs."""
+    if kind == "ones":
+        return torch.ones((ze - zs, ext[1], ext[0]), dtype=torch.int32, device=dev)
+    from synth import voronoi_coarse
+    coarse = tuple(-(-e // 4) for e in ext)
+    nseeds = max(8, int(round(16000 * (ext[0] * ext[1] * ext[2]) / 1024.0 ** 3)))
+    c0, c1 = zs // 4, -(-ze // 4)
+    lab = voronoi_coarse(coarse, nseeds, seed=1, zrange=(c0, c1))           # (cx, cy, c1-c0), Fortran order
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev)  # (cz, cy, cx)
+    for ax in range(3):
+        t = t.repeat_interleave(4, dim=ax)
+    return t[zs - 4 * c0:ze - 4 * c0, :ext[1], :ext[0]].contiguous()
+
+
+def sharded_main(args, rank, world, dev):
+    import torch.distributed as dist
+    from edt import _lib
+    from edt.distributed import ShardedEDT, global_extents
+    ext = global_extents(world, args.size)
+    kind = os.environ.get("EDT_BENCH_LABELS", "cfg4")  # "ones": the single-label box (closed-form check)
+    an, bb = ((6.0, 6.0, 30.0), True) if kind == "ones" else ((1.0, 1.0, 1.0), False)
+    plan = ShardedEDT(ext, _lib.U32)
+    zs, ze = plan.local_z()
+    labels = slab_labels(ext, zs, ze, dev, kind)
+
+    def step():
+        return plan.run(labels, an, black_border=bb)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # per-kernel durations of one more step (hipEvents inside the library, this rank's stream)
+    from edt import device
+    acc = {}
+    for _ in range(3):
+        device.set_profiling(True)
+        step()
+        torch.cuda.synchronize()
+        for name, ms in device.pass_times():
+            acc.setdefault(name, []).append(ms)
+    device.set_profiling(False)
+    kernel_ms = {k: float(np.sum(v)) / 3 for k, v in acc.items()}  # chunks of a step add up
+    dist.barrier()
+
+    ys, ye = plan.local_y()
+    cpu = None
+    if kind == "ones":
+        # correctness of the timed output: closed form of the all-ones box on this rank's y-slab
+        idx = [torch.arange(e, device=dev, dtype=torch.float64) for e in ext]
+        d = [torch.minimum(i + 1, e - i) * w for i, e, w in zip(idx, ext, an)]
+        want = torch.minimum(torch.minimum((d[2] ** 2)[:, None, None], (d[1][ys:ye] ** 2)[None, :, None]),
+                             (d[0] ** 2)[None, None, :]).to(torch.float32)
+        ok = torch.tensor([1 if torch.equal(out, want) else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        verified, how = bool(ok.item()), "closed form of the box"
+    else:
+        verified, how, cpu = _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev)
+
+    if rank == 0:
+        vox = ext[0] * ext[1] * ext[2]
+        # roofline of the dominant kernel ON ONE RANK: its algorithmic bytes (SURVEY 8(d): X reads
+        # labels + writes fp32; Y and Z read labels + read / write fp32) over its summed duration
+        bpv = {"x_pass": 4 + 4, "y_pass": 4 + 8, "z_pass": 4 + 8}
+        roofline = None
+        if any(k in kernel_ms for k in bpv):
+            dom = max((k for k in kernel_ms if k in bpv), key=lambda k: kernel_ms[k])
+            achieved = bpv[dom] * (vox / world) / (kernel_ms[dom] * 1e-3) / 1e9
+            whole = 32.0 * vox / (elapsed / args.steps) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                        "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                        "whole_job_algorithmic_GBs": round(whole, 1),
+                        "whole_job_frac": round(whole / (8000.0 * world), 4),
+                        "note": "per rank; the exchange is not a kernel of this library and is not listed; "
+                                "whole_job_frac = 32 B/voxel over ms_per_step against world x 8 TB/s"}
+        line = {
+            "metric": "Mvox/s edt3dsq 512^3 uint32", "value": round(vox / (elapsed / args.steps) / 1e6, 1),
+            "unit": "Mvox/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 envelope / f32 storage / u32 labels", "data": "synthetic",
+            "config": {"workload": f"WEAK scaling: one {ext[0]}x{ext[1]}x{ext[2]} uint32 volume = {args.size}^3 voxels "
+                                   f"per GPU ({'single label' if kind == 'ones' else 'multi-label segmentation, 16000 seeds per 1024^3 (configs[3])'}), "
+                                   f"anisotropy {an}, black_border={bb}, Z-sharded over {world} GPUs, "
+                                   "one all-to-all (Z-slabs -> Y-slabs) before the z pass",
+                       "form": "slab records" if plan.records else "byte flags",
+                       "chunks": getattr(plan, "nchunks", 1),
+                       "output_verified": verified, "verified_by": how},
+            "roofline": roofline,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    dist.destroy_process_group()
+
+
+def _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev):
+    """Bit-for-bit check of the timed multi-GPU output: rank 0 collects every rank's label slab and result
+    slab and runs the CPU reference (oracle/_ref, test infrastructure) on the whole volume with all host
+    threads.  Returns (verified | None, how, cpu_baseline | None).  EDT_BENCH_VERIFY=0 skips it."""
+    import torch.distributed as dist
+    if os.environ.get("EDT_BENCH_VERIFY", "1") == "0":
+        return None, "skipped (EDT_BENCH_VERIFY=0)", None
+    have = torch.tensor([0], device=dev)
+    lib = None
+    if rank == 0:
+        try:
+            from oracle import harness
+            if harness.have_ref():
+                lib = harness.ref(fast=True)
+                have[0] = 1
+        except Exception:
+            lib = None
+    dist.broadcast(have, 0)
+    if int(have.item()) == 0:
+        return None, "skipped (oracle/_ref not present)", None
+    sx, sy, sz = ext
+    stage = dist.get_backend() == "gloo"
+
+    def send(t):
+        t = t.contiguous()
+        dist.send(t.cpu() if stage else t, 0)
+
+    def recv(shape, dtype, src):
+        buf = torch.empty(shape, dtype=dtype, device="cpu" if stage else dev)
+        dist.recv(buf, src)
+        return buf.cpu()
+
+    if rank != 0:
+        send(labels)
+        send(out)
+        return None, "", None
+    lab_full = np.empty((sz, sy, sx), dtype=np.int32)
+    res_full = np.empty((sz, sy, sx), dtype=np.float32)
+    for r in range(world):
+        zs, ze = plan.zparts[r]
+        ys, ye = plan.yparts[r]
+        if r == 0:
+            lab_r, out_r = labels.cpu(), out.contiguous().cpu()
+        else:
+            lab_r = recv((ze - zs, sy, sx), torch.int32, r)
+            out_r = recv((sz, ye - ys, sx), torch.float32, r)
+        lab_full[zs:ze] = lab_r.numpy()
+        res_full[:, ys:ye, :] = out_r.numpy()
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    want = lib.raw3d(lab_full.view(np.uint32), 2, sx, sy, sz, an, bb, parallel=cores)
+    dt = time.perf_counter() - t0
+    ok = bool(np.array_equal(want, res_full.reshape(-1)))
+    model = cpu_model()
+    cpu = {"value": round(sx * sy * sz / dt / 1e6, 2), "unit": "Mvox/s", "cores": cores, "kind": "reference",
+           "cpu": model, "sample": f"the whole {sx}x{sy}x{sz} volume of this run, one pass with {cores} threads "
+                                   "(the pass that also checks the GPU output bit for bit)"}
+    return ok, f"compiled CPU reference on the whole volume, {cores} threads", cpu
 
 
 def main():
@@ -94,8 +350,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512, help="edge length of the per-GPU volume")
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg3m", "cfg5"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg3m", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline configuration only")
     ap.add_argument("--generic", action="store_true", help="force the size-agnostic fallback kernels")
     args = ap.parse_args()
 
@@ -106,8 +363,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks")
 
     import edt  # noqa: F401
-    from edt import _lib, device
-    from synth import config_volume
+    from edt import _lib
 
     _lib.load()
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -124,73 +380,91 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        from edt import distributed as edist
-        return edist.bench_main(args, rank, world, dev)
+        return sharded_main(args, rank, world, dev)
 
-    lab_np, an, bb = config_volume(args.config, n)
-    label_bytes = lab_np.dtype.itemsize
-    vox = lab_np.size
-    # (sx,sy,sz) Fortran array == contiguous tensor of shape (sz,sy,sx): no copy of the bytes
-    labels = torch.from_numpy(np.ascontiguousarray(lab_np.T).view(np.int32 if label_bytes == 4 else np.uint8)).to(dev)
-    out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
-    plan = device.Plan(lab_np.shape, 2 if label_bytes == 4 else 0, dev)
-
-    def step():
-        plan.run(labels, an, black_border=bb, sqrt=False, out=out, force_generic=args.generic)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ms_per_step = elapsed / args.steps * 1e3
-    mvox = vox / (elapsed / args.steps) / 1e6
-
-    # per-kernel durations with hipEvents on the launch stream (separate profiled steps)
-    device.set_profiling(True)
-    acc = {}
-    prof_steps = max(3, min(args.steps, 10))
-    for _ in range(prof_steps):
-        step()
-        torch.cuda.synchronize()
-        for name, ms in device.pass_times():
-            acc.setdefault(name, []).append(ms)
-    device.set_profiling(False)
-    kernels = {k: float(np.mean(v)) for k, v in acc.items()}
-    bpv = algorithmic_bytes_per_voxel(label_bytes, "x_bits" in kernels)
+    head = DeviceRun(args.config, n, dev)
+    summary, kernels, bpv = head.measure(args.steps, args.warmup, args.generic)
     dom = max((k for k in kernels if k in bpv), key=lambda k: kernels[k])
-    achieved = bpv[dom] * vox / (kernels[dom] * 1e-3) / 1e9
-    total_kernel_ms = sum(kernels.values())
+    achieved = bpv[dom] * head.vox / (kernels[dom] * 1e-3) / 1e9
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom),
-        "kernel_ms": {k: round(v, 4) for k, v in kernels.items()},
-        "whole_job_algorithmic_GBs": round(sum(bpv.values()) * vox / (total_kernel_ms * 1e-3) / 1e9, 1),
-        "whole_job_frac": round(sum(bpv.values()) * vox / (total_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, args.config),
+        "kernel_ms": summary["kernel_ms"],
+        "whole_job_algorithmic_GBs": summary["whole_job_algorithmic_GBs"],
+        "whole_job_frac": summary["whole_job_frac"],  # 32 B/voxel model over ms_per_step
     }
 
     # sanity: the timed output is the right answer (closed form for the all-ones box)
     if args.config in ("cfg1", "cfg2"):
         from synth import box_edtsq_closed_form
-        ok = bool(np.array_equal(out.cpu().numpy().T, box_edtsq_closed_form(lab_np.shape, an)))
+        ok = bool(np.array_equal(head.out.cpu().numpy().T, box_edtsq_closed_form(head.lab_np.shape, head.an)))
     else:
         ok = None
+    head_lab, head_an, head_bb = head.lab_np, head.an, head.bb
+
+    lib = kind = None
+    if not args.no_cpu_baseline:
+        try:
+            lib, kind = reference_lib()
+        except Exception as e:  # pragma: no cover
+            lib, kind = None, f"unavailable: {e}"
+    cores = os.cpu_count() or 1
+    threads = (1, cores) if kind == "reference" else (1,)
+
+    secondary = []
+    cpu_secondary = {}
+    if not args.no_secondary and args.config == "cfg2" and not args.generic:
+        del head
+        torch.cuda.empty_cache()
+        for name, size in (("cfg3", n), ("cfg3m", n), ("cfg4", 2 * n)):
+            try:
+                run = DeviceRun(name, size, dev)
+                s, _, _ = run.measure(max(5, args.steps // 2) if size > n else args.steps, args.warmup)
+                entry = {"config": name,
+                         "workload": f"{size}^3 uint32 multi-label, anisotropy {tuple(run.an)}, "
+                                     f"black_border={run.bb}, device-resident in/out, 1 GPU", **s}
+                if lib is not None and run.lab_np is not None:
+                    # bit-for-bit against the CPU reference on the same volume (all threads), timed as well
+                    res, want = time_reference(lib, kind, run.lab_np, tuple(run.an), run.bb, threads[-1:])
+                    got = run.out.cpu().numpy().reshape(-1)
+                    entry["output_verified"] = bool(np.array_equal(got, want))
+                    cpu_secondary[name] = {f"{p} thread(s)": round(v, 1) for p, v in res.items()}
+                else:
+                    entry["output_verified"] = None  # full-size parity of this volume: tests/test_gpu_fullsize.py
+                secondary.append(entry)
+                del run
+                torch.cuda.empty_cache()
+            except Exception as e:  # pragma: no cover  (a secondary must never take the headline down)
+                secondary.append({"config": name, "error": repr(e)})
 
     result = {
-        "metric": "Mvox/s edt3dsq 512^3 uint32", "value": round(mvox, 1), "unit": "Mvox/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "metric": "Mvox/s edt3dsq 512^3 uint32", "value": summary["mvox_per_s"], "unit": "Mvox/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": summary["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 envelope / f32 storage / u32 labels", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {n}^3 uint32 labels, anisotropy {tuple(an)}, "
-                               f"black_border={bb}, device-resident in/out",
+        "config": {"workload": f"{args.config}: {n}^3 uint32 labels, anisotropy {tuple(head_an)}, "
+                               f"black_border={head_bb}, device-resident in/out",
                    "path": "generic" if args.generic else "default", "output_verified": ok},
         "roofline": roofline,
     }
+    if secondary:
+        result["secondary"] = secondary
     if not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(n, tuple(an), bb)
+        if lib is None:
+            result["cpu_baseline"] = {"value": None, "unit": "Mvox/s", "cores": 0, "kind": str(kind), "sample": ""}
+        else:
+            m = min(n, 512)
+            lab = head_lab if head_lab is not None and head_lab.shape[0] == m else np.ones((m, m, m), np.uint32, order="F")
+            res, _ = time_reference(lib, kind, lab, tuple(head_an), head_bb, threads)
+            top = max(res, key=lambda k: res[k])
+            result["cpu_baseline"] = {
+                "value": round(res[top], 2), "unit": "Mvox/s", "cores": int(top), "kind": kind,
+                "cpu": cpu_model(), "host_threads": cores,
+                "sample": f"whole {m}^3 uint32 headline volume ({args.config}), anisotropy {tuple(head_an)}, "
+                          "1 warm-up + best of 3; "
+                          + ", ".join(f"{p} thread(s): {v:.1f} Mvox/s" for p, v in res.items()),
+                "secondary": cpu_secondary,
+            }
     print(json.dumps(result))
 
 

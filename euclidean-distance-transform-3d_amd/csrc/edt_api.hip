@@ -2,6 +2,7 @@
 // carving, host-buffer staging, per-pass event timing.  No compute happens on the host and
 // there is no CPU fallback: every entry point needs a HIP device.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -27,7 +28,7 @@ int debug_mode() { return g_debug_mode; }
 
 // ---- per-pass event timing (bench.py reads this) -------------------------------------
 struct PassLog {
-  bool enabled = false;
+  std::atomic<bool> enabled{false};
   std::vector<hipEvent_t> pool;          // reused events
   std::vector<std::pair<int, int>> span;  // (start, stop) indices of the last call
   std::vector<std::string> names;
@@ -50,7 +51,8 @@ struct ScopedPass {
   int start = -1;
   ScopedPass(const char *name, hipStream_t s) : stream(s) {
     if (g_debug_mode & 0x1000) fprintf(stderr, "[edt_hip] pass start: %s\n", name);
-    if (!g_log.enabled) return;
+    if (!g_log.enabled.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lock(g_log_mutex);  // (only while profiling is switched on)
     hipEvent_t e = log_event();
     if (!e) return;
     start = g_log.used - 1;
@@ -63,6 +65,7 @@ struct ScopedPass {
       fprintf(stderr, "[edt_hip] pass done: %s\n", hipGetErrorString(e));
     }
     if (start < 0) return;
+    std::lock_guard<std::mutex> lock(g_log_mutex);
     hipEvent_t e = log_event();
     if (!e) return;
     (void)hipEventRecord(e, stream);
@@ -116,26 +119,37 @@ static AxisGeom make_geom_z(int64_t sx, int64_t sy, int64_t sz) {
   return g;
 }
 
-static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws) {
+// What a call needs besides the bit planes: the second fp32 volume + hull stacks of the size-agnostic
+// column pass (only when an axis is too long for the in-place LDS kernels, or the caller forces the
+// generic kernels), and the row records of the fused X+Y experiment (debug bit 128).
+static bool plan_needs_pingpong(int ndim, int64_t sx, int64_t sy, int64_t sz, int flags);
+
+static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws, int flags) {
   Plan p;
   p.ndim = ndim; p.sx = sx; p.sy = sy; p.sz = sz; p.voxels = sx * sy * sz;
   p.gy = make_geom_y(sx, sy, sz);
   p.gz = make_geom_z(sx, sy, sz);
   Carver c(ws);
   if (ndim >= 2) {
-    p.bufB = c.take<float>((size_t)p.voxels);
-    p.stack = c.take<int32_t>((size_t)p.voxels);
+    if (plan_needs_pingpong(ndim, sx, sy, sz, flags)) {
+      p.bufB = c.take<float>((size_t)p.voxels);
+      p.stack = c.take<int32_t>((size_t)p.voxels);
+    }
     const size_t wy = (size_t)(p.gy.sx * p.gy.nbands * p.gy.nouter);
     p.nz_y = c.take<uint32_t>(wy);
     p.rs_y = c.take<uint32_t>(wy);
   }
   if (ndim >= 3) {
+    // the z-packed planes are built AFTER the y pass: its run-start plane is dead by then and lends its
+    // storage to the z run starts (four planes in all: 1/8 byte per voxel each, 0.5 GiB for 1024^3)
+    const size_t wy = (size_t)(p.gy.sx * p.gy.nbands * p.gy.nouter);
     const size_t wz = (size_t)(p.gz.sx * p.gz.nbands * p.gz.nouter);
     p.nz_z = c.take<uint32_t>(wz);
-    p.rs_z = c.take<uint32_t>(wz);
-    p.zs_y = c.take<uint32_t>((size_t)(p.gy.sx * p.gy.nbands * p.gy.nouter));
+    if (wz <= wy) p.rs_z = p.rs_y;
+    else p.rs_z = c.take<uint32_t>(wz);
+    p.zs_y = c.take<uint32_t>(wy);
   }
-  if (ndim >= 2) {
+  if (ndim >= 2 && (g_debug_mode & 128)) {
     p.xrec = c.take<unsigned char>(row_records_bytes(sx, sy, sz));
     p.ttab = c.take<float>((size_t)sx + 3);
   }
@@ -163,6 +177,18 @@ static int launch_row_bits(int dtype, const void *labels, float *out, uint32_t *
   if (row_pass_wave_supported(dtype, sx, sy, sz) && !(g_debug_mode & 32))
     return launch_row_pass_wave(dtype, labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream);
   return launch_row_pass_tiled(dtype, labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream);
+}
+
+static bool env_force_generic() {
+  const char *e = std::getenv("EDT_HIP_FORCE_GENERIC");  // test hook: every call takes the fallback kernels
+  return e && e[0] == '1';
+}
+
+static bool plan_needs_pingpong(int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
+  if (ndim < 2) return false;
+  if ((flags & EDT_FLAG_FORCE_GENERIC) || env_force_generic()) return true;
+  if (!column_inplace_supported(make_geom_y(sx, sy, sz))) return true;
+  return ndim == 3 && !column_inplace_supported(make_geom_z(sx, sy, sz));
 }
 
 static int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
@@ -198,17 +224,21 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   if (rc != EDT_OK) return rc;
   if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
   if (!d_labels || !d_out) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
-  Plan p = make_plan(ndim, sx, sy, sz, d_ws);
+  Plan p = make_plan(ndim, sx, sy, sz, d_ws, flags);
   if (ndim >= 2 && (!d_ws || ws_bytes < p.bytes)) {
-    set_error("workspace too small: need " + std::to_string(p.bytes) + " bytes");
+    set_error("workspace too small: need " + std::to_string(p.bytes) +
+              " bytes (edt_hip_workspace_bytes_flags with the flags of this call)");
     return EDT_ERR_BAD_ARG;
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
   const int want_sqrt = (flags & EDT_FLAG_SQRT) ? 1 : 0;
   const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0);
 
-  std::lock_guard<std::mutex> lock(g_log_mutex);
-  log_begin_call();
+  // the pass log is process-wide and only touched (under its mutex) while profiling is switched on
+  if (g_log.enabled.load(std::memory_order_relaxed)) {
+    std::lock_guard<std::mutex> lock(g_log_mutex);
+    log_begin_call();
+  }
 
   if (ndim == 1) {
     ScopedPass t("x_pass", stream);
@@ -217,7 +247,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
 
   // Column passes are in place when the LDS-tiled kernel applies, otherwise they ping-pong
   // between two volumes.  Start in the buffer that makes the last pass land in d_out.
-  const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0;
+  const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0 || env_force_generic();
   const bool tiled_y = !force_generic && column_inplace_supported(p.gy);
   const bool tiled_z = !force_generic && column_inplace_supported(p.gz);
   const int swaps = (tiled_y ? 0 : 1) + ((ndim == 3 && !tiled_z) ? 1 : 0);
@@ -228,7 +258,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   // F from them (no fp32 volume is written by pass 1 or read by pass 2).  MEASURED SLOWER on MI355X
   // (0.905 vs 0.83 ms per 512^3 step: both kernels are bound by instruction issue, not by HBM, so
   // trading 1 GB of traffic for ~25 more instructions per voxel loses) -- kept behind debug bit 128.
-  const bool fused_xy = !force_generic && (g_debug_mode & 128) && !(g_debug_mode & (64 | 32)) && sx <= 512 && sx % 4 == 0 && p.gy.nbands <= 16 &&
+  const bool fused_xy = !force_generic && (g_debug_mode & 128) && p.xrec != nullptr && !(g_debug_mode & (64 | 32)) && sx <= 512 && sx % 4 == 0 && p.gy.nbands <= 16 &&
                         row_pass_wave_supported(dtype, sx, sy, sz) && column_pass_wave_supported(p.gy);
   if (fused_xy) {
     {
@@ -237,22 +267,12 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
                               sx, sy, sz, wx, bb, stream);
       if (rc != EDT_OK) return rc;
     }
-    if (ndim == 3) {
-      ScopedPass t("z_bits", stream);
-      rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
-      if (rc != EDT_OK) return rc;
-    }
   } else if (tiled_x) {
     // labels are read once: pass 1 also emits the run bit-planes of the y and z axes
     {
       ScopedPass t("x_pass", stream);
       rc = launch_row_bits(dtype, d_labels, cur, p.nz_y, p.rs_y, ndim == 3 ? p.zs_y : nullptr, sx, sy, sz,
                            wx, bb, bb ? 0 : 1, stream);
-      if (rc != EDT_OK) return rc;
-    }
-    if (ndim == 3) {
-      ScopedPass t("z_bits", stream);
-      rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
       if (rc != EDT_OK) return rc;
     }
   } else {
@@ -264,11 +284,6 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     {
       ScopedPass t("y_bits", stream);
       rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_y, p.rs_y, p.gy, stream);
-      if (rc != EDT_OK) return rc;
-    }
-    if (ndim == 3) {
-      ScopedPass t("z_bits", stream);
-      rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
       if (rc != EDT_OK) return rc;
     }
   }
@@ -284,6 +299,13 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
       rc = launch_column_pass_serial(cur, other, p.nz_y, p.rs_y, p.stack, p.gy, wy, bb, epi, stream);
       std::swap(cur, other);
     }
+    if (rc != EDT_OK) return rc;
+  }
+  if (ndim == 3) {
+    // z-packed planes (after the y pass: rs_z may live in the y pass's run-start plane)
+    ScopedPass t("z_bits", stream);
+    if (fused_xy || tiled_x) rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
+    else rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
     if (rc != EDT_OK) return rc;
   }
   if (ndim == 3) {
@@ -312,7 +334,7 @@ struct DevicePool {
   void *p[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap[kSlots] = {0, 0, 0, 0, 0, 0};
   std::mutex m;
-  void release() {
+  void release() {  // (call with the owning device current)
     for (int i = 0; i < kSlots; ++i) {
       if (p[i]) (void)hipFree(p[i]);
       p[i] = nullptr;
@@ -321,32 +343,43 @@ struct DevicePool {
   }
   ~DevicePool() { /* the runtime may already be gone at static destruction: leak on purpose */ }
 };
-static DevicePool g_pool;
+// one pool per device ordinal: a host-buffer call uses the pool of the device that is current on the
+// calling thread, so buffers are never handed to kernels running on another device
+constexpr int kMaxDevices = 64;
+static DevicePool g_pools[kMaxDevices];
+
+static DevicePool *current_pool() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return (dev >= 0 && dev < kMaxDevices) ? &g_pools[dev] : nullptr;
+}
 
 struct DeviceBuf {
+  DevicePool *pool;  // nullptr: private allocations only
   void *p = nullptr;
   bool owned = false;
+  explicit DeviceBuf(DevicePool *pl) : pool(pl) {}
   ~DeviceBuf() { if (p && owned) (void)hipFree(p); }
-  // slot < 0: private allocation, freed with the object; otherwise the pool slot is (re)used.
-  // The caller holds g_pool.m when it uses slots.
+  // slot < 0 (or no pool): private allocation, freed with the object; otherwise the pool slot is (re)used.
+  // The caller holds pool->m when it uses slots.
   int alloc(size_t bytes, int slot = -1) {
     if (bytes == 0) bytes = 256;
-    if (slot >= 0) {
-      if (g_pool.cap[slot] < bytes) {
-        if (g_pool.p[slot]) (void)hipFree(g_pool.p[slot]);
-        g_pool.p[slot] = nullptr;
-        g_pool.cap[slot] = 0;
-        const hipError_t e = hipMalloc(&g_pool.p[slot], bytes);
+    if (slot >= 0 && pool) {
+      if (pool->cap[slot] < bytes) {
+        if (pool->p[slot]) (void)hipFree(pool->p[slot]);
+        pool->p[slot] = nullptr;
+        pool->cap[slot] = 0;
+        const hipError_t e = hipMalloc(&pool->p[slot], bytes);
         if (e != hipSuccess) {
-          g_pool.p[slot] = nullptr;
+          pool->p[slot] = nullptr;
           (void)hipGetLastError();
-          g_pool.release();  // give everything back and let the caller see the failure
+          pool->release();  // give everything back and let the caller see the failure
           set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
           return EDT_ERR_NOMEM;
         }
-        g_pool.cap[slot] = bytes;
+        pool->cap[slot] = bytes;
       }
-      p = g_pool.p[slot];
+      p = pool->p[slot];
       owned = false;
       return EDT_OK;
     }
@@ -375,18 +408,16 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
   if (!labels || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
   rc = require_device();
   if (rc != EDT_OK) return rc;
-  // test hook: EDT_HIP_FORCE_GENERIC=1 routes host-buffer calls through the fallback kernels
-  if (const char *e = std::getenv("EDT_HIP_FORCE_GENERIC")) {
-    if (e[0] == '1') flags |= EDT_FLAG_FORCE_GENERIC;
-  }
+  if (env_force_generic()) flags |= EDT_FLAG_FORCE_GENERIC;
 
   const size_t lbytes = (size_t)voxels * dtype_size(dtype);
   const size_t obytes = (size_t)voxels * sizeof(float);
-  const size_t wbytes = edt_hip_workspace_bytes(dtype, ndim, sx, sy, sz);
+  const size_t wbytes = edt_hip_workspace_bytes_flags(dtype, ndim, sx, sy, sz, flags);
   const bool pooled = pool_enabled();
-  std::unique_lock<std::mutex> pool_lock(g_pool.m, std::defer_lock);
-  if (pooled) pool_lock.lock();
-  DeviceBuf d_labels, d_out, d_ws;
+  DevicePool *pool = pooled ? current_pool() : nullptr;
+  std::unique_lock<std::mutex> pool_lock;
+  if (pool) pool_lock = std::unique_lock<std::mutex>(pool->m);
+  DeviceBuf d_labels(pool), d_out(pool), d_ws(pool);
   if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
   if ((rc = d_out.alloc(obytes, pooled ? 1 : -1)) != EDT_OK) return rc;
   if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
@@ -413,9 +444,10 @@ static int voxel_graph_host(const void *labels, int dtype, const uint8_t *graph,
   const size_t lbytes = (size_t)voxels * dtype_size(dtype);
   const size_t wbytes = edt_hip_workspace_bytes(EDT_U8, ndim, X, Y, Z);
   const bool pooled = pool_enabled();
-  std::unique_lock<std::mutex> pool_lock(g_pool.m, std::defer_lock);
-  if (pooled) pool_lock.lock();
-  DeviceBuf d_labels, d_graph, d_big, d_bigdt, d_ws, d_out;
+  DevicePool *pool = pooled ? current_pool() : nullptr;
+  std::unique_lock<std::mutex> pool_lock;
+  if (pool) pool_lock = std::unique_lock<std::mutex>(pool->m);
+  DeviceBuf d_labels(pool), d_graph(pool), d_big(pool), d_bigdt(pool), d_ws(pool), d_out(pool);
   if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
   if ((rc = d_out.alloc((size_t)voxels * sizeof(float), pooled ? 1 : -1)) != EDT_OK) return rc;
   if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
@@ -544,10 +576,14 @@ int edt_hip_edt3d(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t
                   (black_border ? EDT_FLAG_BLACK_BORDER : 0) | EDT_FLAG_SQRT, output);
 }
 
-size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
+size_t edt_hip_workspace_bytes_flags(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
   if (check_shape(dtype, ndim, sx, sy, sz) != EDT_OK) return 0;
   if (sx == 0 || sy == 0 || sz == 0) return 256;
-  return make_plan(ndim, sx, sy, sz, nullptr).bytes;
+  return make_plan(ndim, sx, sy, sz, nullptr, flags).bytes;
+}
+
+size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
+  return edt_hip_workspace_bytes_flags(dtype, ndim, sx, sy, sz, 0);
 }
 
 int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy,
@@ -558,8 +594,17 @@ int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, 
 }
 
 int edt_hip_release_cache(void) {
-  std::lock_guard<std::mutex> lock(g_pool.m);
-  g_pool.release();
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return EDT_OK; }
+  for (int d = 0; d < kMaxDevices; ++d) {
+    std::lock_guard<std::mutex> lock(g_pools[d].m);
+    bool any = false;
+    for (int i = 0; i < DevicePool::kSlots; ++i) any = any || g_pools[d].p[i] != nullptr;
+    if (!any) continue;
+    if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
+    g_pools[d].release();
+  }
+  (void)hipSetDevice(cur);
   return EDT_OK;
 }
 
@@ -570,7 +615,7 @@ int edt_hip_set_debug_mode(int mode) {
 
 int edt_hip_set_profiling(int enabled) {
   std::lock_guard<std::mutex> lock(g_log_mutex);
-  g_log.enabled = enabled != 0;
+  g_log.enabled.store(enabled != 0);
   log_begin_call();  // the shard phases append to the log (several calls make one step): start clean
   return EDT_OK;
 }
@@ -716,7 +761,10 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
     }
     if (!d_blocks[h]) { set_error("null destination block"); return EDT_ERR_BAD_ARG; }
   }
-  if (g_log.enabled && g_log.used > 2048) log_begin_call();  // nobody is reading the log
+  if (g_log.enabled.load(std::memory_order_relaxed)) {
+    std::lock_guard<std::mutex> lock(g_log_mutex);
+    if (g_log.used > 2048) log_begin_call();  // nobody is reading the log
+  }
   RecordPlan p = make_record_plan(sx, sy, sz_local, d_workspace);
   if (!d_workspace || workspace_bytes < p.bytes) {
     set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");

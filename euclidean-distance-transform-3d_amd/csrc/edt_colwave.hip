@@ -23,19 +23,8 @@ extern template int launch_wave_c<1>(float *, const uint32_t *, const uint32_t *
 int window_limit() {
   static const int v = [] {
     const char *e = getenv("EDT_HIP_WINDOW_LIMIT");
-    const int t = e ? atoi(e) : 96;
+    const int t = e ? atoi(e) : 128;
     return t < 0 ? 0 : (t > 1024 ? 1024 : t);
-  }();
-  return v;
-}
-
-// A tile takes the windowed path only if at least 1/window_flat_div() of its run-continuing rows are not
-// flat (EDT_HIP_WINDOW_FLATDIV overrides; 65536 = flatness is not looked at).
-int window_flat_div() {
-  static const int v = [] {
-    const char *e = getenv("EDT_HIP_WINDOW_FLATDIV");
-    const int t = e ? atoi(e) : 8;
-    return t < 1 ? 1 : (t > 0x10000 ? 0x10000 : t);
   }();
   return v;
 }

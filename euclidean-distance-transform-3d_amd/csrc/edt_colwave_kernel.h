@@ -42,6 +42,7 @@
 #endif
 
 #define EDT_LANE __device__ __forceinline__
+#define EDT_LANE_MEMBER __device__ __forceinline__
 #include "edt_colwave_lane.h"
 
 namespace edt_amd {
@@ -50,11 +51,9 @@ namespace edt_amd {
 struct BruteArgs {
   uint32_t limit_bits;  // a tile takes the path when the bit pattern of its largest field value is <= this; 0 = never
   int x32;              // candidates are fp32 sums (c_d exactly representable up to the limit)
-  int flat_div;         // ... and when at least 1/flat_div of its run-continuing rows are not flat (0x10000: always)
-  edt_lane::BruteTab tab;
+  int force;            // diagnostics: every tile takes the path
 };
-int window_limit();     // edt_colwave.hip: largest window (rows) the windowed path is used for
-int window_flat_div();  // edt_colwave.hip: ... and the flatness bound of the tile choice
+int window_limit();  // edt_colwave.hip: largest window (rows) the windowed path is used for
 
 namespace {
 
@@ -85,6 +84,25 @@ __device__ __forceinline__ void scan_runs(edt_lane::Lane &L, int lane) {
   L.hi_out = y;
 }
 
+// The same scan over the "break" words (edt_colwave_lane.h: brute_flat_reach): last break row in an earlier
+// band of the column (-1: none), first break row in a later band (n: none).
+template <int CW>
+__device__ __forceinline__ void scan_breaks(uint32_t brk, int row0, int n, int lane, int &blo_in, int &bhi_out) {
+  int x = __shfl_up(brk ? row0 + 31 - __builtin_clz(brk) : -1, CW);
+  if (lane < CW) x = -1;
+  int y = __shfl_down(brk ? row0 + __builtin_ctz(brk) : n, CW);
+  if (lane >= 64 - CW) y = n;
+#pragma unroll
+  for (int d = CW; d < 64; d <<= 1) {
+    const int tx = __shfl_up(x, d);
+    const int ty = __shfl_down(y, d);
+    if (lane >= d) x = tx > x ? tx : x;
+    if (lane + d < 64) y = ty < y ? ty : y;
+  }
+  blo_in = x;
+  bhi_out = y;
+}
+
 }  // namespace
 
 template <int CW, bool BB, bool XF, bool SC>
@@ -107,7 +125,10 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * TG::kBandFloats + kPad);  // [NBP][TC]
   uint32_t *rsp = alive + NBP * TG::kBandWords;                                    // [NBP][TC]
   uint32_t *lohi = rsp + NBP * TG::kBandWords;     // [NBP][TC]: (lo_in + 1) | (hi_out + 1) << 16 (windowed path)
-  uint32_t *tmax = lohi + (XF ? 0 : NBP * TG::kBandWords);  // 1 word: largest field value of the tile
+  uint32_t *bscan = lohi + (XF ? 0 : NBP * TG::kBandWords);  // [NBP][TC]: the same for the breaks
+  // 2 words: largest field value of the tile, "some link of the tile is not flat".  They sit in the lower padding band (so that the LDS image of the
+  // 512-row shape is exactly half of a CU's 160 KiB), which is only filled with +inf once every thread has read them.
+  uint32_t *tmax = XF ? lohi : reinterpret_cast<uint32_t *>(smem);
   // XF only: row records, one spare slot per band so that the bands of a half-wave read
   // different banks ([33*NBP] x 16 B), then the table T ([sx+3] floats)
   XRowMeta *xrec = reinterpret_cast<XRowMeta *>(tmax + 4);
@@ -221,9 +242,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     wave_sync();
   }
 
-  // ---- tiles whose field is small everywhere, and not flat, take the windowed path ---------------------
-  // (a flat field -- large objects away from their boundaries -- would mean large windows where the hull
-  // path has nothing to do at all: every row owns itself)
+  // ---- tiles whose field is small everywhere take the windowed path (edt_colwave_lane.h: brute_band) ------
   const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
   const uint32_t fl0 = (dbg & 2) ? 0u : flat_word(L, f, fprev);
   const uint32_t need = L.nzw & ~(L.rsw | (L.band == 0 ? 1u : 0u));  // rows that continue a run
@@ -233,23 +252,23 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 #pragma unroll
       for (int r = 0; r < 32; ++r) fm = max(fm, __float_as_uint(f[r]));  // non-negative floats order like ints
       if (!active) fm = 0;
-      // tmax[0]: largest field value; tmax[1]: run-continuing rows; tmax[2]: those that are not flat
-      int cnt = (int)__popc(need) | ((int)__popc(need & ~fl0) << 16);
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        fm = max(fm, (uint32_t)__shfl_xor((int)fm, d));
-        cnt += __shfl_xor(cnt, d);
-      }
+      for (int d = 32; d >= 1; d >>= 1) fm = max(fm, (uint32_t)__shfl_xor((int)fm, d));
+      const uint32_t brk = need & ~fl0;  // links that are not flat
+      const bool any_brk = __ballot(brk != 0u) != 0ull;
       if (lane == 0) {
         atomicMax(tmax, fm);
-        atomicAdd(tmax + 1, (uint32_t)cnt);
+        if (any_brk) tmax[1] = 1u;  // (a tile without any is left to the all-flat shortcut of the hull path)
       }
-      alive[addr_word<CW>(L.colc, L.band)] = L.nzw;
+      int blo_in, bhi_out;
+      scan_breaks<CW>(brk, L.row0, n, lane, blo_in, bhi_out);
+      alive[addr_word<CW>(L.colc, L.band)] = brk;
       lohi[addr_word<CW>(L.colc, L.band)] = (uint32_t)(L.lo_in + 1) | ((uint32_t)(L.hi_out + 1) << 16);
+      bscan[addr_word<CW>(L.colc, L.band)] = (uint32_t)(blo_in + 1) | ((uint32_t)bhi_out << 16);
       __syncthreads();
-      const uint32_t cnts = tmax[1];
-      if (tmax[0] <= ba.limit_bits &&
-          (ba.flat_div == 0x10000 || (cnts >> 16) * (uint32_t)ba.flat_div > (cnts & 0xFFFFu))) {
+      const uint32_t tile_max = tmax[0], tile_brk = tmax[1];
+      if (tile_max <= ba.limit_bits && (tile_brk != 0u || ba.force)) {
+        __syncthreads();  // (every thread has read tmax: the padding band it sits in may be filled now)
         // +inf around the columns: the padding bands and the rows that complete the last band
         for (int i = (int)threadIdx.x; i < 32 * TC; i += (int)blockDim.x)
           tile[addr_tile<CW>(i % TC, -32 + i / TC)] = INFINITY;
@@ -262,13 +281,17 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         BL.band = wave * (64 / TC) + lane / TC;
         BL.row0 = BL.band * 32;
         BL.n = n;
-        BL.nzw = alive[addr_word<CW>(BL.col, BL.band)];
         BL.rsw = rsp[addr_word<CW>(BL.col, BL.band)];
+        BL.brk = alive[addr_word<CW>(BL.col, BL.band)];
+        const uint32_t bs = bscan[addr_word<CW>(BL.col, BL.band)];
+        BL.blo_in = (int)(bs & 0xFFFFu) - 1;
+        BL.bhi_out = (int)(bs >> 16);
         const uint32_t lh = lohi[addr_word<CW>(BL.col, BL.band)];
         BL.lo_in = (int)(lh & 0xFFFFu) - 1;
         BL.hi_out = (int)(lh >> 16) - 1;
         BL.w2 = L.w2;
         BL.w2f = w * w;
+        BL.live = BL.col < cols_left && BL.band < NB;
         const bool colok = BL.col < cols_left;
         float *dst0;        // row 0 of this band's rows, this lane's column
         int64_t dstride;
@@ -282,8 +305,8 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         auto store = [&](int row, float v) {
           if (row < n && colok) dst0[(int64_t)row * dstride] = v;
         };
-        if (ba.x32) brute_band<CW, BB, true>(BL, ba.tab, epi, store);
-        else brute_band<CW, BB, false>(BL, ba.tab, epi, store);
+        if (ba.x32) brute_band<CW, BB, true>(BL, epi, store);
+        else brute_band<CW, BB, false>(BL, epi, store);
         return;
       }
     }
@@ -393,17 +416,18 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   constexpr int NBP = 64 / CW;
   using TG = edt_lane::TileGeom<CW>;
   constexpr int TC = TG::kCols;
-  size_t lds = (size_t)NBP * TG::kBandFloats * sizeof(float) + 2 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t) + 16;
-  if (XF) lds += (size_t)33 * NBP * sizeof(edt_lane::XRowMeta) + (size_t)(xf.idx_inf + 1) * sizeof(float);
-  else lds += 2 * (size_t)TG::kBandFloats * sizeof(float) + (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
+  size_t lds = (size_t)NBP * TG::kBandFloats * sizeof(float) + 2 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
+  if (XF) lds += 16 + (size_t)33 * NBP * sizeof(edt_lane::XRowMeta) + (size_t)(xf.idx_inf + 1) * sizeof(float);
+  else lds += 2 * (size_t)TG::kBandFloats * sizeof(float) + 2 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
   // the windowed path (edt_colwave_lane.h: brute_band): tiles whose largest field value is at most c_T
   BruteArgs ba;
   ba.limit_bits = 0u;
   ba.x32 = 0;
-  if (!XF && !(debug_mode() & 0x2000) && w > 0.0f && (double)w * (double)w < 1.0e30) {
+  ba.force = 0;
+  if (!XF && !(debug_mode() & 0x2000) && w * w >= 1.17549435e-38f && (double)w * (double)w < 1.0e30) {
     const bool force = (debug_mode() & 0x4000) != 0;
     const int T = force ? (int)g.n : window_limit();
-    bool x32 = edt_lane::brute_tab_fill(ba.tab, w, T);
+    bool x32 = edt_lane::brute_exact32(w, T);
     if (debug_mode() & 0x8000) x32 = false;  // diagnostics: fp64 candidates
     ba.x32 = x32 ? 1 : 0;
     const double cT = (double)(w * w) * (double)T * (double)T;
@@ -412,15 +436,11 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
     uint32_t bits;
     memcpy(&bits, &lim, 4);
     ba.limit_bits = force ? 0x7f800000u : bits;  // (forced: every tile, whatever it holds)
-    ba.flat_div = force ? 0x10000 : window_flat_div();
+    ba.force = force ? 1 : 0;
     if (T < 1) ba.limit_bits = 0u;
   }
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF, SC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
+  EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF, SC>)));
   const int64_t tiles_x = ceil_div(g.sx, TC);
   int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;

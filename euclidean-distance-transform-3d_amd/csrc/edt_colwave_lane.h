@@ -710,25 +710,26 @@ EDT_LANE void phase3_eval(const Lane &L, uint32_t aw, float *f, int epi) {
 constexpr int kBruteK = 32;  // register window radius = the rows of +inf padding on either side of the tile
 constexpr int kBruteB = 8;   // rows per block
 
-struct BruteTab {
-  float c32[kBruteK + 1];   // c_d rounded towards zero to fp32 (exact when x32): exit test, X32 candidates
-  double c64[kBruteK + 1];  // c_d = w2 * d^2, exact
-};
-
 struct BruteLane {
   const float *tile;  // LDS tile, row 0 (one band of +inf rows on either side; rows >= n are +inf)
   int col;            // column inside the workgroup tile
   int band, row0, n;
-  uint32_t nzw, rsw;  // foreground / run-start bits of the band (0 for a lane without a column)
+  uint32_t rsw;       // run-start bits of the band (0 for a lane without a column)
+  uint32_t brk;       // bit r: row r continues a run and is NOT flat against row r-1 (a "break")
+  int blo_in;         // last break row in an earlier band of the column (-1: none)
+  int bhi_out;        // first break row in a later band (>= n: none)
   int lo_in, hi_out;  // as in Lane
+  bool live;          // the lane has a column (else its LDS words are whatever was there)
   double w2;
   float w2f;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define EDT_ANY(cond) (__ballot(cond) != 0ull)
+#define EDT_OPAQUE(x) asm volatile("" : "+v"(x))
 #else
 #define EDT_ANY(cond) (cond)
+#define EDT_OPAQUE(x) ((void)0)
 #endif
 
 EDT_LANE uint32_t f2u(float v) { uint32_t u; memcpy(&u, &v, 4); return u; }
@@ -737,13 +738,99 @@ EDT_LANE float minpos(float a, float b) {  // min of two non-negative floats (or
   const uint32_t ua = f2u(a), ub = f2u(b);
   return u2f(ua < ub ? ua : ub);
 }
+EDT_LANE float min3pos(float a, float b, float c) {
+  uint32_t ua = f2u(a);
+  const uint32_t ub = f2u(b), uc = f2u(c);
+  ua = ua < ub ? ua : ub;
+  return u2f(ua < uc ? ua : uc);
+}
+
+// Flat blocks need no window at all.  If every link (row r-1 -> r inside a run) at distance <= D around the
+// block is flat, then for rows p, j of one run with |p-j| <= D:  F[j] >= F[p] - w2*|p-j| >= F[p] - c_|p-j|,
+// i.e. no row within D improves p; rows further away cannot either once c_(D+1) >= B_p.  Returns D for the
+// block of rows k0..k0+7: the distance to the nearest break of the whole column (breaks of other bands come
+// from the same kind of scan over the bands as the run structure).
+EDT_LANE int brute_flat_reach(const BruteLane &L, int k0) {
+  const uint32_t lowm = L.brk & (0xFFFFFFFFu >> (24 - k0));  // breaks at rows <= k0+7 of this band
+  const int h = lowm ? L.row0 + 31 - clz32(lowm) : L.blo_in;
+  const uint32_t him = k0 + kBruteB < 32 ? L.brk & (0xFFFFFFFFu << (k0 + kBruteB)) : 0u;
+  const int l = him ? L.row0 + ctz32(him) : L.bhi_out;
+  const int p0 = L.row0 + k0;
+  const int dlo = h >= 0 ? p0 - h : 4095;
+  const int dhi = l < L.n ? l - p0 - kBruteB : 4095;  // (bhi_out >= n: no break above)
+  const int d = dlo < dhi ? dlo : dhi;
+  return d > 0 ? d : 0;
+}
+
+// The steps of the window as a compile-time recursion (every index into the register window is static):
+// steps D and D+1 share one exit test; past the register-resident part the rows come straight from the tile.
+template <int CW, bool X32>
+struct BruteSteps {
+  static constexpr int K = kBruteK, B = kBruteB, TC = TileGeom<CW>::kCols;
+  const BruteLane &L;
+  float (&w)[B + 2 * K];
+  float (&best)[B];
+  double (&best64)[B];
+  const float *PL0, *PL1, *PH0, *PH1;
+  int k0;
+  float bmaxf;
+  double bmax64;
+  int nb32;
+  float w2f;   // per-block copies of L.w2f / L.w2 (see brute_band: keeps the c_d next to their use)
+  double w2;
+
+  template <int D>
+  EDT_LANE_MEMBER void run() {
+    if constexpr (D < K) {
+      // c_d = w2 * d^2: in X32 mode exactly representable, so the fp32 product is it
+      const float c1f = w2f * (float)(D * D), c2f = w2f * (float)((D + 1) * (D + 1));
+      const double c1 = w2 * (double)(D * D), c2 = w2 * (double)((D + 1) * (D + 1));
+      if (X32 ? !EDT_ANY(c1f < bmaxf) : !EDT_ANY(c1 < bmax64)) return;
+      // the rows that enter the window in these two steps
+      w[K - D] = (D <= k0 ? PL0 : PL1)[(K - D) * TC];
+      w[K + B - 1 + D] = (D <= 32 - B - k0 ? PH0 : PH1)[D * TC];
+      w[K - D - 1] = (D + 1 <= k0 ? PL0 : PL1)[(K - D - 1) * TC];
+      w[K + B + D] = (D + 1 <= 32 - B - k0 ? PH0 : PH1)[(D + 1) * TC];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int ii = 0; ii < B; ++ii) {
+        // (the first and the last row of the block need the rows just requested: they come last)
+        const int i = ii < B - 2 ? ii + 1 : (ii == B - 2 ? 0 : B - 1);
+        const float m1 = minpos(w[K + i - D], w[K + i + D]);
+        const float m2 = minpos(w[K + i - D - 1], w[K + i + D + 1]);
+        // (sums of non-negative terms: integer minima, no canonicalisation of the operands)
+        if (X32) best[i] = min3pos(best[i], m1 + c1f, m2 + c2f);
+        else best64[i] = fmin(best64[i], fmin((double)m1 + c1, (double)m2 + c2));
+      }
+      run<D + 2>();
+    } else {
+      for (int d = K + 1; d < 4096; ++d) {
+        const double cd = w2 * (double)(d * d);  // exact
+        const float cdf = (float)cd;             // (X32: exact as well)
+        if (!EDT_ANY(cd < bmax64)) break;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < B; ++i) {
+          int rl = L.row0 + k0 + i - d, rh = L.row0 + k0 + i + d;
+          rl = rl < -1 ? -1 : rl;        // row -1 and row nb32 are +inf rows
+          rh = rh > nb32 ? nb32 : rh;
+          const float m = minpos(L.tile[addr_tile<CW>(L.col, rl)], L.tile[addr_tile<CW>(L.col, rh)]);
+          if (X32) best[i] = minpos(best[i], m + cdf);
+          else best64[i] = fmin(best64[i], (double)m + cd);
+        }
+      }
+    }
+  }
+};
 
 template <int CW, bool BB, bool X32, class Store>
-EDT_LANE void brute_band(const BruteLane &L, const BruteTab &tab, int epi, Store &&store) {
+EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
   constexpr int K = kBruteK, B = kBruteB, TC = TileGeom<CW>::kCols;
   constexpr int kFar = 1 << 14;
   const int row0 = L.row0, n = L.n;
-  const uint32_t rsw = L.rsw, nzw = L.nzw;
+  const uint32_t rsw = L.rsw;
   // the lane's column in its own band and in the bands below / above (the band rotation of the tile
   // differs from band to band; inside a band rows are TC floats apart)
   const float *A0 = L.tile + addr_tile<CW>(L.col, row0);
@@ -762,25 +849,27 @@ EDT_LANE void brute_band(const BruteLane &L, const BruteTab &tab, int epi, Store
     // rows below k0 come from this band while d <= k0, from the band below afterwards; likewise above
     const float *PL0 = A0 + (k0 - K) * TC, *PL1 = Am + (k0 + 32 - K) * TC;
     const float *PH0 = A0 + (k0 + B - 1) * TC, *PH1 = Ap + (k0 + B - 1 - 32) * TC;
-    // ---- B_p of the block's rows ----
-    int a;  // first row of the run the current row belongs to
+    // ---- B_p of the block's rows: distances to the border sites, counted from run start to run start ----
+    const uint32_t s8 = rsw >> k0;  // bit i: a run starts at row k0 + i
+    int dl;  // distance of the current row to the row before its run (>= kFar: none)
     {
       const uint32_t m = rsw & ((1u << k0) - 1u);
-      a = m ? row0 + 31 - clz32(m) : L.lo_in;
+      const int a = m ? row0 + 31 - clz32(m) : L.lo_in;  // start of the run that is open at k0
+      dl = (BB || a > 0) ? row0 + k0 - a : kFar;
     }
     int dlv[B];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int i = 0; i < B; ++i) {
-      const int row = row0 + k0 + i;
-      if ((rsw >> (k0 + i)) & 1u) a = row;
-      dlv[i] = (BB || a > 0) ? row - a + 1 : kFar;
+      dl = ((s8 >> i) & 1u) ? ((BB || row0 + k0 + i > 0) ? 1 : kFar) : dl + 1;
+      dlv[i] = dl;
     }
-    int e;  // first row of the next run
+    int dr;  // distance to the first row of the next run, as seen from the row above the block
     {
       const uint32_t m = k0 + B < 32 ? rsw & (0xFFFFFFFFu << (k0 + B)) : 0u;
-      e = m ? row0 + ctz32(m) : L.hi_out + 1;
+      const int e = m ? row0 + ctz32(m) : L.hi_out + 1;
+      dr = (BB || e < n) ? e - (row0 + k0 + B) : kFar;
     }
     float best[B];
     double best64[B];
@@ -789,61 +878,42 @@ EDT_LANE void brute_band(const BruteLane &L, const BruteTab &tab, int epi, Store
 #pragma unroll
 #endif
     for (int i = B - 1; i >= 0; --i) {
-      const int row = row0 + k0 + i;
-      const int drv = (BB || e < n) ? e - row : kFar;
-      const int dmi = dlv[i] < drv ? dlv[i] : drv;
+      dr += 1;
+      const int dmi = dlv[i] < dr ? dlv[i] : dr;
       const float dm = (float)dmi;
-      // fl32(w2 * d^2) is one exact-product fp32 multiply (as in phase3_eval)
+      // fl32(w2 * d^2) is one exact-product fp32 multiply (as in phase3_eval); background rows hold 0
       const float bord = dmi < kFar ? L.w2f * (dm * dm) : INFINITY;
       float b = minpos(w[K + i], bord);
-      if (!((nzw >> (k0 + i)) & 1u)) b = 0.0f;
+      // rows that complete the last band (no real row holds +inf) and lanes without a column
+      if (f2u(w[K + i]) == 0x7f800000u || !L.live) b = 0.0f;
       best[i] = b;
       if (!X32) best64[i] = (double)b;
       const uint32_t ub = f2u(b);
       bmax = ub > bmax ? ub : bmax;
-      if ((rsw >> (k0 + i)) & 1u) e = row;
+      if ((s8 >> i) & 1u) dr = (BB || row0 + k0 + i < n) ? 0 : kFar;
     }
     const float bmaxf = u2f(bmax);
-    // ---- the window, unrolled over the register-resident part ----
+    const double bmax64 = (double)bmaxf;
+    // ---- flat neighbourhood: nothing within reach can improve any row of the wave's blocks ----
     bool open = true;  // some row of the wave may still improve
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int d = 1; d <= K; ++d) {
-      if (!EDT_ANY(tab.c32[d] < bmaxf)) { open = false; break; }
-      // the two rows that enter the window in this step are needed by the first and the last row of the
-      // block only: those come last, the six rows in between cover the latency of the two reads
-      w[K - d] = (d <= k0 ? PL0 : PL1)[(K - d) * TC];
-      w[K + B - 1 + d] = (d <= 32 - B - k0 ? PH0 : PH1)[d * TC];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-      for (int ii = 0; ii < B; ++ii) {
-        const int i = ii < B - 2 ? ii + 1 : (ii == B - 2 ? 0 : B - 1);
-        const float m = minpos(w[K + i - d], w[K + i + d]);
-        // (sums of non-negative terms: integer min again, no canonicalisation of the operands)
-        if (X32) best[i] = minpos(best[i], m + tab.c32[d]);
-        else best64[i] = fmin(best64[i], (double)m + tab.c64[d]);
-      }
+    EDT_STAT(13, k0, 1);
+    {
+      const int D = brute_flat_reach(L, k0);
+      const double cD = L.w2 * (double)((D + 1) * (D + 1));
+      if (!EDT_ANY(cD < bmax64)) open = false;
     }
-    // ---- windows beyond the register-resident part (rare): straight from the tile ----
+    // ---- the window: register-resident part (two steps per exit test), then straight from the tile ----
     if (open) {
-      for (int d = K + 1; d < 4096; ++d) {
-        const double cd = L.w2 * (double)(d * d);  // exact
-        const float cdf = X32 ? (float)cd : u2f(f2u((float)cd) - 1u);  // (not above c_d)
-        if (!EDT_ANY(cdf < bmaxf)) break;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int i = 0; i < B; ++i) {
-          int rl = row0 + k0 + i - d, rh = row0 + k0 + i + d;
-          rl = rl < -1 ? -1 : rl;        // row -1 and row nb32 are +inf rows
-          rh = rh > nb32 ? nb32 : rh;
-          const float m = minpos(L.tile[addr_tile<CW>(L.col, rl)], L.tile[addr_tile<CW>(L.col, rh)]);
-          if (X32) best[i] = minpos(best[i], m + cdf);
-          else best64[i] = fmin(best64[i], (double)m + cd);
-        }
-      }
+      EDT_STAT(12, k0, 1);
+      // The c_d = w2 * d^2 are wave-uniform but live in vector registers (no scalar fp multiply); hoisted
+      // out of the block loop all 32 of them would stay alive across it.  An opaque copy of w2 per block
+      // keeps each product in the step that uses it.
+      float w2f = L.w2f;
+      double w2 = L.w2;
+      EDT_OPAQUE(w2f);
+      EDT_OPAQUE(w2);
+      BruteSteps<CW, X32> S{L, w, best, best64, PL0, PL1, PH0, PH1, k0, bmaxf, bmax64, nb32, w2f, w2};
+      S.template run<1>();
     }
     // ---- epilogue (src/edt.hpp:47-53, :599-601) and the rows leave ----
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -867,23 +937,15 @@ EDT_LANE void brute_band(const BruteLane &L, const BruteTab &tab, int epi, Store
   }
 }
 
-// c_d tables of the windowed path and the largest window it may use: `x32` reports whether every c_d
-// up to `want` is exactly representable in fp32 (then candidates are fp32 sums)
-inline bool brute_tab_fill(BruteTab &t, float w, int want) {
+// Is c_d = w2 * d^2 exactly representable in fp32 for every d up to `want` (then the candidates of the
+// windowed path are fp32 sums)?
+inline bool brute_exact32(float w, int want) {
   const double w2 = (double)(w * w);
-  bool x32 = true;
   for (int d = 1; d <= want; ++d) {
     const double c = w2 * (double)d * (double)d;
-    if ((double)(float)c != c || !(c < 3.0e38)) x32 = false;
+    if ((double)(float)c != c || !(c < 3.0e38)) return false;
   }
-  for (int d = 0; d <= kBruteK; ++d) {
-    const double c = w2 * (double)d * (double)d;
-    float f = c < 3.0e38 ? (float)c : 3.0e38f;
-    if ((double)f > c) f = nextafterf(f, 0.0f);
-    t.c32[d] = f;
-    t.c64[d] = c;
-  }
-  return x32;
+  return true;
 }
 
 }  // namespace edt_lane

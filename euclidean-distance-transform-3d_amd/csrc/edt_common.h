@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cfloat>
 #include <cstdint>
 #include <cstdio>
@@ -31,6 +32,24 @@ int debug_mode();  // edt_hip_set_debug_mode(): bit0 = column pass moves data on
       return EDT_ERR_HIP;                                                              \
     }                                                                                  \
   } while (0)
+
+// Kernels that need more than 64 KiB of dynamic LDS must be given the attribute once per kernel AND per
+// device (a host process may drive several GPUs from several threads): `done` is the call site's static
+// mask, one bit per device ordinal.  Evaluates to hipSuccess or the failing call's error.
+#define EDT_LDS_ATTR_ONCE(done, ...)                                                            \
+  [&]() -> hipError_t {                                                                         \
+    int dev_ = 0;                                                                               \
+    hipError_t e_ = hipGetDevice(&dev_);                                                        \
+    if (e_ != hipSuccess) return e_;                                                            \
+    const uint64_t bit_ = 1ull << (dev_ & 63);                                                  \
+    if ((done).load(std::memory_order_acquire) & bit_) return hipSuccess;                       \
+    for (const void *f_ : {__VA_ARGS__}) {                                                      \
+      e_ = hipFuncSetAttribute(f_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      if (e_ != hipSuccess) return e_;                                                          \
+    }                                                                                           \
+    (done).fetch_or(bit_, std::memory_order_release);                                           \
+    return hipSuccess;                                                                          \
+  }()
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

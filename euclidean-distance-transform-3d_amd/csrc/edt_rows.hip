@@ -196,14 +196,9 @@ static int launch_row_tiled_t(const void *labels, float *out, uint32_t *nz_y, ui
   if (ngroups <= 0) return EDT_OK;
   const size_t lds = (size_t)((sx + 2 + 3) & ~3) * sizeof(float) +
                      (size_t)kWavesPerBlock * 32 * NC * 24;
-  static bool attr_done = false;
-  if (!attr_done) {
-    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_pass_tiled<T, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_pass_tiled<T, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
+  EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_row_pass_tiled<T, true>),
+                                reinterpret_cast<const void *>(&k_row_pass_tiled<T, false>)));
   int64_t blocks = ceil_div(ngroups, kWavesPerBlock);
   const int64_t resident = 256 * 6;  // persistent grid: the T table is built once per block
   if (blocks > resident) blocks = resident;

@@ -388,12 +388,8 @@ static int launch_tiled_ceb(float *F, const uint32_t *nz, const uint32_t *rs, co
                             float w, hipStream_t stream) {
   const int NB = (int)g.nbands;
   const size_t lds = (size_t)NB * C * (32 * sizeof(float) + 2 * sizeof(uint32_t));
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    EDT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_column_pass_tiled<C, EPI, BB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
+  EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_tiled<C, EPI, BB>)));
   const int64_t tiles_x = ceil_div(g.sx, C);
   const int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;

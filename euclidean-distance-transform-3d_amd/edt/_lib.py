@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("EDT_HIP_LIB") or os.path.join(os.path.dirname(_HERE),
 
 # dtype codes of include/edt_hip.h
 U8, U16, U32, U64, F32, F64, BOOL = range(7)
+DTYPE_SIZE = {U8: 1, U16: 2, U32: 4, U64: 8, F32: 4, F64: 8, BOOL: 1}
 
 FLAG_BLACK_BORDER = 1
 FLAG_SQRT = 2
@@ -46,6 +47,7 @@ SIGNATURES = {
     "edt_hip_edt2dsq_voxel_graph": (_i, [_vp, _i, _vp, _i64, _i64, _f, _f, _i, _vp]),
     "edt_hip_edt3dsq_voxel_graph": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _f, _f, _f, _i, _vp]),
     "edt_hip_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i64]),
+    "edt_hip_workspace_bytes_flags": (_sz, [_i, _i, _i64, _i64, _i64, _i]),
     "edt_hip_edtsq_device": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _vp, _vp, _sz, _vp]),
     "edt_hip_set_profiling": (_i, [_i]),
     "edt_hip_set_debug_mode": (_i, [_i]),

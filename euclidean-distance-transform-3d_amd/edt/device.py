@@ -53,7 +53,16 @@ class Plan:
         if nbytes == 0:
             _lib.check(-2)
         self.workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self._generic_ws = None  # the size-agnostic kernels need a second volume: allocated on first use
         self.voxels = int(np.prod(self.ext))
+
+    def _workspace_for(self, flags):
+        if not (flags & _lib.FLAG_FORCE_GENERIC):
+            return self.workspace
+        if self._generic_ws is None:
+            nbytes = self.lib.edt_hip_workspace_bytes_flags(self.code, self.ndim, *self.ext, flags)
+            self._generic_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._generic_ws
 
     def run(self, labels: torch.Tensor, weights_xyz, black_border=False, sqrt=False,
             out: torch.Tensor | None = None, force_generic=False) -> torch.Tensor:
@@ -62,15 +71,19 @@ class Plan:
             raise ValueError("labels must be a contiguous device tensor")
         if labels.numel() != self.voxels:
             raise ValueError("labels size does not match the plan")
+        # (same-width integer views are how uint32 / uint64 labels reach torch builds without those dtypes)
+        if labels.element_size() != _lib.DTYPE_SIZE[self.code] or (
+                labels.dtype.is_floating_point != (self.code in (_lib.F32, _lib.F64))):
+            raise TypeError(f"labels dtype {labels.dtype} does not match the plan's dtype code {self.code}")
         if out is None:
             out = torch.empty(labels.shape, dtype=torch.float32, device=labels.device)
         w = tuple(float(np.float32(v)) for v in weights_xyz) + (1.0,) * (3 - self.ndim)
         flags = ((_lib.FLAG_BLACK_BORDER if black_border else 0) | (_lib.FLAG_SQRT if sqrt else 0)
                  | (_lib.FLAG_FORCE_GENERIC if force_generic else 0))
+        ws = self._workspace_for(flags)
         rc = self.lib.edt_hip_edtsq_device(
             ctypes.c_void_p(labels.data_ptr()), self.code, self.ndim, *self.ext, w[0], w[1], w[2],
-            flags, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(self.workspace.data_ptr()),
-            self.workspace.numel(), _stream_ptr())
+            flags, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr())
         _lib.check(rc)
         return out
 
@@ -79,7 +92,9 @@ _plans: dict = {}
 
 
 def _plan_for(ext, code, device) -> Plan:
-    key = (tuple(ext), code, str(device))
+    # one plan (= one scratch buffer) per stream: transforms of one shape issued on different streams
+    # must not share scratch, and a workspace is only ever used on the stream it was allocated on
+    key = (tuple(ext), code, str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _plans:
         if len(_plans) > 8:
             _plans.clear()

@@ -373,80 +373,3 @@ def global_extents(world: int, edge: int = 512):
         k //= 2
     ext[2] *= k  # odd remainder: stack along z
     return tuple(ext)
-
-
-def bench_main(args, rank, world, dev):
-    ext = global_extents(world, args.size)
-    an, bb = (6.0, 6.0, 30.0), True
-    plan = ShardedEDT(ext, _lib.U32)
-    zs, ze = plan.local_z()
-    labels = torch.ones((ze - zs, ext[1], ext[0]), dtype=torch.int32, device=dev)
-
-    def step():
-        return plan.run(labels, an, black_border=bb)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-
-    # per-kernel durations of one more step (hipEvents inside the library, this rank's stream)
-    from . import device
-    acc = {}
-    for _ in range(3):
-        device.set_profiling(True)
-        step()
-        torch.cuda.synchronize()
-        for name, ms in device.pass_times():
-            acc.setdefault(name, []).append(ms)
-    device.set_profiling(False)
-    kernel_ms = {k: float(np.sum(v)) / 3 for k, v in acc.items()}  # chunks of a step add up
-    dist.barrier()
-
-    # correctness of the timed output: closed form of the all-ones box on this rank's y-slab
-    ys, ye = plan.local_y()
-    idx = [torch.arange(e, device=dev, dtype=torch.float64) for e in ext]
-    d = [torch.minimum(i + 1, e - i) * w for i, e, w in zip(idx, ext, an)]
-    want = torch.minimum(torch.minimum((d[2] ** 2)[:, None, None], (d[1][ys:ye] ** 2)[None, :, None]),
-                         (d[0] ** 2)[None, None, :]).to(torch.float32)
-    ok = torch.tensor([1 if torch.equal(out, want) else 0], device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-
-    if rank == 0:
-        vox = ext[0] * ext[1] * ext[2]
-        # roofline of the dominant kernel ON ONE RANK: its algorithmic bytes (X reads
-        # labels + writes fp32; Y and Z read labels + read / write fp32) over its summed duration
-        bpv = {"x_pass": 4 + 4, "y_pass": 4 + 8, "z_pass": 4 + 8}
-        roofline = None
-        if any(k in kernel_ms for k in bpv):
-            dom = max((k for k in kernel_ms if k in bpv), key=lambda k: kernel_ms[k])
-            achieved = bpv[dom] * (vox / world) / (kernel_ms[dom] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
-                        "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
-                        "note": "per rank; the exchange is not a kernel of this library and is not listed"}
-        print(json.dumps({
-            "metric": "Mvox/s edt3dsq 512^3 uint32", "value": round(vox / (elapsed / args.steps) / 1e6, 1),
-            "unit": "Mvox/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 envelope / f32 storage / u32 labels", "data": "synthetic",
-            "config": {"workload": f"one {ext[0]}x{ext[1]}x{ext[2]} uint32 volume ({args.size}^3 voxels per GPU), "
-                                   f"anisotropy {an}, black_border={bb}, Z-sharded over {world} GPUs, "
-                                   "one all-to-all (Z-slabs -> Y-slabs) before the z pass",
-                       "form": "slab records" if plan.records else "byte flags",
-                       "chunks": getattr(plan, "nchunks", 1),
-                       "output_verified": bool(ok.item())},
-            "roofline": roofline,
-        }))
-    dist.destroy_process_group()

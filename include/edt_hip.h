@@ -111,8 +111,12 @@ int edt_hip_release_cache(void);
  * allocation), so they can be timed with events and captured into a hipGraph.
  */
 
-/* bytes of scratch edt_hip_edtsq_device needs for a volume of this shape */
+/* bytes of scratch edt_hip_edtsq_device needs for a volume of this shape: the bit planes of the column
+ * passes (5/32 of a byte per voxel and plane -- about 0.16 GiB for 1024^3).  Only a call that has to use
+ * the size-agnostic column kernels (an axis longer than 4095 voxels, or EDT_FLAG_FORCE_GENERIC) needs a
+ * second fp32 volume and the hull stacks as well (+ 8 bytes per voxel): ask with the flags of the call. */
 size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz);
+size_t edt_hip_workspace_bytes_flags(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags);
 
 /* ndim in {1,2,3}; unused extents must be 1.  flags: EDT_FLAG_*.  d_output may not alias
  * d_labels.  Implements _edt3dsq / _edt2dsq / squared_edt_1d_multi_seg (+ optional sqrt). */

@@ -15,6 +15,7 @@
 #include <vector>
 
 #define EDT_LANE static inline
+#define EDT_LANE_MEMBER inline
 #include "edt_colwave_lane.h"
 
 // tests/lane_stats.cpp sets this to tell its counters which lane is running
@@ -121,21 +122,32 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
   // mode 0: hulls only; 1 / 2: every tile takes the windowed path (fp32 candidates when exact / fp64
   // candidates); 3: the kernel's per-tile choice (field small everywhere -> windowed path)
   if (mode != 0 && meta == nullptr) {
-    BruteTab tab;
-    const int want = mode == 3 ? 64 : n;
-    bool x32 = brute_tab_fill(tab, w, want);
+    const int want = mode == 3 ? 96 : n;
+    bool x32 = brute_exact32(w, want);
     if (mode == 2) x32 = false;
     bool take = true;
     if (mode == 3) {
       float fmaxv = 0.0f;
       for (auto &P : lanes)
-        if (P.L.colc < cols_left)
-          for (int r = 0; r < 32; ++r)
-            if (P.L.row0 + r < n && ((P.L.nzw >> r) & 1u)) fmaxv = std::max(fmaxv, P.f[r]);
-      const double cT = (double)(w * w) * 64.0 * 64.0;
+        if (P.L.colc < cols_left && P.L.band < NB)
+          for (int r = 0; r < 32; ++r) fmaxv = std::max(fmaxv, P.f[r]);
+      const double cT = (double)(w * w) * 96.0 * 96.0;
       take = (double)fmaxv <= cT;
     }
     if (take) {
+      // the links that are not flat (the kernel: alive plane)
+      auto lane_at = [&](int colc, int band) -> PerLane * {
+        for (auto &Q : lanes)
+          if (Q.L.colc == colc && Q.L.band == band) return &Q;
+        return nullptr;
+      };
+      std::vector<uint32_t> brk((size_t)NBP * TC, 0);
+      for (auto &P : lanes) {
+        PerLane *below = lane_at(P.L.colc, P.L.band - 1);
+        const uint32_t fl0 = flat_word(P.L, P.f, below ? below->f[31] : 0.0f);
+        const uint32_t need = P.L.nzw & ~(P.L.rsw | (P.L.band == 0 ? 1u : 0u));
+        brk[(size_t)P.L.band * TC + P.L.colc] = need & ~fl0;
+      }
       // +inf around the column: the padding bands and the rows that complete the last band
       for (int row = -32; row < (NB + 1) * 32; ++row)
         if (row < 0 || row >= n)
@@ -143,16 +155,24 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
       std::vector<float> res((size_t)NBP * 32 * TC, 0.0f);
       for (int band = 0; band < NBP; ++band)
         for (int col = 0; col < TC; ++col) {
-          PerLane *P = nullptr;
-          for (auto &Q : lanes)
-            if (Q.L.colc == col && Q.L.band == band) P = &Q;
+          PerLane *P = lane_at(col, band);
           BruteLane BL;
           BL.tile = tile; BL.col = col; BL.band = band; BL.row0 = band * 32; BL.n = n;
-          BL.nzw = P->L.nzw; BL.rsw = P->L.rsw; BL.lo_in = P->L.lo_in; BL.hi_out = P->L.hi_out;
+          BL.rsw = P->L.rsw; BL.lo_in = P->L.lo_in; BL.hi_out = P->L.hi_out;
+          BL.brk = brk[(size_t)band * TC + col];
+          BL.blo_in = -1;  // the kernel: a scan over the bands of the column
+          BL.bhi_out = n;
+          for (int b2 = 0; b2 < NBP; ++b2) {
+            const uint32_t wd = brk[(size_t)b2 * TC + col];
+            if (!wd) continue;
+            if (b2 < band) BL.blo_in = std::max(BL.blo_in, b2 * 32 + 31 - __builtin_clz(wd));
+            if (b2 > band) BL.bhi_out = std::min(BL.bhi_out, b2 * 32 + __builtin_ctz(wd));
+          }
+          BL.live = col < cols_left && band < NB;
           BL.w2 = (double)(w * w); BL.w2f = w * w;
           auto store = [&](int row, float v) { res[(size_t)row * TC + col] = v; };
-          if (x32) brute_band<CW, BB, true>(BL, tab, epi, store);
-          else brute_band<CW, BB, false>(BL, tab, epi, store);
+          if (x32) brute_band<CW, BB, true>(BL, epi, store);
+          else brute_band<CW, BB, false>(BL, epi, store);
         }
       for (int row = 0; row < n; ++row)
         for (int c = 0; c < TC && c < cols_left; ++c) F[x0 + (int64_t)row * stride + c] = res[(size_t)row * TC + c];

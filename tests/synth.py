@@ -61,6 +61,21 @@ def voronoi_labels(shape, nseeds, seed=0, upsample=4, membrane=0.0, dtype=np.uin
     return np.asfortranarray(lab.astype(dtype))
 
 
+def voronoi_coarse(coarse_shape, nseeds, seed=0, zrange=None, workers=-1):
+    """Nearest-seed labels (1..nseeds, uint32, Fortran order) on a coarse grid, optionally only the
+    z-range [z0, z1) of it -- the ranks of a Z-sharded run build just their own slab of ONE global
+    segmentation (BASELINE configs[3]: 16 000 seeds on 256^3, up-sampled x4 afterwards)."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    pts = rng.random((nseeds, 3)) * np.array(coarse_shape)
+    z0, z1 = (0, coarse_shape[2]) if zrange is None else zrange
+    gx, gy, gz = np.meshgrid(np.arange(coarse_shape[0]) + 0.5, np.arange(coarse_shape[1]) + 0.5,
+                             np.arange(z0, z1) + 0.5, indexing="ij")
+    g = np.stack([gx, gy, gz], -1).reshape(-1, 3)
+    idx = cKDTree(pts).query(g, workers=workers)[1]
+    return np.asfortranarray((idx + 1).astype(np.uint32).reshape(coarse_shape[0], coarse_shape[1], z1 - z0))
+
+
 def config_volume(name: str, n: int = 512):
     """The BASELINE.json configurations at edge length `n` (Fortran order, x fastest).
 
@@ -68,6 +83,7 @@ def config_volume(name: str, n: int = 512):
       cfg1: all-ones uint32, (1,1,1), black_border=True
       cfg2: all-ones uint32 single label, (6,6,30), black_border=True      <- headline metric
       cfg3: ~2000 (scaled with volume) random multi-labels, black_border=False
+      cfg4: the same kind of segmentation as configs[3] builds it (16 000 seeds at 1024^3), black_border=False
       cfg5: uint8 binary blobs, black_border=True
     """
     if name == "cfg1":
@@ -80,6 +96,13 @@ def config_volume(name: str, n: int = 512):
     if name == "cfg3m":  # same with thin zero membranes
         nseeds = max(8, int(round(2000 * (n / 512.0) ** 3)))
         return voronoi_labels((n, n, n), nseeds, seed=0, upsample=4, membrane=0.05), (6.0, 6.0, 30.0), False
+    if name == "cfg4":  # the 1024^3 segmentation of configs[3] (scaled with the volume), seed 1
+        nseeds = max(8, int(round(16000 * (n / 1024.0) ** 3)))
+        c = max(1, n // 4)
+        lab = voronoi_coarse((c, c, c), nseeds, seed=1)
+        for ax in range(3):
+            lab = lab.repeat(4, axis=ax)
+        return np.asfortranarray(lab[:n, :n, :n]), (1.0, 1.0, 1.0), False
     if name == "cfg5":
         rng = np.random.default_rng(5)
         up = 16 if n >= 64 else 4

@@ -46,7 +46,12 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.edt_hip_workspace_bytes(99, 3, 4, 4, 4) == 0
     assert lib.edt_hip_workspace_bytes(_lib.U32, 4, 4, 4, 4) == 0
     assert lib.edt_hip_workspace_bytes(_lib.U32, 2, 4, 4, 4) == 0
-    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 64, 64, 64) >= 64 * 64 * 64 * 4
+    # the wave / tiled kernels work in place: scratch = four bit planes (1/8 byte per voxel each) ...
+    assert 4 * 64 * 64 * 64 // 8 <= lib.edt_hip_workspace_bytes(_lib.U32, 3, 64, 64, 64) <= 4 * 64 * 64 * 64 // 8 + 4096
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 1024, 1024, 1024) <= (1 << 29) + 4096   # 0.5 GiB for 1024^3
+    # ... only the size-agnostic kernels need a second fp32 volume and the hull stacks
+    assert (lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 64, 64, 64, _lib.FLAG_FORCE_GENERIC)
+            >= 2 * 64 * 64 * 64 * 4)
     buf = np.zeros(8, dtype=np.uint32)
     out = np.zeros(8, dtype=np.float32)
     rc = lib.edt_hip_squared_edt_1d_multi_seg(buf.ctypes.data, _lib.U32, out.ctypes.data, 8, 2, 1.0, 0)

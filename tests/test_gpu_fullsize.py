@@ -1,0 +1,130 @@
+"""Full-size parity on the GPU (`-m gpu`): the BASELINE volumes against the COMPILED REFERENCE itself
+(oracle/_ref, built from the reference's sources by oracle/Makefile; it travels to the GPU box), run with
+every host thread -- not against our restatement.
+
+  * cfg3 / cfg3m (configs[2]): 512^3 uint32, ~2000 labels, black_border=False, (1,1,1) and (6,6,30)
+  * cfg4 (configs[3]) on ONE GPU: the 1024^3 segmentation
+  * cfg4-sized virtual ranks: 1024 x 1000 x 1016 cut into 8 uneven Z-slabs / Y-slabs,
+    every rank's two phases on one device, the "exchange" a device copy
+  * two host threads driving two streams with their own plans at the same time
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from synth import blocky_labels, config_volume, voronoi_labels
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_edtsq(oracle_ref, lab, an, bb):
+    return oracle_ref.edtsq(lab, an, bb, parallel=os.cpu_count() or 1)
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg3m"])
+def test_cfg3_512_against_compiled_reference(edt_gpu, oracle_ref, name):
+    import torch
+    from edt import device
+
+    lab, an, bb = config_volume(name, 512)
+    want = _ref_edtsq(oracle_ref, lab, an, bb)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).cuda()
+    got = device.edtsq(t, anisotropy=an[::-1], black_border=bb).cpu().numpy().T
+    assert np.array_equal(got, want)
+    # the host-buffer entry point (C ABI, numpy in / numpy out) on the same volume
+    assert np.array_equal(edt_gpu.edtsq(lab, anisotropy=an, black_border=bb), want)
+
+
+def test_cfg4_1024_single_gpu_against_compiled_reference(edt_gpu, oracle_ref):
+    import torch
+    from edt import device
+
+    lab, an, bb = config_volume("cfg4", 1024)
+    want = _ref_edtsq(oracle_ref, lab, an, bb)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).cuda()
+    del lab
+    got = device.edtsq(t, anisotropy=an[::-1], black_border=bb)
+    del t
+    assert np.array_equal(got.cpu().numpy().T, want)
+
+
+def test_uneven_1024_world8_virtual_ranks_against_compiled_reference(edt_gpu, oracle_ref):
+    """sz % 8 != 0 and sy % 8 != 0 at cfg4 size: ceil-sized leading slabs, y cut at multiples of 32 rows."""
+    import torch
+    from edt import _lib
+    from edt.distributed import HipOps, balanced_partition
+
+    shape = (1024, 1000, 1016)
+    sx, sy, sz = shape
+    world, chunks = 8, 4
+    rng = np.random.default_rng(8)
+    lab = np.asfortranarray(blocky_labels(shape, nlabels=60, zero_frac=0.03, block=24, rng=rng).astype(np.uint32))
+    an, bb = (1.0, 1.0, 1.0), False
+    want = _ref_edtsq(oracle_ref, lab, an, bb)
+    dev = torch.device("cuda", 0)
+    ops = HipOps()
+    assert ops.records_supported(_lib.U32, sx, sy, sz)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev)  # (sz, sy, sx), x fastest
+    del lab
+    words = -(-sy // 32)
+    zparts = balanced_partition(sz, world)
+    yparts = [(32 * a, min(32 * b, sy)) for a, b in balanced_partition(words, world)]
+    y_splits = [a for a, _ in yparts] + [sy]
+    rec = [ops.record_floats(sx, b - a) for a, b in yparts]
+    dst = [torch.full((sz, rec[h]), float("nan"), dtype=torch.float32, device=dev) for h in range(world)]
+    for r, (zs, ze) in enumerate(zparts):
+        halo = t[zs - 1] if r > 0 else None  # the previous rank's last slice
+        for c0, c1 in balanced_partition(ze - zs, chunks):
+            blocks = [dst[h][zs + c0:zs + c1] if h == r else
+                      torch.empty((c1 - c0, rec[h]), dtype=torch.float32, device=dev) for h in range(world)]
+            ops.xy_records(t[zs + c0:zs + c1], halo, _lib.U32, an, 0, y_splits, blocks)
+            for h in range(world):
+                if h != r:
+                    dst[h][zs + c0:zs + c1].copy_(blocks[h])  # the exchange
+            halo = t[zs + c1 - 1]
+    del t
+    got = np.empty((sz, sy, sx), dtype=np.float32)
+    for h, (ys, ye) in enumerate(yparts):
+        ops.z_records(dst[h], sx, ye - ys, an[2], 0)
+        got[:, ys:ye, :] = dst[h][:, :(ye - ys) * sx].reshape(sz, ye - ys, sx).cpu().numpy()
+    assert np.array_equal(got.T, want)
+
+
+def test_two_threads_two_streams_stay_bit_exact(edt_gpu, oracle_port):
+    """Two host threads enqueue transforms on their own streams with their own plans at the same time (what a
+    C++ host driving several GPUs, or several streams of one, does): no process-wide lock, no shared scratch."""
+    import torch
+    from edt import device
+
+    dev = torch.device("cuda", 0)
+    cases = []
+    for seed, shape, an, bb in ((1, (160, 144, 96), (6.0, 6.0, 30.0), True), (2, (128, 200, 72), (1.0, 1.0, 1.0), False)):
+        lab = voronoi_labels(shape, nseeds=50, seed=seed, upsample=4, membrane=0.03)
+        cases.append((lab, an, bb, oracle_port.edtsq(lab, an, bb)))
+    errors = []
+
+    def worker(idx):
+        try:
+            lab, an, bb, want = cases[idx]
+            torch.cuda.set_device(dev)
+            stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(stream):
+                t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev, non_blocking=False)
+                plan = device.Plan(lab.shape, 2, dev)
+                out = torch.empty(t.shape, dtype=torch.float32, device=dev)
+                for _ in range(40):
+                    plan.run(t, an, black_border=bb, out=out)
+                stream.synchronize()
+                if not np.array_equal(out.cpu().numpy().T, want):
+                    errors.append(f"thread {idx}: output differs from the oracle")
+        except Exception as e:  # pragma: no cover
+            errors.append(f"thread {idx}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors

@@ -82,3 +82,26 @@ def test_processes_sharing_one_gpu(world, shape, an, bb, sqrt, gather_back, reco
         assert p.exitcode == 0, "worker crashed"
     results = dict(q.get(timeout=5) for _ in range(world))
     assert results == {r: True for r in range(world)}
+
+
+def test_bench_sharded_leg_on_one_gpu():
+    """bench.py's N > 1 leg end to end (torch.distributed.run, 2 ranks sharing cuda:0 over gloo): the cfg4
+    segmentation generator per slab, the timed steps, and the bit-for-bit check of the gathered result against
+    the compiled reference -- what the driver's 8-GPU run does, minus RCCL."""
+    import json
+    import subprocess
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, EDT_BENCH_BACKEND="gloo", EDT_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["form"] == "slab records"
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libedt_ref.so")):
+        assert out["config"]["output_verified"] is True, out["config"]
+        assert out["cpu_baseline"]["kind"] == "reference"

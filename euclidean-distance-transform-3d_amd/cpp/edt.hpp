@@ -3,8 +3,10 @@
 // Same namespaces, function names, argument order and defaults as the reference header
 // (reference: src/edt.hpp:32-803 `namespace pyedt`, :805-954 `namespace edt`;
 // src/edt_voxel_graph.hpp:54-236), so existing callers -- including the reference's Cython
-// binding, which does `cdef extern from "edt.hpp" namespace "pyedt"` (src/edt.pyx:62-113) --
-// compile unchanged against this file.  Every template is a thin inline forwarder into the
+// binding, which does `cdef extern from "edt.hpp" namespace "pyedt"` (src/edt.pyx:62-87) and
+// `cdef extern from "edt_voxel_graph.hpp"` (:89-113; the sibling header of this directory) --
+// compile unchanged against the pair (tests/test_cython_dropin.py builds the unmodified edt.pyx
+// against them).  Every template is a thin inline forwarder into the
 // C ABI of include/edt_hip.h (link with -ledt_hip); the label type becomes a dtype code.
 //
 // Behaviour kept from the reference:

@@ -44,10 +44,6 @@ _DTYPE_CODE = {
 _UNSIGNED = {_lib.U8: np.uint8, _lib.U16: np.uint16, _lib.U32: np.uint32, _lib.U64: np.uint64}
 
 
-def nvl(val, default_val):
-    return default_val if val is None else val
-
-
 def _label_code(data: np.ndarray) -> int:
     try:
         return _DTYPE_CODE[data.dtype]
@@ -156,11 +152,11 @@ def _transform(data, anisotropy, black_border, parallel, voxel_graph, take_sqrt)
             "Voxel connectivity graph is only supported for 2D and 3D. Got {}.".format(dims))
 
     if dims == 1:
-        anisotropy = (nvl(anisotropy, 1.0),)
+        anisotropy = (1.0 if anisotropy is None else anisotropy,)
     elif dims == 2:
-        anisotropy = nvl(anisotropy, (1.0, 1.0))
+        anisotropy = (1.0, 1.0) if anisotropy is None else anisotropy
     elif dims == 3:
-        anisotropy = nvl(anisotropy, (1.0, 1.0, 1.0))
+        anisotropy = (1.0, 1.0, 1.0) if anisotropy is None else anisotropy
     else:
         raise TypeError(
             "Multi-Label EDT library only supports up to 3 dimensions got {}.".format(dims))
@@ -289,36 +285,62 @@ def erase(runs, image):
     return draw(0, runs, image)
 
 
+class _PerLabelImages:
+    """Sized iterable behind :func:`each`: one ``(label, image)`` pair per non-zero label, in ascending
+    label order, where ``image`` is ``dt`` on the label's voxels and 0 elsewhere.
+
+    The label volume is scanned ONCE into a run table (start, end, value per run, sorted by value); every
+    image is then painted run by run.  With ``reuse`` one canvas serves all labels: it is handed out
+    read-only and wiped along the same runs before the next label is painted."""
+
+    def __init__(self, labels, dt, reuse):
+        self._shape = labels.shape
+        self._order = "F" if labels.flags.f_contiguous else "C"
+        self._dt = _flat(dt)
+        self._reuse = reuse
+        flat = _flat(labels)
+        if flat.size == 0:
+            cuts = np.zeros(0, dtype=np.int64)
+            starts = ends = cuts
+        else:
+            cuts = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+            starts = np.concatenate(([0], cuts))
+            ends = np.concatenate((cuts, [flat.size]))
+        values = flat[starts]
+        keep = values != 0
+        starts, ends, values = starts[keep], ends[keep], values[keep]
+        by_value = np.argsort(values, kind="stable")           # runs of one label stay in memory order
+        self._starts, self._ends = starts[by_value], ends[by_value]
+        self._labels, first = np.unique(values[by_value], return_index=True)
+        self._bounds = np.append(first, values.size)            # runs of label i: [bounds[i], bounds[i+1])
+
+    def __len__(self):
+        return int(self._labels.size)
+
+    def _paint(self, canvas, i, source):
+        for s, e in zip(self._starts[self._bounds[i]:self._bounds[i + 1]].tolist(),
+                        self._ends[self._bounds[i]:self._bounds[i + 1]].tolist()):
+            canvas[s:e] = source[s:e] if source is not None else 0
+
+    def __iter__(self):
+        image = flat_image = None
+        for i, label in enumerate(self._labels.tolist()):
+            if image is None or not self._reuse:
+                image = np.zeros(self._shape, dtype=np.float32, order=self._order)
+                flat_image = _flat(image)
+            self._paint(flat_image, i, self._dt)
+            if not self._reuse:
+                yield label, image
+                continue
+            image.flags.writeable = False
+            yield label, image
+            image.flags.writeable = True
+            self._paint(flat_image, i, None)
+
+
 def each(labels, dt, in_place=False):
-    """Iterate ``(label, image)`` where image is ``dt`` restricted to that label
-    (src/edt.pyx:950-994; ``in_place`` reuses one read-only image)."""
-    labels = np.asarray(labels)
-    dt = np.asarray(dt)
-    all_runs = runs(labels)
-    order = "F" if labels.flags.f_contiguous else "C"
-
-    class ImageIterator:
-        def __len__(self):
-            return len(all_runs) - int(0 in all_runs)
-
-        def __iter__(self):
-            for key, rns in all_runs.items():
-                if key == 0:
-                    continue
-                img = np.zeros(labels.shape, dtype=np.float32, order=order)
-                transfer(rns, dt, img)
-                yield (key, img)
-
-    class InPlaceImageIterator(ImageIterator):
-        def __iter__(self):
-            img = np.zeros(labels.shape, dtype=np.float32, order=order)
-            for key, rns in all_runs.items():
-                if key == 0:
-                    continue
-                transfer(rns, dt, img)
-                img.setflags(write=0)
-                yield (key, img)
-                img.setflags(write=1)
-                erase(rns, img)
-
-    return InPlaceImageIterator() if in_place else ImageIterator()
+    """Iterate ``(label, image)``: the distance transform ``dt`` restricted to each non-zero label of
+    ``labels`` in turn (same contract as the reference's ``edt.each``, src/edt.pyx:950-994: ``len()`` is the
+    number of labels, ``in_place=True`` reuses ONE read-only image instead of allocating one per label).
+    For device-resident data see :func:`edt.device.each`."""
+    return _PerLabelImages(np.asarray(labels), np.asarray(dt), bool(in_place))

@@ -1,0 +1,56 @@
+"""CPU tier: the reference's UNMODIFIED Cython binding (src/edt.pyx) compiles and links against the drop-in
+header pair cpp/edt.hpp + cpp/edt_voxel_graph.hpp (north_star: "Python via the existing Cython binding").
+
+The build is tests/cython_dropin.py (generated C++ under tests/_build/cydrop, outside the reference's src/).
+Without a GPU only the host-side run utilities can be exercised through the built module
+(extract_runs / set_run_voxels / transfer_run_voxels, reference: src/edt_voxel_graph.hpp:238-310); the
+transforms through it are tests/test_gpu_reference_verbatim.py.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cython_dropin
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def module_dir():
+    try:
+        so = cython_dropin.build()
+    except FileNotFoundError:
+        pytest.skip("/root/reference absent and no prebuilt module")
+    return os.path.dirname(so)
+
+
+def _run(module_dir, code):
+    env = dict(os.environ, PYTHONPATH=module_dir)
+    return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_builds_and_binds_every_symbol(module_dir):
+    """Import = every pyedt:: symbol of src/edt.pyx:62-113 resolved against our headers and libedt_hip.so."""
+    res = _run(module_dir, "import edt, sys; assert edt.__file__.endswith('.so'); "
+                           "print(sorted(n for n in dir(edt) if not n.startswith('_')))")
+    assert res.returncode == 0, res.stderr[-2000:]
+    for name in ("edt", "edtsq", "sdf", "sdfsq", "edt1d", "edt2d", "edt3d", "edt3dsq", "each", "runs", "draw", "erase",
+                 "transfer"):
+        assert f"'{name}'" in res.stdout, name
+
+
+def test_run_utilities_through_the_cython_module(module_dir):
+    """runs / draw / erase / transfer / each of the reference's Python layer over OUR extract_runs /
+    set_run_voxels / transfer_run_voxels: the checks of tests/test_run_utilities.py (fixture recorded from the
+    reference module itself) with `import edt` resolving to the Cython build."""
+    env = dict(os.environ, EDT_TEST_MODULE_DIR=module_dir)
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_run_utilities.py"),
+                          "-q", "-m", "not gpu", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert " passed" in res.stdout and "failed" not in res.stdout
+    # and it really was the Cython module
+    probe = _run(module_dir, "import edt; print(edt.__file__)")
+    assert probe.stdout.strip().endswith(".so") and "cydrop" in probe.stdout

@@ -1,0 +1,153 @@
+"""GPU tier: the reference's own acceptance suite, VERBATIM (tests/golden/automated_test_reference.py is a
+byte-identical copy of the reference's automated_test.py, 83 cases), with `import edt` resolving to
+
+  (a) this repo's Python drop-in module (euclidean-distance-transform-3d_amd/edt), and
+  (b) the reference's UNMODIFIED Cython binding compiled against cpp/edt.hpp + cpp/edt_voxel_graph.hpp
+      (tests/cython_dropin.py; north_star: "Python via the existing Cython binding"),
+
+both over libedt_hip.so.  The suite runs in a subprocess (`--noconftest`, its own sys.path), so nothing of
+this test tree leaks into it.  Beside it: the golden fixtures through module (b), and the assertions the
+reference's file evidently MEANT where what it wrote is vacuous (automated_test.py:170-186 and :406-424
+never copy the random bits into `labels`; :785-789 compares `np.all(...)` itself with the tolerance).
+"""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+import cython_dropin
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PKG = os.path.join(ROOT, "euclidean-distance-transform-3d_amd")
+SUITE = os.path.join(ROOT, "tests", "golden", "automated_test_reference.py")
+
+
+def _cython_dir():
+    try:
+        return os.path.dirname(cython_dropin.build())
+    except FileNotFoundError:
+        pytest.skip("the Cython drop-in module was not prebuilt and /root/reference is absent")
+
+
+def _run_suite(module_dir, expect_so):
+    env = dict(os.environ, PYTHONPATH=module_dir)
+    env.pop("EDT_HIP_DEBUG_MODE", None)
+    probe = subprocess.run([sys.executable, "-c", "import edt; print(edt.__file__)"], env=env, capture_output=True,
+                           text=True, timeout=300)
+    assert probe.returncode == 0, probe.stderr[-2000:]
+    assert probe.stdout.strip().endswith(".so") == expect_so, probe.stdout
+    res = subprocess.run([sys.executable, "-m", "pytest", SUITE, "-q", "--noconftest", "-p", "no:cacheprovider",
+                          "-o", "python_files=automated_test_reference.py"],
+                         env=env, capture_output=True, text=True, timeout=1800, cwd=os.path.join(ROOT, "tests", "golden"))
+    tail = res.stdout[-3000:] + res.stderr[-1000:]
+    assert res.returncode == 0, tail
+    m = re.search(r"(\d+) passed", res.stdout)
+    assert m and int(m.group(1)) == 83 and "failed" not in res.stdout, tail
+
+
+def test_reference_suite_verbatim_python_module(edt_gpu):
+    _run_suite(PKG, expect_so=False)
+
+
+def test_reference_suite_verbatim_cython_binding(edt_gpu):
+    _run_suite(_cython_dir(), expect_so=True)
+
+
+def test_golden_fixtures_through_the_cython_binding(edt_gpu):
+    """Every recorded reference output (tests/golden/*.npz) reproduced bit for bit by the reference's own
+    Python layer + Cython glue over our headers and kernels."""
+    moddir = _cython_dir()
+    code = f"""
+import numpy as np
+import edt
+assert edt.__file__.endswith('.so')
+GOLD = {os.path.join(ROOT, 'tests', 'golden')!r}
+def load(name):
+    blob = np.load(GOLD + '/' + name, allow_pickle=False)
+    cases = {{}}
+    for key in blob.files:
+        idx, field = key.split('/')
+        cases.setdefault(int(idx), {{}})[field] = blob[key]
+    return [cases[i] for i in sorted(cases)]
+same = lambda a, b: a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+n = 0
+for c in load('edt_random.npz'):
+    lab = c['labels']
+    lab = np.asfortranarray(lab) if str(c['order']) == 'F' else np.ascontiguousarray(lab)
+    an = tuple(c['anisotropy'])
+    an = an[0] if lab.ndim == 1 else an
+    bb = bool(c['black_border'])
+    assert same(edt.edtsq(lab, anisotropy=an, black_border=bb), c['edtsq']), n
+    assert same(edt.edt(lab, anisotropy=an, black_border=bb), c['edt']), n
+    n += 1
+for c in load('edt_configs.npz'):
+    lab = np.asfortranarray(c['labels'])
+    assert same(edt.edtsq(lab, anisotropy=tuple(c['anisotropy']), black_border=bool(c['black_border'])), c['edtsq'])
+    n += 1
+for c in load('edt_sdf_voxel_graph.npz'):
+    lab, an, bb = c['labels'], tuple(c['anisotropy']), bool(c['black_border'])
+    if str(c['kind']) == 'sdf':
+        got = edt.sdf(lab, anisotropy=an, black_border=bb)
+    else:
+        got = edt.edtsq(lab, anisotropy=an, black_border=bb, voxel_graph=c['graph'])
+    assert same(got, c['out']), (n, str(c['kind']))
+    n += 1
+print('ok', n)
+"""
+    env = dict(os.environ, PYTHONPATH=moddir)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert res.stdout.strip().startswith("ok") and int(res.stdout.split()[-1]) > 50
+
+
+# ---- what the vacuous assertions of the reference's file meant ---------------------------------------------
+def test_1d_scipy_comparison_no_border_as_intended(edt_gpu):
+    """automated_test.py:170-186 builds `randos` and then transforms an all-zero `labels`."""
+    rng = np.random.default_rng(170)
+    for _ in range(20):
+        randos = rng.integers(0, 2, size=100, dtype=np.uint32)
+        labels = np.zeros(randos.shape[0] + 2, dtype=np.uint32)
+        labels[1:-1] = randos
+        got = edt_gpu.edt(labels, black_border=False)
+        assert np.all(np.abs(ndimage.distance_transform_edt(labels) - got) < 0.000001)
+
+
+def test_2d_scipy_comparison_as_intended(edt_gpu):
+    """automated_test.py:406-424, same slip in 2-D (uint32 and bool, parallel 1 and 2)."""
+    rng = np.random.default_rng(406)
+    for _ in range(20):
+        for parallel in (1, 2):
+            for dtype in (np.uint32, bool):
+                randos = rng.integers(0, 2, size=(5, 5)).astype(dtype)
+                labels = np.zeros((7, 7), dtype=dtype)
+                labels[1:-1, 1:-1] = randos
+                got = edt_gpu.edt(labels, black_border=False, parallel=parallel)
+                assert np.all(np.abs(ndimage.distance_transform_edt(labels) - got) < 0.000001)
+
+
+def test_voxel_connectivity_graph_2d_as_intended(edt_gpu):
+    """automated_test.py:785-789 writes `np.all(np.abs(dt - ans)) < tol`, which is true for any `dt`.  Written
+    as meant (every |difference| < tol) it FAILS ON THE REFERENCE ITSELF: the expected table of that test does
+    not describe what src/edt_voxel_graph.hpp computes for this input (its outer ring says 1, the implementation
+    -- compiled reference and CPU oracle alike, checked in the build container -- gives 0.5, and 1.5 where the
+    table says 1.80).  So the meaningful assertion is against the implementation's real output."""
+    labels = np.ones((5, 6), dtype=np.int64)
+    omni, noxf, noxb = 0b111111, 0b111110, 0b111101
+    graph = np.full((5, 6), omni, dtype=np.uint8)
+    graph[2, 2], graph[2, 3] = noxf, noxb
+    r = float(np.float32(np.sqrt(1.25)))
+    reference_output = np.array([
+        [0.5, 0.5, 0.5, 0.5, 0.5, 0.5],
+        [0.5, 1.5, r, r, 1.5, 0.5],
+        [0.5, 1.5, 0.5, 0.5, 1.5, 0.5],
+        [0.5, 1.5, r, r, 1.5, 0.5],
+        [0.5, 0.5, 0.5, 0.5, 0.5, 0.5]])
+    for g in (np.ascontiguousarray(graph), np.asfortranarray(graph)):
+        dt = edt_gpu.edt(labels, voxel_graph=g, black_border=True)
+        assert np.all(np.abs(dt - reference_output) < 0.000002)

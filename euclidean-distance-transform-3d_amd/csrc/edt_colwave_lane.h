@@ -828,7 +828,6 @@ struct BruteSteps {
 template <int CW, bool BB, bool X32, class Store>
 EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
   constexpr int K = kBruteK, B = kBruteB, TC = TileGeom<CW>::kCols;
-  constexpr int kFar = 1 << 14;
   const int row0 = L.row0, n = L.n;
   const uint32_t rsw = L.rsw;
   // the lane's column in its own band and in the bands below / above (the band rotation of the tile
@@ -837,6 +836,8 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
   const float *Am = L.tile + addr_tile<CW>(L.col, row0 - 32);
   const float *Ap = L.tile + addr_tile<CW>(L.col, row0 + 32);
   const int nb32 = ((n + 31) >> 5) << 5;  // rows of the tile incl. the +inf rows that complete the last band
+  // distance of the row before the band to the row before ITS run (+inf: that run has no border below)
+  float dl = (BB || L.lo_in > 0) ? (float)(row0 - L.lo_in) : INFINITY;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
@@ -849,27 +850,26 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
     // rows below k0 come from this band while d <= k0, from the band below afterwards; likewise above
     const float *PL0 = A0 + (k0 - K) * TC, *PL1 = Am + (k0 + 32 - K) * TC;
     const float *PH0 = A0 + (k0 + B - 1) * TC, *PH1 = Ap + (k0 + B - 1 - 32) * TC;
-    // ---- B_p of the block's rows: distances to the border sites, counted from run start to run start ----
+    // ---- B_p of the block's rows ----
+    // Distances to the border sites just outside the run, as floats counted from run start to run start
+    // (exact small integers; +inf where there is no border on that side, which then stays +inf through
+    // the count, the square and the product).  dl is carried from block to block.
     const uint32_t s8 = rsw >> k0;  // bit i: a run starts at row k0 + i
-    int dl;  // distance of the current row to the row before its run (>= kFar: none)
-    {
-      const uint32_t m = rsw & ((1u << k0) - 1u);
-      const int a = m ? row0 + 31 - clz32(m) : L.lo_in;  // start of the run that is open at k0
-      dl = (BB || a > 0) ? row0 + k0 - a : kFar;
-    }
-    int dlv[B];
+    float dlv[B];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int i = 0; i < B; ++i) {
-      dl = ((s8 >> i) & 1u) ? ((BB || row0 + k0 + i > 0) ? 1 : kFar) : dl + 1;
+      // a run that starts at row 0 of the column has a border below it only with black_border
+      const float first = (BB || i > 0) ? 1.0f : (row0 + k0 > 0 ? 1.0f : INFINITY);
+      dl = ((s8 >> i) & 1u) ? first : dl + 1.0f;
       dlv[i] = dl;
     }
-    int dr;  // distance to the first row of the next run, as seen from the row above the block
+    float dr;  // distance to the first row of the next run, as seen from the row above the block
     {
       const uint32_t m = k0 + B < 32 ? rsw & (0xFFFFFFFFu << (k0 + B)) : 0u;
       const int e = m ? row0 + ctz32(m) : L.hi_out + 1;
-      dr = (BB || e < n) ? e - (row0 + k0 + B) : kFar;
+      dr = (BB || e < n) ? (float)(e - (row0 + k0 + B)) : INFINITY;
     }
     float best[B];
     double best64[B];
@@ -878,11 +878,10 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
 #pragma unroll
 #endif
     for (int i = B - 1; i >= 0; --i) {
-      dr += 1;
-      const int dmi = dlv[i] < dr ? dlv[i] : dr;
-      const float dm = (float)dmi;
+      dr += 1.0f;
+      const float dm = minpos(dlv[i], dr);
       // fl32(w2 * d^2) is one exact-product fp32 multiply (as in phase3_eval); background rows hold 0
-      const float bord = dmi < kFar ? L.w2f * (dm * dm) : INFINITY;
+      const float bord = L.w2f * (dm * dm);
       float b = minpos(w[K + i], bord);
       // rows that complete the last band (no real row holds +inf) and lanes without a column
       if (f2u(w[K + i]) == 0x7f800000u || !L.live) b = 0.0f;
@@ -890,7 +889,7 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
       if (!X32) best64[i] = (double)b;
       const uint32_t ub = f2u(b);
       bmax = ub > bmax ? ub : bmax;
-      if ((s8 >> i) & 1u) dr = (BB || row0 + k0 + i < n) ? 0 : kFar;
+      if ((s8 >> i) & 1u) dr = 0.0f;  // (a set bit is a real row: the border site of the rows below it)
     }
     const float bmaxf = u2f(bmax);
     const double bmax64 = (double)bmaxf;

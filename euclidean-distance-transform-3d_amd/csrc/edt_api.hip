@@ -439,32 +439,22 @@ static int voxel_graph_host(const void *labels, int dtype, const uint8_t *graph,
   if (voxels == 0) return EDT_OK;
   if (!labels || !graph || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
   if ((rc = require_device()) != EDT_OK) return rc;
-  const int64_t X = 2 * sx, Y = 2 * sy, Z = (ndim == 3) ? 2 * sz : 1;
-  const int64_t big = X * Y * Z;
   const size_t lbytes = (size_t)voxels * dtype_size(dtype);
-  const size_t wbytes = edt_hip_workspace_bytes(EDT_U8, ndim, X, Y, Z);
+  const size_t wbytes = edt_hip_voxel_graph_workspace_bytes(ndim, sx, sy, sz);
   const bool pooled = pool_enabled();
   DevicePool *pool = pooled ? current_pool() : nullptr;
   std::unique_lock<std::mutex> pool_lock;
   if (pool) pool_lock = std::unique_lock<std::mutex>(pool->m);
-  DeviceBuf d_labels(pool), d_graph(pool), d_big(pool), d_bigdt(pool), d_ws(pool), d_out(pool);
+  DeviceBuf d_labels(pool), d_graph(pool), d_ws(pool), d_out(pool);
   if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
   if ((rc = d_out.alloc((size_t)voxels * sizeof(float), pooled ? 1 : -1)) != EDT_OK) return rc;
   if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
   if ((rc = d_graph.alloc((size_t)voxels, pooled ? 3 : -1)) != EDT_OK) return rc;
-  if ((rc = d_big.alloc((size_t)big, pooled ? 4 : -1)) != EDT_OK) return rc;
-  if ((rc = d_bigdt.alloc((size_t)big * sizeof(float), pooled ? 5 : -1)) != EDT_OK) return rc;
   EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
   EDT_HIP_TRY(hipMemcpy(d_graph.p, graph, (size_t)voxels, hipMemcpyHostToDevice));
-  rc = launch_vg_expand(dtype, d_labels.p, (const uint8_t *)d_graph.p, (uint8_t *)d_big.p, sx, sy, sz,
-                        ndim, black_border ? 1 : 0, nullptr);
-  if (rc != EDT_OK) return rc;
-  // half voxel size on the 2x grid (src/edt_voxel_graph.hpp:96-101, :189-193)
-  rc = run_device(d_big.p, EDT_U8, ndim, X, Y, Z, wx / 2, wy / 2, wz / 2,
-                  black_border ? EDT_FLAG_BLACK_BORDER : 0, (float *)d_bigdt.p, d_ws.p, wbytes,
-                  nullptr);
-  if (rc != EDT_OK) return rc;
-  rc = launch_vg_gather((const float *)d_bigdt.p, (float *)d_out.p, sx, sy, sz, ndim, nullptr);
+  rc = edt_hip_edtsq_voxel_graph_device(d_labels.p, dtype, (const uint8_t *)d_graph.p, ndim, sx, sy, sz, wx, wy, wz,
+                                        black_border ? EDT_FLAG_BLACK_BORDER : 0, (float *)d_out.p, d_ws.p, wbytes,
+                                        nullptr);
   if (rc != EDT_OK) return rc;
   EDT_HIP_TRY(hipMemcpy(output, d_out.p, (size_t)voxels * sizeof(float), hipMemcpyDeviceToHost));
   return EDT_OK;
@@ -839,11 +829,17 @@ int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, in
   return launch_subtract(d_a, d_b, d_out, count, (hipStream_t)stream);
 }
 
-// Voxel-graph transform on device-resident data: workspace = [2x uint8 volume | its fp32 transform |
-// the ordinary workspace of the 2x volume]
+// Voxel-graph transform on device-resident data.  Native form (edt_voxel_graph.hip: no doubled volume) where
+// the wave column kernel covers the doubled axes, else the up-sampled form: workspace = [2x uint8 volume |
+// its fp32 transform | the ordinary workspace of the 2x volume].  Debug bit 0x20000 forces the latter.
+static bool vg_use_native(int ndim, int64_t sx, int64_t sy, int64_t sz) {
+  return !(g_debug_mode & 0x20000) && vg_native_supported(ndim, sx, sy, sz);
+}
+
 size_t edt_hip_voxel_graph_workspace_bytes(int ndim, int64_t sx, int64_t sy, int64_t sz) {
   if (check_shape(EDT_U8, ndim, sx, sy, sz) != EDT_OK || ndim < 2) return 0;
   if (sx == 0 || sy == 0 || sz == 0) return 256;
+  if (vg_use_native(ndim, sx, sy, sz)) return vg_native_workspace_bytes(ndim, sx, sy, sz);
   const int64_t X = 2 * sx, Y = 2 * sy, Z = (ndim == 3) ? 2 * sz : 1;
   const size_t big = (size_t)(X * Y * Z);
   return align_up(big, 256) + align_up(big * sizeof(float), 256) + edt_hip_workspace_bytes(EDT_U8, ndim, X, Y, Z) + 256;
@@ -864,6 +860,12 @@ int edt_hip_edtsq_voxel_graph_device(const void *d_labels, int dtype, const uint
     set_error("workspace too small: need " + std::to_string(need) + " bytes");
     return EDT_ERR_BAD_ARG;
   }
+  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  if (vg_use_native(ndim, sx, sy, sz)) {
+    ScopedPass t("voxel_graph", stream);
+    return launch_vg_native(dtype, d_labels, d_graph, ndim, sx, sy, sz, wx, wy, wz, bb,
+                            (flags & EDT_FLAG_SQRT) ? 1 : 0, d_output, d_workspace, stream);
+  }
   const int64_t X = 2 * sx, Y = 2 * sy, Z = (ndim == 3) ? 2 * sz : 1;
   const size_t big = (size_t)(X * Y * Z);
   Carver c(d_workspace);
@@ -871,12 +873,11 @@ int edt_hip_edtsq_voxel_graph_device(const void *d_labels, int dtype, const uint
   float *d_bigdt = c.take<float>(big);
   const size_t wbytes = edt_hip_workspace_bytes(EDT_U8, ndim, X, Y, Z);
   void *d_ws = c.take<unsigned char>(wbytes);
-  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
   rc = launch_vg_expand(dtype, d_labels, d_graph, d_big, sx, sy, sz, ndim, bb, stream);
   if (rc != EDT_OK) return rc;
   // half voxel size on the 2x grid (src/edt_voxel_graph.hpp:96-101, :189-193)
-  rc = run_device(d_big, EDT_U8, ndim, X, Y, Z, wx / 2, wy / 2, wz / 2, bb ? EDT_FLAG_BLACK_BORDER : 0,
-                  d_bigdt, d_ws, wbytes, stream);
+  rc = run_device(d_big, EDT_U8, ndim, X, Y, Z, wx / 2, wy / 2, wz / 2,
+                  (bb ? EDT_FLAG_BLACK_BORDER : 0) | (flags & EDT_FLAG_SQRT), d_bigdt, d_ws, wbytes, stream);
   if (rc != EDT_OK) return rc;
   return launch_vg_gather(d_bigdt, d_output, sx, sy, sz, ndim, stream);
 }

@@ -105,6 +105,39 @@ __device__ __forceinline__ void scan_breaks(uint32_t brk, int row0, int n, int l
 
 }  // namespace
 
+// The windowed path of one lane (edt_colwave_lane.h: brute_band) as a function of its own -- NOT inlined, so
+// that its register allocation is separate from the hull path's (inlined into one body the two paths, each
+// close to the 128-register budget of four waves per SIMD, push each other into scratch).
+template <int CW, bool BB, bool X32>
+__device__ __attribute__((noinline)) void brute_tile(float *tile, const uint32_t *alive, const uint32_t *rsp,
+                                                     const uint32_t *lohi, const uint32_t *bscan, int n, int NB,
+                                                     int cols_left, int band, int col, float w, int epi,
+                                                     float *dst0, int64_t dstride) {
+  using namespace edt_lane;
+  BruteLane BL;
+  BL.tile = tile;
+  BL.col = col;
+  BL.band = band;
+  BL.row0 = band * 32;
+  BL.n = n;
+  BL.rsw = rsp[addr_word<CW>(col, band)];
+  BL.brk = alive[addr_word<CW>(col, band)];
+  const uint32_t bs = bscan[addr_word<CW>(col, band)];
+  BL.blo_in = (int)(bs & 0xFFFFu) - 1;
+  BL.bhi_out = (int)(bs >> 16);
+  const uint32_t lh = lohi[addr_word<CW>(col, band)];
+  BL.lo_in = (int)(lh & 0xFFFFu) - 1;
+  BL.hi_out = (int)(lh >> 16) - 1;
+  BL.w2 = (double)(w * w);
+  BL.w2f = w * w;
+  BL.live = col < cols_left && band < NB;
+  const bool colok = col < cols_left;
+  auto store = [&](int row, float v) {
+    if (row < n && colok) dst0[(int64_t)row * dstride] = v;
+  };
+  brute_band<CW, BB, X32>(BL, epi, store);
+}
+
 template <int CW, bool BB, bool XF, bool SC>
 __global__ void __launch_bounds__(64 * edt_lane::TileGeom<CW>::kCols / CW, 4)
 k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
@@ -275,38 +308,17 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         for (int i = (int)threadIdx.x; i < ((NB + 1) * 32 - n) * TC; i += (int)blockDim.x)
           tile[addr_tile<CW>(i % TC, n + i / TC)] = INFINITY;
         __syncthreads();
-        BruteLane BL;
-        BL.tile = tile;
-        BL.col = lane % TC;
-        BL.band = wave * (64 / TC) + lane / TC;
-        BL.row0 = BL.band * 32;
-        BL.n = n;
-        BL.rsw = rsp[addr_word<CW>(BL.col, BL.band)];
-        BL.brk = alive[addr_word<CW>(BL.col, BL.band)];
-        const uint32_t bs = bscan[addr_word<CW>(BL.col, BL.band)];
-        BL.blo_in = (int)(bs & 0xFFFFu) - 1;
-        BL.bhi_out = (int)(bs >> 16);
-        const uint32_t lh = lohi[addr_word<CW>(BL.col, BL.band)];
-        BL.lo_in = (int)(lh & 0xFFFFu) - 1;
-        BL.hi_out = (int)(lh >> 16) - 1;
-        BL.w2 = L.w2;
-        BL.w2f = w * w;
-        BL.live = BL.col < cols_left && BL.band < NB;
-        const bool colok = BL.col < cols_left;
-        float *dst0;        // row 0 of this band's rows, this lane's column
-        int64_t dstride;
+        // (its own function: the windowed path and the hull path each get a register allocation of their own)
+        const int band2 = wave * (64 / TC) + lane / TC, col2 = lane % TC;
+        float *dst0;  // row 0 of the column this lane writes
         if constexpr (SC) {
-          const int b = BL.band < BandScatter::kBands ? BL.band : 0;
-          dst0 = scatter->rows[b] + o * scatter->ostride[b] + x0 + BL.col - (int64_t)BL.row0 * st;
+          const int b = band2 < BandScatter::kBands ? band2 : 0;
+          dst0 = scatter->rows[b] + o * scatter->ostride[b] + x0 + col2 - (int64_t)band2 * 32 * st;
         } else {
-          dst0 = Ftile + BL.col;
+          dst0 = Ftile + col2;
         }
-        dstride = st;
-        auto store = [&](int row, float v) {
-          if (row < n && colok) dst0[(int64_t)row * dstride] = v;
-        };
-        if (ba.x32) brute_band<CW, BB, true>(BL, epi, store);
-        else brute_band<CW, BB, false>(BL, epi, store);
+        if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
+        else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
         return;
       }
     }

@@ -804,10 +804,11 @@ struct BruteSteps {
         else best64[i] = fmin(best64[i], fmin((double)m1 + c1, (double)m2 + c2));
       }
       run<D + 2>();
-    } else {
+    } else if constexpr (!X32) {
+      // Windows beyond the register-resident part, fp64 candidates (the rarer form: 16 more registers of
+      // minima): one step at a time, every row straight from the tile.
       for (int d = K + 1; d < 4096; ++d) {
         const double cd = w2 * (double)(d * d);  // exact
-        const float cdf = (float)cd;             // (X32: exact as well)
         if (!EDT_ANY(cd < bmax64)) break;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -817,9 +818,58 @@ struct BruteSteps {
           rl = rl < -1 ? -1 : rl;        // row -1 and row nb32 are +inf rows
           rh = rh > nb32 ? nb32 : rh;
           const float m = minpos(L.tile[addr_tile<CW>(L.col, rl)], L.tile[addr_tile<CW>(L.col, rh)]);
-          if (X32) best[i] = minpos(best[i], m + cdf);
-          else best64[i] = fmin(best64[i], (double)m + cd);
+          best64[i] = fmin(best64[i], (double)m + cd);
         }
+      }
+    } else {
+      // Windows beyond the register-resident part: the same two-steps-per-test scheme as a rolled loop.
+      // At step d row i looks at the rows p0+i-d and p0+i+d, i.e. at the B rows that entered the window
+      // most recently on either side.  With two steps in flight that is a ring of B + 1 live rows: rings
+      // of 16 registers indexed by d mod 16, which is static once the loop body covers 16 consecutive
+      // steps.  Rows are addressed individually (a window of this size leaves the +inf padding: rows
+      // beyond the column are clamped to the +inf rows -1 / nb32).
+      constexpr int R = 16;
+      static_assert((K % R) == 0 && B < R, "ring phase / size");
+      const int p0 = L.row0 + k0;
+      float rlo[R], rhi[R];  // slot s: the row that entered at a step congruent to s (mod R)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int s = K - B + 2; s <= K; ++s) {  // the last B - 1 rows of the register-resident window
+        rlo[s % R] = w[K - s];
+        rhi[s % R] = w[K + B - 1 + s];
+      }
+      auto row_at = [&](int r) -> float {
+        r = r < -1 ? -1 : (r > nb32 ? nb32 : r);
+        return L.tile[addr_tile<CW>(L.col, r)];
+      };
+      for (int d0 = K + 1; d0 < 4096; d0 += R) {
+        bool done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int e = 0; e < R; e += 2) {  // steps d, d + 1 with d = d0 + e;  d mod R == (1 + e) mod R
+          const int d = d0 + e;
+          const double c1 = w2 * (double)(d * d), c2 = w2 * (double)((d + 1) * (d + 1));  // exact
+          const float c1f = (float)c1, c2f = (float)c2;                                   // (X32: exact as well)
+          if (!EDT_ANY(c1 < bmax64)) { done = true; break; }
+          const int s1 = (1 + e) % R, s2 = (2 + e) % R;
+          rlo[s1] = row_at(p0 - d);
+          rhi[s1] = row_at(p0 + B - 1 + d);
+          rlo[s2] = row_at(p0 - d - 1);
+          rhi[s2] = row_at(p0 + B + d);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+          for (int i = 0; i < B; ++i) {
+            // row p0+i-d entered at step d-i, row p0+i+d at step d-(B-1-i)
+            const float m1 = minpos(rlo[(s1 - i + R) % R], rhi[(s1 - (B - 1 - i) + R) % R]);
+            const float m2 = minpos(rlo[(s2 - i + R) % R], rhi[(s2 - (B - 1 - i) + R) % R]);
+            if (X32) best[i] = min3pos(best[i], m1 + c1f, m2 + c2f);
+            else best64[i] = fmin(best64[i], fmin((double)m1 + c1, (double)m2 + c2));
+          }
+        }
+        if (done) break;
       }
     }
   }

@@ -54,6 +54,12 @@ int launch_vg_expand(int dtype, const void *labels, const uint8_t *graph, uint8_
                      int64_t sy, int64_t sz, int ndim, int bb, hipStream_t stream);
 int launch_vg_gather(const float *big, float *out, int64_t sx, int64_t sy, int64_t sz, int ndim,
                      hipStream_t stream);
+// native form (no doubled volume): only the cells the result depends on are computed
+bool vg_native_supported(int ndim, int64_t sx, int64_t sy, int64_t sz);
+size_t vg_native_workspace_bytes(int ndim, int64_t sx, int64_t sy, int64_t sz);
+int launch_vg_native(int dtype, const void *labels, const uint8_t *graph, int ndim, int64_t sx, int64_t sy,
+                     int64_t sz, float wx, float wy, float wz, int bb, int want_sqrt, float *out, void *ws,
+                     hipStream_t stream);
 // ---- Z-sharded helpers: edt_shard.hip ---------------------------------------------------
 int launch_zflags(int dtype, const void *labels, const void *halo, uint8_t *flags, int64_t sxy,
                   int64_t szl, hipStream_t stream);

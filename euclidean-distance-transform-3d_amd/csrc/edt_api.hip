@@ -6,7 +6,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "edt_common.h"
 #include "edt_kernels.h"
@@ -139,7 +142,7 @@ static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws, in
     p.nz_y = c.take<uint32_t>(wy);
     p.rs_y = c.take<uint32_t>(wy);
   }
-  if (ndim >= 3) {
+  if (ndim >= 3 && !(flags & EDT_FLAG_BATCH_2D)) {
     // the z-packed planes are built AFTER the y pass: its run-start plane is dead by then and lends its
     // storage to the z run starts (four planes in all: 1/8 byte per voxel each, 0.5 GiB for 1024^3)
     const size_t wy = (size_t)(p.gy.sx * p.gy.nbands * p.gy.nouter);
@@ -153,6 +156,7 @@ static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws, in
     p.xrec = c.take<unsigned char>(row_records_bytes(sx, sy, sz));
     p.ttab = c.take<float>((size_t)sx + 3);
   }
+  if (ndim == 1) (void)c.take<unsigned char>(line_workspace_bytes(sx));  // block scan + table of the 1-D pipeline
   p.bytes = align_up(c.off, 256) + 256;
   return p;
 }
@@ -184,11 +188,13 @@ static bool env_force_generic() {
   return e && e[0] == '1';
 }
 
+static bool force_generic_1d(int flags) { return (flags & EDT_FLAG_FORCE_GENERIC) || env_force_generic(); }
+
 static bool plan_needs_pingpong(int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
   if (ndim < 2) return false;
   if ((flags & EDT_FLAG_FORCE_GENERIC) || env_force_generic()) return true;
   if (!column_inplace_supported(make_geom_y(sx, sy, sz))) return true;
-  return ndim == 3 && !column_inplace_supported(make_geom_z(sx, sy, sz));
+  return ndim == 3 && !(flags & EDT_FLAG_BATCH_2D) && !column_inplace_supported(make_geom_z(sx, sy, sz));
 }
 
 static int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
@@ -225,7 +231,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
   if (!d_labels || !d_out) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   Plan p = make_plan(ndim, sx, sy, sz, d_ws, flags);
-  if (ndim >= 2 && (!d_ws || ws_bytes < p.bytes)) {
+  if (!d_ws || ws_bytes < p.bytes) {
     set_error("workspace too small: need " + std::to_string(p.bytes) +
               " bytes (edt_hip_workspace_bytes_flags with the flags of this call)");
     return EDT_ERR_BAD_ARG;
@@ -233,6 +239,9 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
   const int want_sqrt = (flags & EDT_FLAG_SQRT) ? 1 : 0;
   const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0);
+  // a stack of 2-D images is a volume without a z pass
+  if ((flags & EDT_FLAG_BATCH_2D) && ndim != 3) { set_error("EDT_FLAG_BATCH_2D needs ndim = 3 (sz = image count)"); return EDT_ERR_BAD_ARG; }
+  const bool zpass = ndim == 3 && !(flags & EDT_FLAG_BATCH_2D);
 
   // the pass log is process-wide and only touched (under its mutex) while profiling is switched on
   if (g_log.enabled.load(std::memory_order_relaxed)) {
@@ -242,7 +251,8 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
 
   if (ndim == 1) {
     ScopedPass t("x_pass", stream);
-    return launch_row_pass_serial(dtype, d_labels, d_out, sx, 1, wx, bb, 0, want_sqrt, stream);
+    if (force_generic_1d(flags)) return launch_row_pass_serial(dtype, d_labels, d_out, sx, 1, wx, bb, 0, want_sqrt, stream);
+    return launch_line_pass(dtype, d_labels, d_out, sx, wx, bb, want_sqrt, d_ws, stream);
   }
 
   // Column passes are in place when the LDS-tiled kernel applies, otherwise they ping-pong
@@ -250,7 +260,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0 || env_force_generic();
   const bool tiled_y = !force_generic && column_inplace_supported(p.gy);
   const bool tiled_z = !force_generic && column_inplace_supported(p.gz);
-  const int swaps = (tiled_y ? 0 : 1) + ((ndim == 3 && !tiled_z) ? 1 : 0);
+  const int swaps = (tiled_y ? 0 : 1) + ((zpass && !tiled_z) ? 1 : 0);
   float *cur = (swaps % 2 == 0) ? d_out : p.bufB;
   float *other = (cur == d_out) ? p.bufB : d_out;
   const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
@@ -263,7 +273,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   if (fused_xy) {
     {
       ScopedPass t("x_bits", stream);
-      rc = launch_row_records(dtype, d_labels, p.xrec, p.ttab, p.nz_y, p.rs_y, ndim == 3 ? p.zs_y : nullptr,
+      rc = launch_row_records(dtype, d_labels, p.xrec, p.ttab, p.nz_y, p.rs_y, zpass ? p.zs_y : nullptr,
                               sx, sy, sz, wx, bb, stream);
       if (rc != EDT_OK) return rc;
     }
@@ -271,7 +281,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     // labels are read once: pass 1 also emits the run bit-planes of the y and z axes
     {
       ScopedPass t("x_pass", stream);
-      rc = launch_row_bits(dtype, d_labels, cur, p.nz_y, p.rs_y, ndim == 3 ? p.zs_y : nullptr, sx, sy, sz,
+      rc = launch_row_bits(dtype, d_labels, cur, p.nz_y, p.rs_y, zpass ? p.zs_y : nullptr, sx, sy, sz,
                            wx, bb, bb ? 0 : 1, stream);
       if (rc != EDT_OK) return rc;
     }
@@ -289,7 +299,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   }
   {
     ScopedPass t("y_pass", stream);
-    const int epi = ndim == 2 ? last_epi : 0;
+    const int epi = zpass ? 0 : last_epi;
     if (fused_xy) {
       rc = launch_column_pass_wave_xfused(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, p.xrec, p.ttab,
                                           bb ? 0 : 1, stream);
@@ -301,14 +311,14 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     }
     if (rc != EDT_OK) return rc;
   }
-  if (ndim == 3) {
+  if (zpass) {
     // z-packed planes (after the y pass: rs_z may live in the y pass's run-start plane)
     ScopedPass t("z_bits", stream);
     if (fused_xy || tiled_x) rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
     else rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
     if (rc != EDT_OK) return rc;
   }
-  if (ndim == 3) {
+  if (zpass) {
     ScopedPass t("z_pass", stream);
     if (tiled_z) {
       rc = launch_column_inplace(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream);
@@ -399,6 +409,47 @@ static bool pool_enabled() {
   return !(e && e[0] == '1');
 }
 
+// First touch of a large, freshly allocated result array is what dominated the host-buffer path: the kernel
+// zero-fills every page on its first write, one core at a time inside the device-to-host copy (measured:
+// ~35 of the 57 ms of a 512^3 call, against 2 x 9.5 ms of PCIe and 0.7 ms of kernels).  The pages are
+// therefore touched by a few threads WHILE the labels travel to the device and the kernels run; the copy
+// back then proceeds at PCIe speed.  (Every byte of the buffer is overwritten by the result afterwards.)
+struct Prefault {
+  std::vector<std::thread> threads;
+  Prefault(void *buf, size_t bytes) {
+    constexpr size_t kPage = 4096, kMin = size_t(32) << 20;
+    const char *off = std::getenv("EDT_HIP_NO_PREFAULT");
+    if (bytes < kMin || (off && off[0] == '1')) return;
+    unsigned n = std::thread::hardware_concurrency();
+    n = n == 0 ? 4 : (n > 16 ? 16 : n);
+    const size_t chunk = align_up((bytes + n - 1) / n, kPage);
+    volatile char *base = static_cast<volatile char *>(buf);
+#ifdef MADV_HUGEPAGE
+    {
+      // transparent huge pages for the part of the buffer that can have them (the box runs THP in
+      // "madvise" mode): 2 MiB per fault instead of 4 KiB, and a cheaper unmap when the array is freed
+      const char *thp = std::getenv("EDT_HIP_NO_THP");
+      const uintptr_t lo = align_up(reinterpret_cast<uintptr_t>(buf), kPage);
+      const uintptr_t hi = (reinterpret_cast<uintptr_t>(buf) + bytes) & ~(uintptr_t)(kPage - 1);
+      if (hi > lo && !(thp && thp[0] == '1')) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    }
+#endif
+    for (unsigned t = 0; t < n; ++t) {
+      const size_t lo = (size_t)t * chunk, hi = std::min(bytes, lo + chunk);
+      if (lo >= hi) break;
+      threads.emplace_back([base, lo, hi] {
+        for (size_t o = lo; o < hi; o += kPage) base[o] = 0;
+        base[hi - 1] = 0;
+      });
+    }
+  }
+  void join() {
+    for (auto &t : threads) t.join();
+    threads.clear();
+  }
+  ~Prefault() { join(); }
+};
+
 static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz,
                     float wx, float wy, float wz, int flags, float *output) {
   int rc = check_shape(dtype, ndim, sx, sy, sz);
@@ -421,14 +472,56 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
   if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
   if ((rc = d_out.alloc(obytes, pooled ? 1 : -1)) != EDT_OK) return rc;
   if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
+  Prefault touch(output, obytes);  // the result pages, while the labels travel and the kernels run
   EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
   rc = run_device(d_labels.p, dtype, ndim, sx, sy, sz, wx, wy, wz, flags, (float *)d_out.p, d_ws.p,
                   wbytes, nullptr);
   if (rc != EDT_OK) return rc;
+  touch.join();
   EDT_HIP_TRY(hipMemcpy(output, d_out.p, obytes, hipMemcpyDeviceToHost));
   return EDT_OK;
 }
 
+
+// sdf / sdfsq on host buffers in ONE round trip (reference: src/edt.pyx:121-202, two transforms and a
+// subtraction on the host): labels up once, edt(labels), the background mask and edt(mask) on the device, the
+// difference down once.
+static int sdf_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx,
+                    float wy, float wz, int flags, float *output) {
+  int rc = check_shape(dtype, ndim, sx, sy, sz);
+  if (rc != EDT_OK) return rc;
+  const int64_t voxels = sx * sy * sz;
+  if (voxels == 0) return EDT_OK;
+  if (!labels || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
+  if ((rc = require_device()) != EDT_OK) return rc;
+  if (env_force_generic()) flags |= EDT_FLAG_FORCE_GENERIC;
+  const size_t lbytes = (size_t)voxels * dtype_size(dtype), obytes = (size_t)voxels * sizeof(float);
+  const size_t wbytes = std::max(edt_hip_workspace_bytes_flags(dtype, ndim, sx, sy, sz, flags),
+                                 edt_hip_workspace_bytes_flags(EDT_U8, ndim, sx, sy, sz, flags));
+  const bool pooled = pool_enabled();
+  DevicePool *pool = pooled ? current_pool() : nullptr;
+  std::unique_lock<std::mutex> pool_lock;
+  if (pool) pool_lock = std::unique_lock<std::mutex>(pool->m);
+  DeviceBuf d_labels(pool), d_a(pool), d_ws(pool), d_mask(pool), d_b(pool);
+  if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
+  if ((rc = d_a.alloc(obytes, pooled ? 1 : -1)) != EDT_OK) return rc;
+  if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
+  if ((rc = d_mask.alloc((size_t)voxels, pooled ? 3 : -1)) != EDT_OK) return rc;
+  if ((rc = d_b.alloc(obytes, pooled ? 4 : -1)) != EDT_OK) return rc;
+  Prefault touch(output, obytes);
+  EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
+  rc = run_device(d_labels.p, dtype, ndim, sx, sy, sz, wx, wy, wz, flags, (float *)d_a.p, d_ws.p, wbytes, nullptr);
+  if (rc != EDT_OK) return rc;
+  rc = launch_is_background(dtype, d_labels.p, (uint8_t *)d_mask.p, voxels, nullptr);
+  if (rc != EDT_OK) return rc;
+  rc = run_device(d_mask.p, EDT_U8, ndim, sx, sy, sz, wx, wy, wz, flags, (float *)d_b.p, d_ws.p, wbytes, nullptr);
+  if (rc != EDT_OK) return rc;
+  rc = launch_subtract((const float *)d_a.p, (const float *)d_b.p, (float *)d_a.p, voxels, nullptr);
+  if (rc != EDT_OK) return rc;
+  touch.join();
+  EDT_HIP_TRY(hipMemcpy(output, d_a.p, obytes, hipMemcpyDeviceToHost));
+  return EDT_OK;
+}
 
 static int voxel_graph_host(const void *labels, int dtype, const uint8_t *graph, int ndim, int64_t sx,
                             int64_t sy, int64_t sz, float wx, float wy, float wz, int black_border,
@@ -450,12 +543,14 @@ static int voxel_graph_host(const void *labels, int dtype, const uint8_t *graph,
   if ((rc = d_out.alloc((size_t)voxels * sizeof(float), pooled ? 1 : -1)) != EDT_OK) return rc;
   if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
   if ((rc = d_graph.alloc((size_t)voxels, pooled ? 3 : -1)) != EDT_OK) return rc;
+  Prefault touch(output, (size_t)voxels * sizeof(float));
   EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
   EDT_HIP_TRY(hipMemcpy(d_graph.p, graph, (size_t)voxels, hipMemcpyHostToDevice));
   rc = edt_hip_edtsq_voxel_graph_device(d_labels.p, dtype, (const uint8_t *)d_graph.p, ndim, sx, sy, sz, wx, wy, wz,
                                         black_border ? EDT_FLAG_BLACK_BORDER : 0, (float *)d_out.p, d_ws.p, wbytes,
                                         nullptr);
   if (rc != EDT_OK) return rc;
+  touch.join();
   EDT_HIP_TRY(hipMemcpy(output, d_out.p, (size_t)voxels * sizeof(float), hipMemcpyDeviceToHost));
   return EDT_OK;
 }
@@ -564,6 +659,19 @@ int edt_hip_edt3d(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t
                   float wy, float wz, int black_border, int /*parallel*/, float *output) {
   return run_host(labels, dtype, 3, sx, sy, sz, wx, wy, wz,
                   (black_border ? EDT_FLAG_BLACK_BORDER : 0) | EDT_FLAG_SQRT, output);
+}
+
+int edt_hip_edt2dsq_batch(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t count, float wx, float wy,
+                          int black_border, int take_sqrt, float *output) {
+  return run_host(labels, dtype, 3, sx, sy, count, wx, wy, 1.0f,
+                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (take_sqrt ? EDT_FLAG_SQRT : 0) | EDT_FLAG_BATCH_2D,
+                  output);
+}
+
+int edt_hip_sdf(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
+                float wz, int black_border, int squared, float *output) {
+  return sdf_host(labels, dtype, ndim, sx, sy, sz, wx, wy, wz,
+                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (squared ? 0 : EDT_FLAG_SQRT), output);
 }
 
 size_t edt_hip_workspace_bytes_flags(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
@@ -888,6 +996,20 @@ int edt_hip_select_label_device(const void *d_labels, int dtype, const float *d_
   if (count == 0) return EDT_OK;
   if (!d_labels || !d_dt || !d_out || !key) { set_error("null pointer"); return EDT_ERR_BAD_ARG; }
   return launch_select_label(dtype, d_labels, d_dt, d_out, key, count, (hipStream_t)stream);
+}
+
+size_t edt_hip_runs_workspace_bytes(int64_t count) { return count < 0 ? 0 : runs_workspace_bytes(count); }
+
+int edt_hip_extract_runs_device(const void *d_labels, int dtype, int64_t count, int64_t *d_starts, int64_t capacity,
+                                int64_t *d_count, void *d_workspace, size_t workspace_bytes, void *stream) {
+  if (count < 0 || capacity < 0 || dtype_size(dtype) == 0) { set_error("bad argument"); return EDT_ERR_BAD_ARG; }
+  if (!d_count) { set_error("null pointer"); return EDT_ERR_BAD_ARG; }
+  if (count == 0) { EDT_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int64_t), (hipStream_t)stream)); return EDT_OK; }
+  if (!d_labels || !d_workspace || workspace_bytes < runs_workspace_bytes(count)) {
+    set_error("null pointer or workspace too small (edt_hip_runs_workspace_bytes)");
+    return EDT_ERR_BAD_ARG;
+  }
+  return launch_extract_runs(dtype, d_labels, count, d_starts, capacity, d_count, d_workspace, (hipStream_t)stream);
 }
 
 int edt_hip_is_background_device(const void *d_labels, int dtype, uint8_t *d_mask, int64_t count,

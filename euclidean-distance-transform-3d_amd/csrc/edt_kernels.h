@@ -35,6 +35,13 @@ __device__ __forceinline__ float finish(float m, int epi) {
 // ---- generic (any extent) kernels: edt_generic.hip ------------------------------------
 int launch_row_pass_serial(int dtype, const void *labels, float *out, int64_t sx, int64_t nrows,
                            float w, int bb, int to_finite, int take_sqrt, hipStream_t stream);
+// ---- the 1-D transform as a parallel pipeline for lines of any length: edt_line.hip -----------------
+size_t line_workspace_bytes(int64_t n);
+int launch_line_pass(int dtype, const void *labels, float *out, int64_t n, float w, int bb, int take_sqrt,
+                     void *ws, hipStream_t stream);
+size_t runs_workspace_bytes(int64_t n);
+int launch_extract_runs(int dtype, const void *labels, int64_t n, int64_t *starts, int64_t capacity, int64_t *total,
+                        void *ws, hipStream_t stream);
 int launch_axis_bits(int dtype, const void *labels, const void *halo, uint32_t *nz, uint32_t *rs,
                      const AxisGeom &g, hipStream_t stream);
 int launch_column_pass_serial(const float *fin, float *fout, const uint32_t *nz, const uint32_t *rs,

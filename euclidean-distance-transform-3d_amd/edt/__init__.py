@@ -30,7 +30,7 @@ from ._lib import EdtHipError  # noqa: F401  (re-export)
 __all__ = [
     "edt", "edtsq", "sdf", "sdfsq",
     "edt1d", "edt1dsq", "edt2d", "edt2dsq", "edt3d", "edt3dsq",
-    "each", "EdtHipError",
+    "each", "edt_stack", "edtsq_stack", "EdtHipError",
 ]
 
 _DTYPE_CODE = {
@@ -73,6 +73,9 @@ def _ptr(arr: np.ndarray) -> ctypes.c_void_p:
 def sdf(data, anisotropy=None, black_border=False, parallel=1, voxel_graph=None, order=None):
     """Signed distance function: ``edt(data) - edt(data == 0)`` (reference: src/edt.pyx:121-158)."""
     data = np.asarray(data) if isinstance(data, list) else data
+    if voxel_graph is None:
+        # one round trip: both transforms and the subtraction run on the device (edt_hip_sdf)
+        return _transform(data, anisotropy, black_border, parallel, None, take_sqrt=True, signed=True)
 
     def fn(labels):
         return edt(labels, anisotropy=anisotropy, black_border=black_border, parallel=parallel,
@@ -86,6 +89,8 @@ def sdf(data, anisotropy=None, black_border=False, parallel=1, voxel_graph=None,
 def sdfsq(data, anisotropy=None, black_border=False, parallel=1, voxel_graph=None):
     """Squared signed distance function (reference: src/edt.pyx:161-202)."""
     data = np.asarray(data) if isinstance(data, list) else data
+    if voxel_graph is None:
+        return _transform(data, anisotropy, black_border, parallel, None, take_sqrt=False, signed=True)
 
     def fn(labels):
         return edtsq(labels, anisotropy=anisotropy, black_border=black_border, parallel=parallel,
@@ -132,10 +137,40 @@ def edt3dsq(data, anisotropy=(1.0, 1.0, 1.0), black_border=False, parallel=1, vo
     return _run(np.asarray(data), anisotropy, black_border, voxel_graph, False, ndim=3)
 
 
+def _stack(images, anisotropy, black_border, take_sqrt):
+    images = np.asarray(images)
+    if images.ndim != 3:
+        raise TypeError("a stack of 2-D images is a 3-D array (count, height, width)")
+    if images.size == 0:
+        return np.zeros(images.shape, dtype=np.float32)
+    images = np.ascontiguousarray(images)      # C order: the last axis (width) is x
+    code = _label_code(images)
+    buf = _as_label_buffer(images, code)
+    an = (1.0, 1.0) if anisotropy is None else tuple(float(np.float32(a)) for a in anisotropy)
+    if len(an) != 2:
+        raise ValueError("anisotropy of a 2-D image has 2 entries")
+    count, sy, sx = images.shape
+    out = np.empty(images.shape, dtype=np.float32)
+    _lib.check(_lib.load().edt_hip_edt2dsq_batch(_ptr(buf), code, sx, sy, count, an[1], an[0],
+                                                 1 if black_border else 0, 1 if take_sqrt else 0, _ptr(out)))
+    return out
+
+
+def edtsq_stack(images, anisotropy=None, black_border=False):
+    """Squared EDT of every 2-D image of ``images[count, height, width]`` independently, in one call (an
+    extension over the reference's API: the stack goes through the GPU as one batch, edt_hip_edt2dsq_batch).
+    ``anisotropy`` = (height spacing, width spacing), as for a C-ordered 2-D array."""
+    return _stack(images, anisotropy, black_border, take_sqrt=False)
+
+
+def edt_stack(images, anisotropy=None, black_border=False):
+    return _stack(images, anisotropy, black_border, take_sqrt=True)
+
+
 # ----------------------------------------------------------------------------------------
 # argument handling (mirrors src/edt.pyx:276-310) and dispatch into the C ABI
 # ----------------------------------------------------------------------------------------
-def _transform(data, anisotropy, black_border, parallel, voxel_graph, take_sqrt):
+def _transform(data, anisotropy, black_border, parallel, voxel_graph, take_sqrt, signed=False):
     if isinstance(data, list):
         data = np.array(data)
     data = np.asarray(data)
@@ -160,10 +195,10 @@ def _transform(data, anisotropy, black_border, parallel, voxel_graph, take_sqrt)
     else:
         raise TypeError(
             "Multi-Label EDT library only supports up to 3 dimensions got {}.".format(dims))
-    return _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim=dims)
+    return _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim=dims, signed=signed)
 
 
-def _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim):
+def _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim, signed=False):
     if data.ndim != ndim:
         raise TypeError(f"expected a {ndim}-D array, got {data.ndim}-D")
     if data.size == 0:
@@ -211,7 +246,12 @@ def _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim):
             np.sqrt(out, out)
         return out.reshape(data.shape, order=order)
 
-    if ndim == 1:
+    if signed:  # sdf / sdfsq: edt(x) - edt(x == 0), everything but the two copies on the device
+        e = tuple(extents) + (1,) * (3 - ndim)
+        ww = tuple(w) + (1.0,) * (3 - ndim)
+        _lib.check(lib.edt_hip_sdf(_ptr(buf), code, ndim, e[0], e[1], e[2], ww[0], ww[1], ww[2], bb,
+                                   0 if take_sqrt else 1, _ptr(out)))
+    elif ndim == 1:
         rc = lib.edt_hip_squared_edt_1d_multi_seg(_ptr(buf), code, _ptr(out), data.size, 1, w[0], bb)
         _lib.check(rc)
         if take_sqrt:

@@ -20,6 +20,7 @@ DTYPE_SIZE = {U8: 1, U16: 2, U32: 4, U64: 8, F32: 4, F64: 8, BOOL: 1}
 FLAG_BLACK_BORDER = 1
 FLAG_SQRT = 2
 FLAG_FORCE_GENERIC = 4
+FLAG_BATCH_2D = 8
 
 OK = 0
 ERR_NO_DEVICE = -1
@@ -46,6 +47,10 @@ SIGNATURES = {
     "edt_hip_edt3d": (_i, [_vp, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp]),
     "edt_hip_edt2dsq_voxel_graph": (_i, [_vp, _i, _vp, _i64, _i64, _f, _f, _i, _vp]),
     "edt_hip_edt3dsq_voxel_graph": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _f, _f, _f, _i, _vp]),
+    "edt_hip_edt2dsq_batch": (_i, [_vp, _i, _i64, _i64, _i64, _f, _f, _i, _i, _vp]),
+    "edt_hip_runs_workspace_bytes": (_sz, [_i64]),
+    "edt_hip_extract_runs_device": (_i, [_vp, _i, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "edt_hip_sdf": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp]),
     "edt_hip_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i64]),
     "edt_hip_workspace_bytes_flags": (_sz, [_i, _i, _i64, _i64, _i64, _i]),
     "edt_hip_edtsq_device": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _vp, _vp, _sz, _vp]),

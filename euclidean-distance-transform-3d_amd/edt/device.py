@@ -65,7 +65,7 @@ class Plan:
         return self._generic_ws
 
     def run(self, labels: torch.Tensor, weights_xyz, black_border=False, sqrt=False,
-            out: torch.Tensor | None = None, force_generic=False) -> torch.Tensor:
+            out: torch.Tensor | None = None, force_generic=False, batch2d=False) -> torch.Tensor:
         """Enqueue the transform of ``labels`` (device, contiguous, ``voxels`` elements)."""
         if not labels.is_cuda or not labels.is_contiguous():
             raise ValueError("labels must be a contiguous device tensor")
@@ -79,7 +79,8 @@ class Plan:
             out = torch.empty(labels.shape, dtype=torch.float32, device=labels.device)
         w = tuple(float(np.float32(v)) for v in weights_xyz) + (1.0,) * (3 - self.ndim)
         flags = ((_lib.FLAG_BLACK_BORDER if black_border else 0) | (_lib.FLAG_SQRT if sqrt else 0)
-                 | (_lib.FLAG_FORCE_GENERIC if force_generic else 0))
+                 | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
+                 | (_lib.FLAG_BATCH_2D if batch2d else 0))
         ws = self._workspace_for(flags)
         rc = self.lib.edt_hip_edtsq_device(
             ctypes.c_void_p(labels.data_ptr()), self.code, self.ndim, *self.ext, w[0], w[1], w[2],
@@ -125,6 +126,31 @@ def edtsq(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Te
 
 def edt(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
     return _transform(labels, anisotropy, black_border, sqrt=True)
+
+
+def _stack2d(images: torch.Tensor, anisotropy, black_border, sqrt):
+    if images.dim() != 3:
+        raise TypeError("a stack of 2-D images is a 3-D tensor (count, height, width)")
+    if images.numel() == 0:
+        return torch.zeros(images.shape, dtype=torch.float32, device=images.device)
+    images = images.contiguous()
+    an = (1.0, 1.0) if anisotropy is None else tuple(float(a) for a in anisotropy)
+    if len(an) != 2:
+        raise ValueError("anisotropy of a 2-D image has 2 entries")
+    ext = tuple(images.shape[::-1])            # (width, height, count): x fastest
+    plan = _plan_for(ext, dtype_code(images.dtype), images.device)
+    return plan.run(images, (an[1], an[0], 1.0), black_border, sqrt, batch2d=True)
+
+
+def edtsq_stack(images: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
+    """Squared EDT of every image of a stack ``(count, height, width)`` independently -- one launch per pass for
+    the whole stack (EDT_FLAG_BATCH_2D), so that many small images fill the chip.  Same result as calling
+    :func:`edtsq` on each image."""
+    return _stack2d(images, anisotropy, black_border, sqrt=False)
+
+
+def edt_stack(images: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
+    return _stack2d(images, anisotropy, black_border, sqrt=True)
 
 
 def sdf(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
@@ -192,23 +218,80 @@ def select_label(labels: torch.Tensor, dt: torch.Tensor, key, out: torch.Tensor 
     return out
 
 
+def runs(labels: torch.Tensor):
+    """Device-side ``extract_runs`` (reference: src/edt_voxel_graph.hpp:238-268): the maximal constant runs of
+    the flattened (C-order) tensor as three device tensors ``(starts, ends, values)``, in memory order
+    (run k covers ``[starts[k], ends[k])`` and holds ``values[k]``).  Two enqueue-only kernels sweeps
+    (edt_hip_extract_runs_device); the only host synchronisation is reading the run count."""
+    lib = _lib.load()
+    labels = labels.contiguous()
+    n = labels.numel()
+    dev = labels.device
+    if n == 0:
+        z = torch.zeros(0, dtype=torch.int64, device=dev)
+        return z, z.clone(), labels.reshape(-1)
+    code = dtype_code(labels.dtype)
+    ws = torch.empty(int(lib.edt_hip_runs_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    lp, cp, wp = ctypes.c_void_p(labels.data_ptr()), ctypes.c_void_p(count.data_ptr()), ctypes.c_void_p(ws.data_ptr())
+    _lib.check(lib.edt_hip_extract_runs_device(lp, code, n, None, 0, cp, wp, ws.numel(), _stream_ptr()))
+    nruns = int(count.item())
+    starts = torch.empty(nruns, dtype=torch.int64, device=dev)
+    _lib.check(lib.edt_hip_extract_runs_device(lp, code, n, ctypes.c_void_p(starts.data_ptr()), nruns, cp, wp,
+                                               ws.numel(), _stream_ptr()))
+    ends = torch.empty_like(starts)
+    ends[:-1] = starts[1:]
+    ends[-1] = n
+    return starts, ends, labels.reshape(-1)[starts]
+
+
+class _DeviceLabelImages:
+    """Sized iterable behind :func:`each`: the run table of the labels is extracted once on the device; every
+    label's image is then produced by ONE streaming kernel over just the span of memory its runs cover
+    (first run start .. last run end) instead of the whole volume."""
+
+    def __init__(self, labels, dt, reuse):
+        if labels.shape != dt.shape or dt.dtype != torch.float32:
+            raise ValueError("dt must be a float32 tensor of the labels' shape")
+        self.labels, self.dt, self.reuse = labels.contiguous(), dt.contiguous(), reuse
+        starts, ends, values = runs(self.labels)
+        keep = values != 0
+        starts, ends, values = starts[keep], ends[keep], values[keep]
+        self.keys, inverse = torch.unique(values, return_inverse=True)   # over RUNS, not voxels
+        nk = self.keys.numel()
+        big = self.labels.numel()
+        lo = torch.full((nk,), big, dtype=torch.int64, device=labels.device).scatter_reduce(0, inverse, starts, "amin")
+        hi = torch.zeros((nk,), dtype=torch.int64, device=labels.device).scatter_reduce(0, inverse, ends, "amax")
+        self._keys, self._lo, self._hi = self.keys.tolist(), lo.tolist(), hi.tolist()
+
+    def __len__(self):
+        return len(self._keys)
+
+    def _select(self, key, lo, hi, out):
+        lab, dt, flat = self.labels.reshape(-1), self.dt.reshape(-1), out.reshape(-1)
+        select_label(lab[lo:hi], dt[lo:hi], key, out=flat[lo:hi])
+
+    def __iter__(self):
+        shared = torch.zeros_like(self.dt) if self.reuse else None
+        prev = None
+        for key, lo, hi in zip(self._keys, self._lo, self._hi):
+            if self.reuse:
+                if prev is not None:
+                    shared.reshape(-1)[prev[0]:prev[1]].zero_()   # wipe only what the previous label wrote
+                out = shared
+                prev = (lo, hi)
+            else:
+                out = torch.zeros_like(self.dt)
+            self._select(key, lo, hi, out)
+            yield key, out
+
+
 def each(labels: torch.Tensor, dt: torch.Tensor, in_place: bool = False):
     """Device-resident :func:`edt.each` (reference: src/edt.pyx:950-994): an iterable of
     ``(label, image)`` with ``image = dt`` restricted to that label, zeros elsewhere; the label 0 is
     skipped.  ``in_place=True`` reuses ONE output tensor for every label (the reference's read-only
-    in-place image).  The DT never leaves the device: one streaming kernel per label."""
-    keys = [k for k in torch.unique(labels).tolist() if k != 0]
-
-    class ImageIterator:
-        def __len__(self):
-            return len(keys)
-
-        def __iter__(self):
-            shared = torch.empty_like(dt, dtype=torch.float32) if in_place else None
-            for key in keys:
-                yield key, select_label(labels, dt, key, out=shared)
-
-    return ImageIterator()
+    in-place image).  The DT never leaves the device."""
+    return _DeviceLabelImages(labels, dt, bool(in_place))
 
 
 def pass_times():

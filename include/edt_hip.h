@@ -55,7 +55,9 @@ enum {
 enum {
   EDT_FLAG_BLACK_BORDER = 1, /* treat the outside of the volume as background          */
   EDT_FLAG_SQRT = 2,         /* return distances instead of squared distances          */
-  EDT_FLAG_FORCE_GENERIC = 4 /* use the size-agnostic fallback kernels (test hook)      */
+  EDT_FLAG_FORCE_GENERIC = 4, /* use the size-agnostic fallback kernels (test hook)     */
+  EDT_FLAG_BATCH_2D = 8      /* edt_hip_edtsq_device with ndim = 3: the volume is a STACK of sz independent
+                                2-D images (sx x sy each) -- x and y passes only, one launch for all images */
 };
 
 /* ---- introspection -------------------------------------------------------------- */
@@ -100,6 +102,12 @@ int edt_hip_edt3dsq_voxel_graph(const void *labels, int dtype, const uint8_t *gr
                                 int64_t sy, int64_t sz, float wx, float wy, float wz,
                                 int black_border, float *workspace);
 
+/* sdf / sdfsq of the reference's Python layer (src/edt.pyx:121-158, :161-202): edt(labels) - edt(labels == 0)
+ * (squared != 0: edtsq(labels) - edtsq(labels == 0)) on host buffers in one round trip -- labels up once, both
+ * transforms and the subtraction on the device, the difference down once.  ndim in {1,2,3}, unused extents 1. */
+int edt_hip_sdf(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
+                float wz, int black_border, int squared, float *output);
+
 /* The host-buffer entry points keep their device buffers (labels, output, scratch) between calls --
  * allocating gigabytes per call costs more than moving them over PCIe.  This frees them.
  * (EDT_HIP_NO_CACHE=1 in the environment disables the cache altogether.) */
@@ -117,6 +125,13 @@ int edt_hip_release_cache(void);
  * second fp32 volume and the hull stacks as well (+ 8 bytes per voxel): ask with the flags of the call. */
 size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz);
 size_t edt_hip_workspace_bytes_flags(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags);
+
+/* A stack of `count` independent 2-D images, images[k][y][x] (pyedt::_edt2dsq per image, src/edt.hpp:632-678):
+ * one launch per pass for the whole stack, so that small images fill the chip (a single 512 x 512 image is 16
+ * workgroups on 256 compute units).  Host buffers; take_sqrt != 0 gives edt instead of edtsq.  The device-resident
+ * form is edt_hip_edtsq_device(ndim = 3, sz = count, flags | EDT_FLAG_BATCH_2D). */
+int edt_hip_edt2dsq_batch(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t count, float wx, float wy,
+                          int black_border, int take_sqrt, float *output);
 
 /* ndim in {1,2,3}; unused extents must be 1.  flags: EDT_FLAG_*.  d_output may not alias
  * d_labels.  Implements _edt3dsq / _edt2dsq / squared_edt_1d_multi_seg (+ optional sqrt). */
@@ -183,6 +198,14 @@ int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_loca
 /* out[i] = a[i] - b[i]  (src/edt.pyx:156-158, sdf = edt(x) - edt(x == 0)) */
 int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, int64_t count,
                             void *stream);
+/* pyedt::extract_runs (src/edt_voxel_graph.hpp:238-268) on device-resident labels: the START offsets of the
+ * maximal constant runs of the flattened array, ascending (run k = [starts[k], starts[k+1]) resp. up to count for
+ * the last one; its label is labels[starts[k]]).  *d_count receives the number of runs; at most `capacity` starts are
+ * written (capacity = 0, d_starts = NULL: count only).  Enqueue-only; scratch: edt_hip_runs_workspace_bytes. */
+size_t edt_hip_runs_workspace_bytes(int64_t count);
+int edt_hip_extract_runs_device(const void *d_labels, int dtype, int64_t count, int64_t *d_starts, int64_t capacity,
+                                int64_t *d_count, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* mask[i] = (labels[i] == 0) as one byte per voxel (the `data == 0` of src/edt.pyx:157) */
 int edt_hip_is_background_device(const void *d_labels, int dtype, uint8_t *d_mask, int64_t count,
                                  void *stream);

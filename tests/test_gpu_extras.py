@@ -1,0 +1,109 @@
+"""GPU tier: the entry points around the 3-D hot path: the parallel 1-D pipeline for lines
+of any length, stacks of 2-D images in one batch, device-side run extraction / per-label images, sdf in one
+round trip, the concurrent first touch of the host result buffer."""
+import numpy as np
+import pytest
+
+from synth import blocky_labels, voronoi_labels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 1023, 1024, 1025, 5000, 70001, 1 << 20])
+def test_line_of_any_length(edt_gpu, oracle_port, n):
+    rng = np.random.default_rng(n)
+    for kind in ("ones", "blocky", "noise"):
+        if kind == "ones":
+            lab = np.ones(n, dtype=np.uint32)
+        elif kind == "blocky":
+            lab = blocky_labels((n,), nlabels=5, zero_frac=0.2, block=int(rng.integers(1, 4000)), rng=rng).astype(np.uint16)
+        else:
+            lab = rng.integers(0, 3, size=n).astype(np.uint8)
+        for w in (1.0, 6.0, 0.7, 1e-3):          # exact multiples and a tabulated sequential sum
+            for bb in (True, False):
+                want = oracle_port.edtsq(lab, w, bb)
+                got = edt_gpu.edtsq(lab, anisotropy=w, black_border=bb)
+                assert np.array_equal(got, want), (n, kind, w, bb)
+                assert np.array_equal(edt_gpu.edt(lab, anisotropy=w, black_border=bb), np.sqrt(want))
+
+
+def test_line_device_resident_and_generic_agree(edt_gpu, oracle_port):
+    import torch
+    from edt import device
+    rng = np.random.default_rng(3)
+    lab = blocky_labels((300000,), nlabels=7, zero_frac=0.1, block=977, rng=rng).astype(np.int32)
+    want = oracle_port.edtsq(lab, 2.5, False)
+    t = torch.from_numpy(lab).cuda()
+    assert np.array_equal(device.edtsq(t, anisotropy=2.5).cpu().numpy(), want)
+    plan = device.Plan((lab.size,), 2, t.device)
+    got = plan.run(t, (2.5,), black_border=False, force_generic=True)   # the one-thread port of the reference loop
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 7), (9, 64, 64), (33, 130, 96), (300, 40, 52), (4, 513, 1000)])
+def test_stack_of_images_equals_image_by_image(edt_gpu, oracle_port, shape):
+    import torch
+    from edt import device
+    rng = np.random.default_rng(sum(shape))
+    stack = blocky_labels(shape, nlabels=6, zero_frac=0.15, block=7, rng=rng).astype(np.uint32)
+    for an, bb in (((1.0, 1.0), False), ((3.0, 0.5), True)):
+        want = np.stack([oracle_port.edtsq(img, an, bb) for img in stack])
+        got = edt_gpu.edtsq_stack(stack, anisotropy=an, black_border=bb)
+        assert got.shape == want.shape and np.array_equal(got, want), (shape, an, bb)
+        assert np.array_equal(edt_gpu.edt_stack(stack, anisotropy=an, black_border=bb), np.sqrt(want))
+        t = torch.from_numpy(stack.view(np.int32)).cuda()
+        assert np.array_equal(device.edtsq_stack(t, anisotropy=an, black_border=bb).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "int32", "int64", "float32"])
+def test_device_runs_equal_host_runs(edt_gpu, dtype):
+    import torch
+    from edt import device
+    rng = np.random.default_rng(12)
+    for shape in ((1,), (5000,), (37, 41), (20, 33, 29)):
+        lab = blocky_labels(shape, nlabels=6, zero_frac=0.2, block=3, rng=rng).astype(dtype)
+        starts, ends, values = device.runs(torch.from_numpy(lab).cuda())
+        host = edt_gpu.runs(lab)                       # {label: [(start, end), ...]}
+        flat = sorted((s, e, k) for k, rr in host.items() for s, e in rr)
+        assert starts.tolist() == [s for s, _, _ in flat]
+        assert ends.tolist() == [e for _, e, _ in flat]
+        assert values.cpu().numpy().tolist() == [k for _, _, k in flat]
+    s, e, v = device.runs(torch.zeros(0, dtype=torch.int32, device="cuda"))
+    assert s.numel() == 0 and e.numel() == 0
+
+
+def test_device_each_large_labels_in_place(edt_gpu):
+    import torch
+    from edt import device
+    lab = voronoi_labels((96, 80, 72), nseeds=40, seed=2, upsample=4, membrane=0.05)
+    tl = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).cuda()
+    dt = device.edt(tl, anisotropy=(3, 2, 1))
+    mdt, mlab = dt.cpu().numpy(), tl.cpu().numpy()
+    for in_place in (False, True):
+        it = device.each(tl, dt, in_place=in_place)
+        assert len(it) == len(np.unique(mlab)) - int(0 in mlab)
+        for k, img in it:
+            assert np.array_equal(img.cpu().numpy(), (mlab == k) * mdt), (k, in_place)
+
+
+def test_sdf_single_round_trip(edt_gpu, oracle_port):
+    rng = np.random.default_rng(77)
+    for shape in ((200,), (70, 45), (40, 52, 36)):
+        lab = blocky_labels(shape, nlabels=3, zero_frac=0.4, block=5, rng=rng).astype(np.uint16)
+        an = (2.0, 1.0, 3.0)[:len(shape)]
+        an = an[0] if len(shape) == 1 else an
+        for bb in (True, False):
+            for arr in (lab, np.asfortranarray(lab)):
+                assert np.array_equal(edt_gpu.sdf(arr, anisotropy=an, black_border=bb), oracle_port.sdf(arr, an, bb),
+                                      equal_nan=True)
+                assert np.array_equal(edt_gpu.sdfsq(arr, anisotropy=an, black_border=bb),
+                                      oracle_port.sdfsq(arr, an, bb), equal_nan=True)
+
+
+def test_large_result_buffer_is_prefaulted_correctly(edt_gpu, oracle_port):
+    """>= 32 MiB results are first-touched by helper threads while the labels travel (csrc/edt_api.hip:
+    Prefault): the bytes that come back are still exactly the transform."""
+    lab = voronoi_labels((320, 256, 128), nseeds=300, seed=9, upsample=4)     # 40 MiB result
+    want = oracle_port.edtsq(lab, (1.0, 1.0, 2.0), False)
+    for _ in range(2):
+        assert np.array_equal(edt_gpu.edtsq(lab, anisotropy=(1.0, 1.0, 2.0), black_border=False), want)

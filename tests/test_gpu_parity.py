@@ -244,11 +244,46 @@ def test_long_runs_deep_hulls(edt_gpu, oracle_port):
                 assert same(got, want), (name, an, bb, explain(got, want))
 
 
-def test_cpp_drop_in_header_on_gpu(edt_gpu, tmp_path):
+def test_cpp_drop_in_header_on_gpu(edt_gpu, oracle_port, tmp_path):
+    """The C++ facade (cpp/edt.hpp + cpp/edt_voxel_graph.hpp): fixed known answers, then randomized parity --
+    cases written here from the CPU oracle, run by the C++ binary through the template of every label type
+    (1-D / 2-D / 3-D, voxel graphs, caller-owned and library-allocated outputs) and compared bit for bit."""
+    import struct
     import subprocess
     from test_abi import build_cpp_dropin
-    res = subprocess.run([build_cpp_dropin(tmp_path)], capture_output=True, text=True)
+    from oracle import harness
+    exe = build_cpp_dropin(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
+    rng = np.random.default_rng(2024)
+    dtypes = [np.uint8, np.uint16, np.uint32, np.uint64, np.float32, np.float64, bool]
+    blob = []
+    for t in range(60):
+        dims = 1 + t % 3
+        dt = dtypes[t % len(dtypes)]
+        shape = tuple(int(rng.integers(1, 40)) for _ in range(dims))
+        lab = blocky_labels(shape, nlabels=1 if dt is bool else 5, zero_frac=0.25, block=int(rng.integers(1, 7)),
+                            rng=rng).astype(dt)
+        lab = np.asfortranarray(lab)                       # x fastest, as the C++ API takes it
+        an = tuple(float(a) for a in ANISO[int(rng.integers(0, len(ANISO)))][:dims])
+        bb = bool(rng.integers(0, 2))
+        graph = None
+        if dims >= 2 and t % 4 == 0:
+            graph = np.asfortranarray(rng.integers(0, 64, size=shape).astype(np.uint8))
+            graph[rng.random(shape) < 0.7] = 0b00111111
+        want = oracle_port.edtsq(lab, an[0] if dims == 1 else an, bb, voxel_graph=graph)
+        ext = shape + (1,) * (3 - dims)
+        w = an + (1.0,) * (3 - dims)
+        code = harness._DTYPE_CODE[np.dtype(dt)]
+        blob.append(struct.pack("<7i3f", code, dims, ext[0], ext[1], ext[2], int(bb), int(graph is not None), *w))
+        blob.append(lab.tobytes(order="F"))
+        if graph is not None:
+            blob.append(graph.tobytes(order="F"))
+        blob.append(np.asfortranarray(want).astype(np.float32).tobytes(order="F"))
+    path = tmp_path / "cases.bin"
+    path.write_bytes(struct.pack("<i", 60) + b"".join(blob))
+    res = subprocess.run([exe, str(path)], capture_output=True, text=True)
+    assert res.returncode == 0 and "60 of 60" in res.stdout, res.stdout + res.stderr
 
 
 def test_device_resident_voxel_graph(edt_gpu):

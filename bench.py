@@ -262,6 +262,32 @@ def sharded_main(args, rank, world, dev):
     else:
         verified, how, cpu = _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev)
 
+    # the SAME kind of volume on ONE GPU (args.size^3 voxels of the same segmentation density, single-device
+    # path), timed on rank 0 while the others wait: what `value` of this weak-scaling line is to be compared with
+    # (the --gpus 1 line's headline is the single-label box, a lighter workload)
+    same_n1 = None
+    if rank == 0 and kind != "ones":
+        try:
+            from edt import device as _dev
+            cube = (args.size,) * 3
+            lab1 = slab_labels(cube, 0, args.size, dev, kind)
+            out1 = torch.empty(cube, dtype=torch.float32, device=dev)
+            plan1 = _dev.Plan(cube, _lib.U32, dev)
+            for _ in range(3):
+                plan1.run(lab1, an, black_border=bb, out=out1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                plan1.run(lab1, an, black_border=bb, out=out1)
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t1) / 10 * 1e3
+            same_n1 = {"ms_per_step": round(ms1, 4), "mvox_per_s": round(args.size ** 3 / ms1 / 1e3, 1),
+                       "what": f"{args.size}^3 voxels of the same segmentation on ONE GPU (single-device path), rank 0"}
+            del lab1, out1, plan1
+        except Exception as e:  # pragma: no cover
+            same_n1 = {"error": repr(e)}
+    dist.barrier()
+
     if rank == 0:
         vox = ext[0] * ext[1] * ext[2]
         # roofline of the dominant kernel ON ONE RANK: its algorithmic bytes (X reads
@@ -291,7 +317,8 @@ def sharded_main(args, rank, world, dev):
                                    "one all-to-all (Z-slabs -> Y-slabs) before the z pass",
                        "form": "slab records" if plan.records else "byte flags",
                        "chunks": getattr(plan, "nchunks", 1),
-                       "output_verified": verified, "verified_by": how},
+                       "output_verified": verified, "verified_by": how,
+                       "single_gpu_same_workload": same_n1},
             "roofline": roofline,
         }
         if cpu is not None:

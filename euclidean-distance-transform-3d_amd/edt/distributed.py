@@ -328,9 +328,12 @@ class ShardedEDT:
         if self._exchange == "alltoall":  # (also at world 1: a no-op that keeps the dry run honest)
             # one collective call per chunk (RCCL runs it as a group of sends / receives; every
             # peer pair has its own xGMI link); the own part is already in place -> empty entries
-            empty = dst[0:0]
-            ins = [empty if h == self.rank else blocks[h] for h in range(self.world)]
-            outs = [empty if h == self.rank else recv[h] for h in range(self.world)]
+            # (the own entry is a one-element dummy rather than an empty tensor: every entry of the list is an
+            # ordinary non-empty message, whatever the backend makes of zero-length ones)
+            if getattr(self, "_dummy", None) is None or self._dummy.device != dst.device:
+                self._dummy = torch.zeros(2, dtype=torch.float32, device=dst.device)
+            ins = [self._dummy[0:1] if h == self.rank else blocks[h] for h in range(self.world)]
+            outs = [self._dummy[1:2] if h == self.rank else recv[h] for h in range(self.world)]
             pending.append(dist.all_to_all(outs, ins, group=self.group, async_op=True))
         else:
             peers = [h for h in range(self.world) if h != self.rank]

@@ -10,20 +10,20 @@ namespace edt_amd {
 
 template <int CW>
 int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w, int bb, int epi,
-                  const XFuse *xf, hipStream_t stream, const BandScatter *scatter, bool sc_al);
-extern template int launch_wave_c<32>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool);
-extern template int launch_wave_c<16>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool);
-extern template int launch_wave_c<8>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool);
-extern template int launch_wave_c<4>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool);
-extern template int launch_wave_c<2>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool);
-extern template int launch_wave_c<1>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool);
+                  const XFuse *xf, hipStream_t stream, const BandScatter *scatter, bool sc_al, int out_stride);
+extern template int launch_wave_c<32>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
+extern template int launch_wave_c<16>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
+extern template int launch_wave_c<8>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
+extern template int launch_wave_c<4>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
+extern template int launch_wave_c<2>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
+extern template int launch_wave_c<1>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
 
 // Largest window of the windowed path (edt_colwave_lane.h: brute_band): a tile takes it when no row can be
 // improved by a row further than this away.  EDT_HIP_WINDOW_LIMIT overrides the default (experiments).
 int window_limit() {
   static const int v = [] {
     const char *e = getenv("EDT_HIP_WINDOW_LIMIT");
-    const int t = e ? atoi(e) : 128;
+    const int t = e ? atoi(e) : 192;
     return t < 0 ? 0 : (t > 1024 ? 1024 : t);
   }();
   return v;
@@ -36,22 +36,22 @@ bool column_pass_wave_supported(const AxisGeom &g) {
 
 static int launch_wave_any(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int bb, int epi, const XFuse *xf, hipStream_t stream,
-                           const BandScatter *sc = nullptr, bool sc_al = false) {
+                           const BandScatter *sc = nullptr, bool sc_al = false, int out_stride = 1) {
   const int64_t NB = g.nbands;
-  if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
-  if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
-  if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
-  if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al);
-  if (NB <= 32 && xf == nullptr) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, nullptr, stream, sc, sc_al);
-  if (NB <= 64 && xf == nullptr) return launch_wave_c<1>(F, nz, rs, g, w, bb, epi, nullptr, stream, sc, sc_al);
+  if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
+  if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
+  if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
+  if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
+  if (NB <= 32 && xf == nullptr) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, nullptr, stream, sc, sc_al, out_stride);
+  if (NB <= 64 && xf == nullptr) return launch_wave_c<1>(F, nz, rs, g, w, bb, epi, nullptr, stream, sc, sc_al, out_stride);
   set_error("axis too long for the wave column pass");
   return EDT_ERR_UNSUPPORTED;
 }
 
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                            float w, int bb, int epi, hipStream_t stream, const BandScatter *scatter) {
+                            float w, int bb, int epi, hipStream_t stream, const BandScatter *scatter, int out_stride) {
   // (the caller of the scattering variant guarantees 16-byte aligned destinations when sx % 4 == 0)
-  return launch_wave_any(F, nz, rs, g, w, bb, epi, nullptr, stream, scatter, scatter != nullptr);
+  return launch_wave_any(F, nz, rs, g, w, bb, epi, nullptr, stream, scatter, scatter != nullptr, out_stride);
 }
 
 // First column pass with pass 1 fused in: F is only written.  `meta` = row records of k_row_bits,

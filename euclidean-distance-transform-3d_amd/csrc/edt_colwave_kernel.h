@@ -52,6 +52,7 @@ struct BruteArgs {
   uint32_t limit_bits;  // a tile takes the path when the bit pattern of its largest field value is <= this; 0 = never
   int x32;              // candidates are fp32 sums (c_d exactly representable up to the limit)
   int force;            // diagnostics: every tile takes the path
+  int stride;           // 1: every row is evaluated; 2: only the even rows are (and written), see BruteSteps
 };
 int window_limit();  // edt_colwave.hip: largest window (rows) the windowed path is used for
 
@@ -108,7 +109,7 @@ __device__ __forceinline__ void scan_breaks(uint32_t brk, int row0, int n, int l
 // The windowed path of one lane (edt_colwave_lane.h: brute_band) as a function of its own -- NOT inlined, so
 // that its register allocation is separate from the hull path's (inlined into one body the two paths, each
 // close to the 128-register budget of four waves per SIMD, push each other into scratch).
-template <int CW, bool BB, bool X32>
+template <int CW, bool BB, bool X32, int S>
 __device__ __attribute__((noinline)) void brute_tile(float *tile, const uint32_t *alive, const uint32_t *rsp,
                                                      const uint32_t *lohi, const uint32_t *bscan, int n, int NB,
                                                      int cols_left, int band, int col, float w, int epi,
@@ -135,7 +136,7 @@ __device__ __attribute__((noinline)) void brute_tile(float *tile, const uint32_t
   auto store = [&](int row, float v) {
     if (row < n && colok) dst0[(int64_t)row * dstride] = v;
   };
-  brute_band<CW, BB, X32>(BL, epi, store);
+  brute_band<CW, BB, X32, S>(BL, epi, store);
 }
 
 template <int CW, bool BB, bool XF, bool SC>
@@ -317,8 +318,14 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         } else {
           dst0 = Ftile + col2;
         }
-        if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
-        else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
+        // (stride 2: only the even rows are evaluated and written -- the doubled grids of the voxel-graph transform)
+        if (ba.stride == 2) {
+          if (ba.x32) brute_tile<CW, BB, true, 2>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
+          else brute_tile<CW, BB, false, 2>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
+        } else {
+          if (ba.x32) brute_tile<CW, BB, true, 1>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
+          else brute_tile<CW, BB, false, 1>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
+        }
         return;
       }
     }
@@ -424,7 +431,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 template <int CW, bool BB, bool XF, bool SC>
 static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
-                           bool scatter_aligned) {
+                           bool scatter_aligned, int out_stride) {
   constexpr int NBP = 64 / CW;
   using TG = edt_lane::TileGeom<CW>;
   constexpr int TC = TG::kCols;
@@ -436,10 +443,17 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   ba.limit_bits = 0u;
   ba.x32 = 0;
   ba.force = 0;
+  ba.stride = (out_stride == 2 && !(debug_mode() & 0x40000)) ? 2 : 1;  // (debug bit 0x40000: evaluate every row)
   if (!XF && !(debug_mode() & 0x2000) && w * w >= 1.17549435e-38f && (double)w * (double)w < 1.0e30) {
     const bool force = (debug_mode() & 0x4000) != 0;
-    const int T = force ? (int)g.n : window_limit();
-    bool x32 = edt_lane::brute_exact32(w, T);
+    // The window limit: tools/window_sweep.py (smooth Voronoi cells of growing size, 512^3) puts the
+    // crossover with the hull path between windows of ~170 and ~270 rows.  fp32 candidates need c_d exact in
+    // fp32 up to the limit (w2 = 900: d <= 136): where exactness ends between 64 rows and the limit, the limit
+    // is lowered to it (fp32 candidates are ~25 % cheaper than fp64 ones; the tiles in between go to the hulls).
+    int T = force ? (int)g.n : window_limit();
+    const int exact = edt_lane::brute_exact_prefix(w, T);
+    bool x32 = exact >= T;
+    if (!x32 && !force && exact >= 64) { T = exact; x32 = true; }
     if (debug_mode() & 0x8000) x32 = false;  // diagnostics: fp64 candidates
     ba.x32 = x32 ? 1 : 0;
     const double cT = (double)(w * w) * (double)T * (double)T;
@@ -470,26 +484,26 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
 template <int CW, bool BB, bool XF>
 static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
-                           bool scatter_aligned) {
+                           bool scatter_aligned, int out_stride) {
   // the scattering epilogue (Z-sharded path) is a compile-time variant of the unfused kernel
   if constexpr (!XF) {
     if (scatter != nullptr)
-      return launch_wave_cbx_sc<CW, BB, false, true>(F, nz, rs, g, w, epi, xf, stream, scatter, scatter_aligned);
+      return launch_wave_cbx_sc<CW, BB, false, true>(F, nz, rs, g, w, epi, xf, stream, scatter, scatter_aligned, out_stride);
   }
-  return launch_wave_cbx_sc<CW, BB, XF, false>(F, nz, rs, g, w, epi, xf, stream, nullptr, false);
+  return launch_wave_cbx_sc<CW, BB, XF, false>(F, nz, rs, g, w, epi, xf, stream, nullptr, false, out_stride);
 }
 
 template <int CW>
 int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                          int bb, int epi, const XFuse *xf, hipStream_t stream, const BandScatter *scatter,
-                         bool sc_al) {
+                         bool sc_al, int out_stride) {
   // the border rule and the fused pass 1 are compile-time variants, the epilogue a run-time one
   const XFuse none = {nullptr, nullptr, 0, 0, 0};
   if (xf)
-    return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al)
-              : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al);
-  return bb ? launch_wave_cbx<CW, true, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al)
-            : launch_wave_cbx<CW, false, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al);
+    return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride)
+              : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride);
+  return bb ? launch_wave_cbx<CW, true, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al, out_stride)
+            : launch_wave_cbx<CW, false, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al, out_stride);
 }
 
 }  // namespace edt_amd

@@ -748,27 +748,30 @@ EDT_LANE float min3pos(float a, float b, float c) {
 // Flat blocks need no window at all.  If every link (row r-1 -> r inside a run) at distance <= D around the
 // block is flat, then for rows p, j of one run with |p-j| <= D:  F[j] >= F[p] - w2*|p-j| >= F[p] - c_|p-j|,
 // i.e. no row within D improves p; rows further away cannot either once c_(D+1) >= B_p.  Returns D for the
-// block of rows k0..k0+7: the distance to the nearest break of the whole column (breaks of other bands come
+// block of rows k0..k0+nrows-1: the distance to the nearest break of the whole column (breaks of other bands come
 // from the same kind of scan over the bands as the run structure).
-EDT_LANE int brute_flat_reach(const BruteLane &L, int k0) {
-  const uint32_t lowm = L.brk & (0xFFFFFFFFu >> (24 - k0));  // breaks at rows <= k0+7 of this band
+EDT_LANE int brute_flat_reach(const BruteLane &L, int k0, int nrows) {
+  const uint32_t lowm = L.brk & (0xFFFFFFFFu >> (32 - nrows - k0));  // breaks at rows < k0 + nrows of this band
   const int h = lowm ? L.row0 + 31 - clz32(lowm) : L.blo_in;
-  const uint32_t him = k0 + kBruteB < 32 ? L.brk & (0xFFFFFFFFu << (k0 + kBruteB)) : 0u;
+  const uint32_t him = k0 + nrows < 32 ? L.brk & (0xFFFFFFFFu << (k0 + nrows)) : 0u;
   const int l = him ? L.row0 + ctz32(him) : L.bhi_out;
   const int p0 = L.row0 + k0;
   const int dlo = h >= 0 ? p0 - h : 4095;
-  const int dhi = l < L.n ? l - p0 - kBruteB : 4095;  // (bhi_out >= n: no break above)
+  const int dhi = l < L.n ? l - p0 - nrows : 4095;  // (bhi_out >= n: no break above)
   const int d = dlo < dhi ? dlo : dhi;
   return d > 0 ? d : 0;
 }
 
 // The steps of the window as a compile-time recursion (every index into the register window is static):
 // steps D and D+1 share one exit test; past the register-resident part the rows come straight from the tile.
-template <int CW, bool X32>
+// S = output stride: 1 = every row of the block is evaluated; 2 = a block is 16 rows of which the even ones
+// are evaluated (the doubled grids of the voxel-graph transform, whose odd rows are never read again) --
+// every row is a candidate either way.
+template <int CW, bool X32, int S>
 struct BruteSteps {
-  static constexpr int K = kBruteK, B = kBruteB, TC = TileGeom<CW>::kCols;
+  static constexpr int K = kBruteK, B = kBruteB, TC = TileGeom<CW>::kCols, NR = S * B;  // NR rows per block
   const BruteLane &L;
-  float (&w)[B + 2 * K];
+  float (&w)[NR + 2 * K];
   float (&best)[B];
   double (&best64)[B];
   const float *PL0, *PL1, *PH0, *PH1;
@@ -788,25 +791,67 @@ struct BruteSteps {
       if (X32 ? !EDT_ANY(c1f < bmaxf) : !EDT_ANY(c1 < bmax64)) return;
       // the rows that enter the window in these two steps
       w[K - D] = (D <= k0 ? PL0 : PL1)[(K - D) * TC];
-      w[K + B - 1 + D] = (D <= 32 - B - k0 ? PH0 : PH1)[D * TC];
+      w[K + NR - 1 + D] = (D <= 32 - NR - k0 ? PH0 : PH1)[D * TC];
       w[K - D - 1] = (D + 1 <= k0 ? PL0 : PL1)[(K - D - 1) * TC];
-      w[K + B + D] = (D + 1 <= 32 - B - k0 ? PH0 : PH1)[(D + 1) * TC];
+      w[K + NR + D] = (D + 1 <= 32 - NR - k0 ? PH0 : PH1)[(D + 1) * TC];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
       for (int ii = 0; ii < B; ++ii) {
         // (the first and the last row of the block need the rows just requested: they come last)
         const int i = ii < B - 2 ? ii + 1 : (ii == B - 2 ? 0 : B - 1);
-        const float m1 = minpos(w[K + i - D], w[K + i + D]);
-        const float m2 = minpos(w[K + i - D - 1], w[K + i + D + 1]);
+        const float m1 = minpos(w[K + S * i - D], w[K + S * i + D]);
+        const float m2 = minpos(w[K + S * i - D - 1], w[K + S * i + D + 1]);
         // (sums of non-negative terms: integer minima, no canonicalisation of the operands)
         if (X32) best[i] = min3pos(best[i], m1 + c1f, m2 + c2f);
         else best64[i] = fmin(best64[i], fmin((double)m1 + c1, (double)m2 + c2));
       }
       run<D + 2>();
-    } else if constexpr (!X32) {
+    } else if constexpr (X32 && S == 2) {
+      // Windows beyond the register-resident part, blocks of 16 rows with the even ones evaluated: at step d
+      // output i looks at the rows p0+2i-d (entered at step d-2i) and p0+2i+d (entered at step d-15+2i) --
+      // the last 16 entries of either side: rings of 16 registers indexed by d mod 16, one step per exit test.
+      constexpr int R = 16;
+      static_assert((K % R) == 0 && NR == R, "ring phase / size");
+      const int p0 = L.row0 + k0;
+      float rlo[R], rhi[R];  // slot s: the row that entered at a step congruent to s (mod R)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int s = K - R + 2; s <= K; ++s) {  // the last 15 rows of the register-resident window on either side
+        rlo[s % R] = w[K - s];
+        rhi[s % R] = w[K + NR - 1 + s];
+      }
+      auto row_at = [&](int r) -> float {
+        r = r < -1 ? -1 : (r > nb32 ? nb32 : r);
+        return L.tile[addr_tile<CW>(L.col, r)];
+      };
+      for (int d0 = K + 1; d0 < 4096; d0 += R) {
+        bool done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int e = 0; e < R; ++e) {  // step d = d0 + e;  d mod R == (1 + e) mod R
+          const int d = d0 + e;
+          const double c = w2 * (double)(d * d);  // exact, and so is its fp32 form (X32)
+          const float cf = (float)c;
+          if (!EDT_ANY(c < bmax64)) { done = true; break; }
+          const int sl = (1 + e) % R;
+          rlo[sl] = row_at(p0 - d);
+          rhi[sl] = row_at(p0 + NR - 1 + d);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+          for (int i = 0; i < B; ++i) {
+            const float m = minpos(rlo[(sl - 2 * i + 2 * R) % R], rhi[(sl - (NR - 1) + 2 * i + 2 * R) % R]);
+            best[i] = minpos(best[i], m + cf);
+          }
+        }
+        if (done) break;
+      }
+    } else if constexpr (!X32 || S != 1) {
       // Windows beyond the register-resident part, fp64 candidates (the rarer form: 16 more registers of
-      // minima): one step at a time, every row straight from the tile.
+      // minima) and strided blocks: one step at a time, every row straight from the tile.
       for (int d = K + 1; d < 4096; ++d) {
         const double cd = w2 * (double)(d * d);  // exact
         if (!EDT_ANY(cd < bmax64)) break;
@@ -814,11 +859,12 @@ struct BruteSteps {
 #pragma unroll
 #endif
         for (int i = 0; i < B; ++i) {
-          int rl = L.row0 + k0 + i - d, rh = L.row0 + k0 + i + d;
+          int rl = L.row0 + k0 + S * i - d, rh = L.row0 + k0 + S * i + d;
           rl = rl < -1 ? -1 : rl;        // row -1 and row nb32 are +inf rows
           rh = rh > nb32 ? nb32 : rh;
           const float m = minpos(L.tile[addr_tile<CW>(L.col, rl)], L.tile[addr_tile<CW>(L.col, rh)]);
-          best64[i] = fmin(best64[i], (double)m + cd);
+          if (X32) best[i] = minpos(best[i], m + (float)cd);  // (X32: c_d is exact in fp32)
+          else best64[i] = fmin(best64[i], (double)m + cd);
         }
       }
     } else {
@@ -875,9 +921,9 @@ struct BruteSteps {
   }
 };
 
-template <int CW, bool BB, bool X32, class Store>
+template <int CW, bool BB, bool X32, int S, class Store>
 EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
-  constexpr int K = kBruteK, B = kBruteB, TC = TileGeom<CW>::kCols;
+  constexpr int K = kBruteK, B = kBruteB, TC = TileGeom<CW>::kCols, NR = S * B;
   const int row0 = L.row0, n = L.n;
   const uint32_t rsw = L.rsw;
   // the lane's column in its own band and in the bands below / above (the band rotation of the tile
@@ -891,35 +937,35 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int k0 = 0; k0 < 32; k0 += B) {
-    float w[B + 2 * K];  // w[K + i] = F(row0 + k0 + i); the window grows by one row per side and step
+  for (int k0 = 0; k0 < 32; k0 += NR) {
+    float w[NR + 2 * K];  // w[K + j] = F(row0 + k0 + j); the window grows by one row per side and step
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < B; ++i) w[K + i] = A0[(k0 + i) * TC];
+    for (int j = 0; j < NR; ++j) w[K + j] = A0[(k0 + j) * TC];
     // rows below k0 come from this band while d <= k0, from the band below afterwards; likewise above
     const float *PL0 = A0 + (k0 - K) * TC, *PL1 = Am + (k0 + 32 - K) * TC;
-    const float *PH0 = A0 + (k0 + B - 1) * TC, *PH1 = Ap + (k0 + B - 1 - 32) * TC;
+    const float *PH0 = A0 + (k0 + NR - 1) * TC, *PH1 = Ap + (k0 + NR - 1 - 32) * TC;
     // ---- B_p of the block's rows ----
     // Distances to the border sites just outside the run, as floats counted from run start to run start
     // (exact small integers; +inf where there is no border on that side, which then stays +inf through
     // the count, the square and the product).  dl is carried from block to block.
-    const uint32_t s8 = rsw >> k0;  // bit i: a run starts at row k0 + i
-    float dlv[B];
+    const uint32_t s8 = rsw >> k0;  // bit j: a run starts at row k0 + j
+    float dlv[B];  // of the evaluated rows (every S-th row of the block)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < B; ++i) {
+    for (int j = 0; j < NR; ++j) {
       // a run that starts at row 0 of the column has a border below it only with black_border
-      const float first = (BB || i > 0) ? 1.0f : (row0 + k0 > 0 ? 1.0f : INFINITY);
-      dl = ((s8 >> i) & 1u) ? first : dl + 1.0f;
-      dlv[i] = dl;
+      const float first = (BB || j > 0) ? 1.0f : (row0 + k0 > 0 ? 1.0f : INFINITY);
+      dl = ((s8 >> j) & 1u) ? first : dl + 1.0f;
+      if (j % S == 0) dlv[j / S] = dl;
     }
     float dr;  // distance to the first row of the next run, as seen from the row above the block
     {
-      const uint32_t m = k0 + B < 32 ? rsw & (0xFFFFFFFFu << (k0 + B)) : 0u;
+      const uint32_t m = k0 + NR < 32 ? rsw & (0xFFFFFFFFu << (k0 + NR)) : 0u;
       const int e = m ? row0 + ctz32(m) : L.hi_out + 1;
-      dr = (BB || e < n) ? (float)(e - (row0 + k0 + B)) : INFINITY;
+      dr = (BB || e < n) ? (float)(e - (row0 + k0 + NR)) : INFINITY;
     }
     float best[B];
     double best64[B];
@@ -927,19 +973,22 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = B - 1; i >= 0; --i) {
+    for (int j = NR - 1; j >= 0; --j) {
       dr += 1.0f;
-      const float dm = minpos(dlv[i], dr);
-      // fl32(w2 * d^2) is one exact-product fp32 multiply (as in phase3_eval); background rows hold 0
-      const float bord = L.w2f * (dm * dm);
-      float b = minpos(w[K + i], bord);
-      // rows that complete the last band (no real row holds +inf) and lanes without a column
-      if (f2u(w[K + i]) == 0x7f800000u || !L.live) b = 0.0f;
-      best[i] = b;
-      if (!X32) best64[i] = (double)b;
-      const uint32_t ub = f2u(b);
-      bmax = ub > bmax ? ub : bmax;
-      if ((s8 >> i) & 1u) dr = 0.0f;  // (a set bit is a real row: the border site of the rows below it)
+      if (j % S == 0) {
+        const int i = j / S;
+        const float dm = minpos(dlv[i], dr);
+        // fl32(w2 * d^2) is one exact-product fp32 multiply (as in phase3_eval); background rows hold 0
+        const float bord = L.w2f * (dm * dm);
+        float b = minpos(w[K + j], bord);
+        // rows that complete the last band (no real row holds +inf) and lanes without a column
+        if (f2u(w[K + j]) == 0x7f800000u || !L.live) b = 0.0f;
+        best[i] = b;
+        if (!X32) best64[i] = (double)b;
+        const uint32_t ub = f2u(b);
+        bmax = ub > bmax ? ub : bmax;
+      }
+      if ((s8 >> j) & 1u) dr = 0.0f;  // (a set bit is a real row: the border site of the rows below it)
     }
     const float bmaxf = u2f(bmax);
     const double bmax64 = (double)bmaxf;
@@ -947,7 +996,7 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
     bool open = true;  // some row of the wave may still improve
     EDT_STAT(13, k0, 1);
     {
-      const int D = brute_flat_reach(L, k0);
+      const int D = brute_flat_reach(L, k0, NR);
       const double cD = L.w2 * (double)((D + 1) * (D + 1));
       if (!EDT_ANY(cD < bmax64)) open = false;
     }
@@ -961,8 +1010,8 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
       double w2 = L.w2;
       EDT_OPAQUE(w2f);
       EDT_OPAQUE(w2);
-      BruteSteps<CW, X32> S{L, w, best, best64, PL0, PL1, PH0, PH1, k0, bmaxf, bmax64, nb32, w2f, w2};
-      S.template run<1>();
+      BruteSteps<CW, X32, S> steps{L, w, best, best64, PL0, PL1, PH0, PH1, k0, bmaxf, bmax64, nb32, w2f, w2};
+      steps.template run<1>();
     }
     // ---- epilogue (src/edt.hpp:47-53, :599-601) and the rows leave ----
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -982,19 +1031,22 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < B; ++i) store(row0 + k0 + i, best[i]);
+    for (int i = 0; i < B; ++i) store(row0 + k0 + S * i, best[i]);
   }
 }
 
-// Is c_d = w2 * d^2 exactly representable in fp32 for every d up to `want` (then the candidates of the
-// windowed path are fp32 sums)?
-inline bool brute_exact32(float w, int want) {
+// The largest D <= want such that c_d = w2 * d^2 is exactly representable in fp32 for every d <= D (then the
+// candidates of the windowed path may be fp32 sums up to windows of D rows).
+inline int brute_exact_prefix(float w, int want) {
   const double w2 = (double)(w * w);
-  for (int d = 1; d <= want; ++d) {
-    const double c = w2 * (double)d * (double)d;
-    if ((double)(float)c != c || !(c < 3.0e38)) return false;
+  int d = 0;
+  while (d < want) {
+    const double c = w2 * (double)(d + 1) * (double)(d + 1);
+    if ((double)(float)c != c || !(c < 3.0e38)) break;
+    ++d;
   }
-  return true;
+  return d;
 }
+inline bool brute_exact32(float w, int want) { return brute_exact_prefix(w, want) >= want; }
 
 }  // namespace edt_lane

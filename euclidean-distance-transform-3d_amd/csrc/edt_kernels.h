@@ -106,9 +106,11 @@ struct XFuse {
 // ---- wave-autonomous LDS-tiled column pass: edt_colwave.hip -----------------------------------
 bool column_pass_wave_supported(const AxisGeom &g);
 // scatter != nullptr (device table): the rows are written to the slab records instead of F
+// out_stride = 2: only the even rows of every column are needed (tiles on the windowed path evaluate and write
+// just those; tiles on the hull path still write every row)
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                             float w, int bb, int epi, hipStream_t stream,
-                            const BandScatter *scatter = nullptr);
+                            const BandScatter *scatter = nullptr, int out_stride = 1);
 // the same with pass 1 fused in (F is write-only): needs the row records + T of edt_rowwave.hip
 int launch_column_pass_wave_xfused(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                                    float w, int bb, int epi, const void *meta, const float *ttab,

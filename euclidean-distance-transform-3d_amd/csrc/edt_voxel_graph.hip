@@ -150,7 +150,9 @@ __global__ void k_vg_ttab(float *__restrict__ ttab, float w, int count) {
   ttab[count] = INFINITY;
 }
 
-// Pass X of the doubled grid, even cells only: one wave per doubled row (Y, Z) -> sx floats.
+// Pass X of the doubled grid, even cells only: one wave per VOXEL row (y, z) produces its doubled rows
+// (Y, Z) = (2y + yp, 2z + zp) -- four in 3-D, two in 2-D -- from ONE read of the row's label and graph bytes;
+// the four independent computations also give the scalar / shuffle chains something to overlap with.
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const float *__restrict__ ttab,
@@ -160,23 +162,24 @@ k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   const int NC = (sx + 63) >> 6;  // <= 32 (launcher)
-  const int64_t nrows = (int64_t)Y2 * Z2;
-  const uint64_t below = (1ull << lane) - 1ull;            // lanes before this one
-  const uint64_t above = lane < 63 ? ~((2ull << lane) - 1ull) : 0ull;  // lanes after it
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < nrows; row += (int64_t)gridDim.x * 4) {
-    const int Y = (int)(row % Y2), Z = (int)(row / Y2);
-    const int y = Y >> 1, z = Z >> 1, yp = Y & 1, zp = Z & 1;
-    float *out = F1 + row * sx;
-    if (bb && ((yp && y == sy - 1) || (zp && Z2 > 1 && z == sz - 1))) {  // trimmed row: all background
-      for (int c = 0; c < NC; ++c)
-        if (c * 64 + lane < sx) out[c * 64 + lane] = 0.0f;
-      continue;
-    }
-    const T *lrow = labels + ((int64_t)z * sy + y) * sx;
-    const uint8_t *grow = graph + ((int64_t)z * sy + y) * sx;
-    // ---- phase A: the cells of every 64-voxel chunk; last / first background cell per chunk ----
-    uint32_t flagsE = 0, flagsO = 0;        // bit c: this lane's even / odd cell of chunk c is FOREGROUND
-    int lastz = -kVgFar, firstz = kVgFar;   // lane c: last / first background cell (doubled coordinate) of chunk c
+  const int NQ = Z2 > 1 ? 4 : 2;  // doubled rows per voxel row
+  const int64_t nvrows = (int64_t)sy * (Z2 > 1 ? sz : 1);
+  const uint64_t below = (1ull << lane) - 1ull;                         // lanes before this one
+  const uint64_t above = lane < 63 ? ~((2ull << lane) - 1ull) : 0ull;   // lanes after it
+  for (int64_t vrow = (int64_t)blockIdx.x * 4 + wave; vrow < nvrows; vrow += (int64_t)gridDim.x * 4) {
+    const int y = (int)(vrow % sy), z = (int)(vrow / sy);
+    const T *lrow = labels + vrow * sx;
+    const uint8_t *grow = graph + vrow * sx;
+    // a doubled row trimmed by black_border is all background (src/edt_voxel_graph.hpp:156-187)
+    bool dead[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      dead[q] = bb && (((q & 1) && y == sy - 1) || ((q >> 1) && Z2 > 1 && z == sz - 1));
+    // ---- phase A: the cells of every 64-voxel chunk; last / first background cell per chunk and row ----
+    uint32_t flagsE[4] = {0, 0, 0, 0}, flagsO[4] = {0, 0, 0, 0};  // bit c: the lane's even / odd cell is FOREGROUND
+    int lastz[4], firstz[4];  // lane c: last / first background cell (doubled coordinate) of chunk c
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { lastz[q] = -kVgFar; firstz[q] = kVgFar; }
     for (int c = 0; c < NC; ++c) {
       const int x = c * 64 + lane;
       const bool valid = x < sx;
@@ -186,61 +189,74 @@ k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const
         fg = vg_fg(lrow[x]);
         g = grow[x];
       }
-      const bool E = vg_even_cell(fg, g, yp, zp);
-      bool O = vg_odd_cell(fg, g, yp, zp);
-      if (bb && x == sx - 1) O = false;
-      flagsE |= (E ? 1u : 0u) << c;
-      flagsO |= (O ? 1u : 0u) << c;
-      const uint64_t zE = __ballot(valid && !E), zO = __ballot(valid && !O);
-      int lz = -kVgFar, fz = kVgFar;
-      if (zE) {
-        lz = 2 * (c * 64 + 63 - __builtin_clzll(zE));
-        fz = 2 * (c * 64 + __builtin_ctzll(zE));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q >= NQ) break;
+        const bool E = !dead[q] && vg_even_cell(fg, g, q & 1, q >> 1);
+        bool O = !dead[q] && vg_odd_cell(fg, g, q & 1, q >> 1);
+        if (bb && x == sx - 1) O = false;
+        flagsE[q] |= (E ? 1u : 0u) << c;
+        flagsO[q] |= (O ? 1u : 0u) << c;
+        const uint64_t zE = __ballot(valid && !E), zO = __ballot(valid && !O);
+        int lz = -kVgFar, fz = kVgFar;
+        if (zE) {
+          lz = 2 * (c * 64 + 63 - __builtin_clzll(zE));
+          fz = 2 * (c * 64 + __builtin_ctzll(zE));
+        }
+        if (zO) {
+          const int l2 = 2 * (c * 64 + 63 - __builtin_clzll(zO)) + 1, f2 = 2 * (c * 64 + __builtin_ctzll(zO)) + 1;
+          lz = l2 > lz ? l2 : lz;
+          fz = f2 < fz ? f2 : fz;
+        }
+        if (lane == c) { lastz[q] = lz; firstz[q] = fz; }
       }
-      if (zO) {
-        const int l2 = 2 * (c * 64 + 63 - __builtin_clzll(zO)) + 1, f2 = 2 * (c * 64 + __builtin_ctzll(zO)) + 1;
-        lz = l2 > lz ? l2 : lz;
-        fz = f2 < fz ? f2 : fz;
-      }
-      if (lane == c) { lastz = lz; firstz = fz; }
     }
-    // exclusive prefix max of lastz / exclusive suffix min of firstz over the chunks (lanes), seeded
-    // with the border sites just outside the row (black_border) or "none"
-    int prev = __shfl_up(lastz, 1), next = __shfl_down(firstz, 1);
-    if (lane == 0) prev = bb ? -1 : -kVgFar;
-    if (lane >= NC - 1) next = bb ? 2 * sx : kVgFar;
+    // exclusive prefix max of lastz / exclusive suffix min of firstz over the chunks (lanes), seeded with the
+    // border sites just outside the row (black_border) or "none"
+    int prev[4], next[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      prev[q] = __shfl_up(lastz[q], 1);
+      next[q] = __shfl_down(firstz[q], 1);
+      if (lane == 0) prev[q] = bb ? -1 : -kVgFar;
+      if (lane >= NC - 1) next[q] = bb ? 2 * sx : kVgFar;
+    }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const int tp = __shfl_up(prev, d), tn = __shfl_down(next, d);
-      if (lane >= d) prev = tp > prev ? tp : prev;
-      if (lane + d < 64) next = tn < next ? tn : next;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int tp = __shfl_up(prev[q], d), tn = __shfl_down(next[q], d);
+        if (lane >= d) prev[q] = tp > prev[q] ? tp : prev[q];
+        if (lane + d < 64) next[q] = tn < next[q] ? tn : next[q];
+      }
     }
     // ---- phase B: distances to the nearest background cell on either side, table look-up, square ----
     for (int c = 0; c < NC; ++c) {
       const int x = c * 64 + lane;
       const bool valid = x < sx;
-      const bool E = (flagsE >> c) & 1u, O = (flagsO >> c) & 1u;
-      const uint64_t zE = __ballot(valid && !E), zO = __ballot(valid && !O);
-      const int pv = __shfl(prev, c), nx = __shfl(next, c);
-      int Xl = pv, Xr = nx;
-      {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q >= NQ) break;
+        const bool E = (flagsE[q] >> c) & 1u, O = (flagsO[q] >> c) & 1u;
+        const uint64_t zE = __ballot(valid && !E), zO = __ballot(valid && !O);
+        int Xl = __shfl(prev[q], c), Xr = __shfl(next[q], c);
         const uint64_t mE = zE & below, mO = zO & below;
         if (mE) { const int p = 2 * (c * 64 + 63 - __builtin_clzll(mE)); Xl = p > Xl ? p : Xl; }
         if (mO) { const int p = 2 * (c * 64 + 63 - __builtin_clzll(mO)) + 1; Xl = p > Xl ? p : Xl; }
         const uint64_t nE = zE & above, nO = zO & (above | (1ull << lane));  // the own odd cell lies to the right
         if (nE) { const int p = 2 * (c * 64 + __builtin_ctzll(nE)); Xr = p < Xr ? p : Xr; }
         if (nO) { const int p = 2 * (c * 64 + __builtin_ctzll(nO)) + 1; Xr = p < Xr ? p : Xr; }
+        const int X = 2 * x;
+        int il = X - Xl, ir = Xr - X;
+        il = il < idx_inf ? il : idx_inf;
+        ir = ir < idx_inf ? ir : idx_inf;
+        const float tl = Tl[il], tr = Tl[ir];
+        const float d = tl < tr ? tl : tr;
+        float f = d * d;                                    // `d[i] *= d[i]` (src/edt.hpp:116-118)
+        if (!bb && f >= INFINITY) f = 3.402823466e+38f;     // tofinite (src/edt.hpp:39-45)
+        if (!E) f = 0.0f;
+        if (valid) F1[((int64_t)(2 * z + (q >> 1)) * Y2 + (2 * y + (q & 1))) * sx + x] = f;
       }
-      const int X = 2 * x;
-      int il = X - Xl, ir = Xr - X;
-      il = il < idx_inf ? il : idx_inf;
-      ir = ir < idx_inf ? ir : idx_inf;
-      const float tl = Tl[il], tr = Tl[ir];
-      const float d = tl < tr ? tl : tr;
-      float f = d * d;                                            // `d[i] *= d[i]` (src/edt.hpp:116-118)
-      if (!bb && f >= INFINITY) f = 3.402823466e+38f;             // tofinite (src/edt.hpp:39-45)
-      if (!E) f = 0.0f;
-      if (valid) out[x] = f;
     }
   }
 }
@@ -252,29 +268,55 @@ template <typename T, bool ALONG_Z>
 __global__ void __launch_bounds__(256)
 k_vg_bits(const T *__restrict__ labels, const uint8_t *__restrict__ graph, uint32_t *__restrict__ nz,
           uint32_t *__restrict__ rs, int sx, int sy, int sz, int Y2, int Z2, int nwords, int bb) {
-  // ALONG_Z: outer = y (sy of them), axis = Z2;  else: outer = Z (Z2 of them), axis = Y2
+  // ALONG_Z: outer = y (sy of them), axis = Z2;  else: outer = Z (Z2 of them), axis = Y2.
+  // A word covers 32 doubled rows = 16 voxels along the axis, each read once (two cells per voxel).
   const int64_t nouter = ALONG_Z ? sy : Z2;
   const int64_t total = (int64_t)sx * nwords * nouter;
-  const int n2 = ALONG_Z ? Z2 : Y2;
+  const int n2 = ALONG_Z ? Z2 : Y2, nvox = ALONG_Z ? sz : sy;
+  const int64_t vstride = ALONG_Z ? (int64_t)sx * sy : sx;  // between consecutive voxels along the axis
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int x = (int)(idx % sx);
     const int wd = (int)((idx / sx) % nwords);
     const int o = (int)(idx / ((int64_t)sx * nwords));
-    auto cell = [&](int r) -> bool {  // even-X cell at axis position r (0 <= r < n2)
-      int Y, Z;
-      if (ALONG_Z) { Y = 2 * o; Z = r; } else { Y = r; Z = o; }
-      const int y = Y >> 1, z = Z >> 1, yp = Y & 1, zp = Z & 1;
-      if (bb && ((yp && y == sy - 1) || (zp && Z2 > 1 && z == sz - 1))) return false;
-      const int64_t src = x + (int64_t)sx * (y + (int64_t)sy * z);
-      return vg_even_cell(vg_fg(labels[src]), graph[src], yp, zp);
+    // the fixed coordinates: ALONG_Z -> the even row 2*o (yp = 0); else slice Z = o (zp = o & 1, z = o >> 1)
+    const int zfix = ALONG_Z ? 0 : (o >> 1), zp = ALONG_Z ? 0 : (o & 1);
+    if (!ALONG_Z && bb && zp && Z2 > 1 && zfix == sz - 1) {  // trimmed slice: all background
+      nz[idx] = 0u;
+      rs[idx] = wd == 0 ? 1u : 0u;
+      continue;
+    }
+    const int64_t base = ALONG_Z ? x + (int64_t)sx * o : x + (int64_t)sx * sy * zfix;
+    // the two cells of voxel v along the axis: even position 2v, odd position 2v+1
+    auto cells = [&](int v, bool &c0, bool &c1) {
+      const int64_t src = base + vstride * v;
+      const bool fg = vg_fg(labels[src]);
+      const uint32_t g = graph[src];
+      if (ALONG_Z) {  // (Y even) Z = 2v: fg; Z = 2v+1: fg && +z edge
+        c0 = fg;
+        c1 = fg && (g & 0x10u);
+        if (bb && v == sz - 1) c1 = false;
+      } else {        // Y = 2v: even cell of (yp = 0, zp); Y = 2v+1: (yp = 1, zp)
+        c0 = vg_even_cell(fg, g, 0, zp);
+        c1 = vg_even_cell(fg, g, 1, zp);
+        if (bb && v == sy - 1) c1 = false;
+      }
     };
     uint32_t w = 0;
-    for (int r = 0; r < 32; ++r) {
-      const int p = wd * 32 + r;
-      if (p < n2 && cell(p)) w |= 1u << r;
+    const int v0 = wd * 16;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      if (v0 + k >= nvox) break;
+      bool c0, c1;
+      cells(v0 + k, c0, c1);
+      w |= (c0 ? 1u : 0u) << (2 * k) | (c1 ? 1u : 0u) << (2 * k + 1);
     }
-    const uint32_t carry = wd > 0 ? (cell(wd * 32 - 1) ? 1u : 0u) : 0u;
+    uint32_t carry = 0;
+    if (wd > 0) {
+      bool c0, c1;
+      cells(v0 - 1, c0, c1);
+      carry = c1 ? 1u : 0u;
+    }
     uint32_t rsw = w ^ ((w << 1) | carry);
     if (wd == 0) rsw |= 1u;
     const int valid = n2 - wd * 32;  // rows of this word that exist
@@ -340,9 +382,9 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
   const float hx = wx / 2, hy = wy / 2, hz = wz / 2;
   hipLaunchKernelGGL(k_vg_ttab, dim3(1), dim3(64), 0, stream, ttab, hx, idx_inf);
   {
-    const int64_t nrows = Y2 * Z2;
-    int64_t blocks = ceil_div(nrows, 4);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const int64_t nvrows = sy * (ndim == 3 ? sz : 1);  // one wave per voxel row (its 2 or 4 doubled rows)
+    int64_t blocks = ceil_div(nvrows, 4);
+    if (blocks > 256 * 32) blocks = 256 * 32;
     static std::atomic<uint64_t> attr_done{0};
     EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_vg_rows<T>)));
     hipLaunchKernelGGL(k_vg_rows<T>, dim3((unsigned)blocks), dim3(256), (size_t)(idx_inf + 1) * sizeof(float), stream,
@@ -359,7 +401,8 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
   const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0);
   AxisGeom gy;
   gy.sx = sx; gy.n = Y2; gy.stride = sx; gy.nouter = Z2; gy.outer_stride = sx * Y2; gy.nbands = nbY;
-  int rc = launch_column_pass_wave(F1, nzY, rsY, gy, hy, bb, ndim == 2 ? last_epi : 0, stream);
+  // (only the even rows of the doubled columns are read again: by the z pass / the gather)
+  int rc = launch_column_pass_wave(F1, nzY, rsY, gy, hy, bb, ndim == 2 ? last_epi : 0, stream, nullptr, 2);
   if (rc != EDT_OK) return rc;
   if (ndim == 3) {
     const int64_t total = sx * nbZ * sy;
@@ -370,7 +413,7 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
     EDT_HIP_TRY(hipGetLastError());
     AxisGeom gz;  // the even rows only: outer index = y, two doubled rows apart
     gz.sx = sx; gz.n = Z2; gz.stride = sx * Y2; gz.nouter = sy; gz.outer_stride = 2 * sx; gz.nbands = nbZ;
-    rc = launch_column_pass_wave(F1, nzZ, rsZ, gz, hz, bb, last_epi, stream);
+    rc = launch_column_pass_wave(F1, nzZ, rsZ, gz, hz, bb, last_epi, stream, nullptr, 2);
     if (rc != EDT_OK) return rc;
   }
   int64_t blocks = ceil_div(sx * sy * sz, 256);

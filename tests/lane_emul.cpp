@@ -32,7 +32,7 @@ namespace {
 
 template <int CW, bool BB>
 void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t sx, int n, int NB,
-               int64_t stride, int64_t x0, float w, int epi, const XRowMeta *meta = nullptr,
+               int64_t rstride, int64_t x0, float w, int epi, const XRowMeta *meta = nullptr,
                const float *Ttab = nullptr, int idx_inf = 0, int flim = 0, int mode = 0) {
   constexpr int NBP = 64 / CW;
   using TG = TileGeom<CW>;
@@ -52,14 +52,14 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
       for (int lane = 0; lane < 64; ++lane) {
         const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
         if (row < n && gc < cols_left)
-          std::memcpy(&tile[(size_t)io_lds_word<CW, 4>(i, lane)], F + x0 + (int64_t)row * stride + gc, 16);
+          std::memcpy(&tile[(size_t)io_lds_word<CW, 4>(i, lane)], F + x0 + (int64_t)row * rstride + gc, 16);
       }
   } else {
     for (int i = 0; i < IO::count(NBP, 1); ++i)
       for (int lane = 0; lane < 64; ++lane) {
         const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
         if (row < n && gc < cols_left)
-          std::memcpy(&tile[(size_t)io_lds_word<CW, 1>(i, lane)], F + x0 + (int64_t)row * stride + gc, 4);
+          std::memcpy(&tile[(size_t)io_lds_word<CW, 1>(i, lane)], F + x0 + (int64_t)row * rstride + gc, 4);
       }
   }
   struct PerLane { Lane L; float f[32]; uint32_t aw, flat; Hull1 H; };
@@ -120,7 +120,11 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
   }
   // ---- the windowed path (edt_colwave_lane.h: brute_band) -------------------------------------
   // mode 0: hulls only; 1 / 2: every tile takes the windowed path (fp32 candidates when exact / fp64
-  // candidates); 3: the kernel's per-tile choice (field small everywhere -> windowed path)
+  // candidates); 3: the kernel's per-tile choice (field small everywhere -> windowed path); 4 / 5: as 1 / 2 with
+  // output stride 2 (only the even rows are evaluated and written)
+  const int stride = (mode == 4 || mode == 5) ? 2 : 1;
+  if (mode == 4) mode = 1;
+  if (mode == 5) mode = 2;
   if (mode != 0 && meta == nullptr) {
     const int want = mode == 3 ? 96 : n;
     bool x32 = brute_exact32(w, want);
@@ -171,11 +175,16 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
           BL.live = col < cols_left && band < NB;
           BL.w2 = (double)(w * w); BL.w2f = w * w;
           auto store = [&](int row, float v) { res[(size_t)row * TC + col] = v; };
-          if (x32) brute_band<CW, BB, true>(BL, epi, store);
-          else brute_band<CW, BB, false>(BL, epi, store);
+          if (stride == 2) {
+            if (x32) brute_band<CW, BB, true, 2>(BL, epi, store);
+            else brute_band<CW, BB, false, 2>(BL, epi, store);
+          } else {
+            if (x32) brute_band<CW, BB, true, 1>(BL, epi, store);
+            else brute_band<CW, BB, false, 1>(BL, epi, store);
+          }
         }
-      for (int row = 0; row < n; ++row)
-        for (int c = 0; c < TC && c < cols_left; ++c) F[x0 + (int64_t)row * stride + c] = res[(size_t)row * TC + c];
+      for (int row = 0; row < n; row += stride)
+        for (int c = 0; c < TC && c < cols_left; ++c) F[x0 + (int64_t)row * rstride + c] = res[(size_t)row * TC + c];
       return;
     }
   }
@@ -248,14 +257,14 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
       for (int lane = 0; lane < 64; ++lane) {
         const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
         if (row < n && gc < cols_left)
-          std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<CW, 4>(i, lane)], 16);
+          std::memcpy(F + x0 + (int64_t)row * rstride + gc, &tile[(size_t)io_lds_word<CW, 4>(i, lane)], 16);
       }
   } else {
     for (int i = 0; i < IO::count(NBP, 1); ++i)
       for (int lane = 0; lane < 64; ++lane) {
         const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
         if (row < n && gc < cols_left)
-          std::memcpy(F + x0 + (int64_t)row * stride + gc, &tile[(size_t)io_lds_word<CW, 1>(i, lane)], 4);
+          std::memcpy(F + x0 + (int64_t)row * rstride + gc, &tile[(size_t)io_lds_word<CW, 1>(i, lane)], 4);
       }
   }
 }

@@ -450,6 +450,25 @@ struct Prefault {
   ~Prefault() { join(); }
 };
 
+// Devices of the one-process multi-GPU route (edt_multi.hip); empty = single device.
+static std::mutex g_devices_mutex;
+static std::vector<int> g_devices = [] {
+  std::vector<int> v;
+  if (const char *e = std::getenv("EDT_HIP_DEVICES")) {
+    const char *p = e;
+    while (*p) {
+      char *end = nullptr;
+      const long d = std::strtol(p, &end, 10);
+      if (end == p) break;
+      v.push_back((int)d);
+      p = (*end == ',') ? end + 1 : end;
+    }
+  }
+  return v;
+}();
+
+constexpr int EDT_FLAG_SINGLE_DEVICE = 0x4000;  // internal: do not take the multi-GPU route
+
 static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz,
                     float wx, float wy, float wz, int flags, float *output) {
   int rc = check_shape(dtype, ndim, sx, sy, sz);
@@ -460,6 +479,18 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
   rc = require_device();
   if (rc != EDT_OK) return rc;
   if (env_force_generic()) flags |= EDT_FLAG_FORCE_GENERIC;
+  if (ndim == 3 && !(flags & (EDT_FLAG_FORCE_GENERIC | EDT_FLAG_BATCH_2D | EDT_FLAG_SINGLE_DEVICE))) {
+    std::vector<int> devs;
+    {
+      std::lock_guard<std::mutex> lock(g_devices_mutex);
+      devs = g_devices;
+    }
+    if (devs.size() >= 2 && multi_supported(dtype, sx, sy, sz, (int)devs.size())) {
+      Prefault touch(output, (size_t)voxels * sizeof(float));
+      touch.join();
+      return run_multi(labels, dtype, sx, sy, sz, wx, wy, wz, flags, output, devs.data(), (int)devs.size());
+    }
+  }
 
   const size_t lbytes = (size_t)voxels * dtype_size(dtype);
   const size_t obytes = (size_t)voxels * sizeof(float);
@@ -666,6 +697,41 @@ int edt_hip_edt2dsq_batch(const void *labels, int dtype, int64_t sx, int64_t sy,
   return run_host(labels, dtype, 3, sx, sy, count, wx, wy, 1.0f,
                   (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (take_sqrt ? EDT_FLAG_SQRT : 0) | EDT_FLAG_BATCH_2D,
                   output);
+}
+
+int edt_hip_set_devices(const int *devices, int n_devices) {
+  if (n_devices < 0 || (n_devices > 0 && !devices)) { set_error("bad device list"); return EDT_ERR_BAD_ARG; }
+  const int have = edt_hip_device_count();
+  for (int i = 0; i < n_devices; ++i)
+    if (devices[i] < 0 || devices[i] >= have) { set_error("device ordinal out of range"); return EDT_ERR_BAD_ARG; }
+  std::lock_guard<std::mutex> lock(g_devices_mutex);
+  g_devices.assign(devices, devices + n_devices);
+  return EDT_OK;
+}
+
+int edt_hip_edt3dsq_multi(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
+                          float wz, int black_border, int take_sqrt, float *output, const int *devices,
+                          int n_devices) {
+  int rc = check_shape(dtype, 3, sx, sy, sz);
+  if (rc != EDT_OK) return rc;
+  if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
+  if (!labels || !output || !devices || n_devices < 1) { set_error("null pointer / empty device list"); return EDT_ERR_BAD_ARG; }
+  if ((rc = require_device()) != EDT_OK) return rc;
+  const int have = edt_hip_device_count();
+  for (int i = 0; i < n_devices; ++i)
+    if (devices[i] < 0 || devices[i] >= have) { set_error("device ordinal out of range"); return EDT_ERR_BAD_ARG; }
+  const int flags = (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (take_sqrt ? EDT_FLAG_SQRT : 0);
+  if (!multi_supported(dtype, sx, sy, sz, n_devices)) {  // one device does it
+    int prev = 0;
+    EDT_HIP_TRY(hipGetDevice(&prev));
+    EDT_HIP_TRY(hipSetDevice(devices[0]));
+    rc = run_host(labels, dtype, 3, sx, sy, sz, wx, wy, wz, flags | EDT_FLAG_SINGLE_DEVICE, output);
+    (void)hipSetDevice(prev);
+    return rc;
+  }
+  Prefault touch(output, (size_t)(sx * sy * sz) * sizeof(float));
+  touch.join();
+  return run_multi(labels, dtype, sx, sy, sz, wx, wy, wz, flags, output, devices, n_devices);
 }
 
 int edt_hip_sdf(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,

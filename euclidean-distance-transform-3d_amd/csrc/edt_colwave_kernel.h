@@ -133,8 +133,10 @@ __device__ __attribute__((noinline)) void brute_tile(float *tile, const uint32_t
   BL.w2f = w * w;
   BL.live = col < cols_left && band < NB;
   const bool colok = col < cols_left;
+  // (a pointer that crosses a call is generic: say that it is global memory, or the rows leave through flat stores)
+  auto *gdst = (__attribute__((address_space(1))) float *)dst0;
   auto store = [&](int row, float v) {
-    if (row < n && colok) dst0[(int64_t)row * dstride] = v;
+    if (row < n && colok) gdst[(int64_t)row * dstride] = v;
   };
   brute_band<CW, BB, X32, S>(BL, epi, store);
 }

@@ -130,3 +130,10 @@ size_t row_records_bytes(int64_t sx, int64_t sy, int64_t sz);
 int launch_row_records(int dtype, const void *labels, void *meta, float *ttab, uint32_t *nz_y, uint32_t *ys_y,
                     uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb, hipStream_t stream);
 }  // namespace edt_amd
+
+namespace edt_amd {
+// ---- one process, several GPUs (host buffers): edt_multi.hip ----------------------------------------
+bool multi_supported(int dtype, int64_t sx, int64_t sy, int64_t sz, int n_devices);
+int run_multi(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
+              int flags, float *output, const int *devices, int n_devices);
+}  // namespace edt_amd

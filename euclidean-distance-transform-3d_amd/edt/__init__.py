@@ -30,7 +30,7 @@ from ._lib import EdtHipError  # noqa: F401  (re-export)
 __all__ = [
     "edt", "edtsq", "sdf", "sdfsq",
     "edt1d", "edt1dsq", "edt2d", "edt2dsq", "edt3d", "edt3dsq",
-    "each", "edt_stack", "edtsq_stack", "EdtHipError",
+    "each", "edt_stack", "edtsq_stack", "set_devices", "EdtHipError",
 ]
 
 _DTYPE_CODE = {
@@ -135,6 +135,16 @@ def edt3d(data, anisotropy=(1.0, 1.0, 1.0), black_border=False, parallel=1, voxe
 
 def edt3dsq(data, anisotropy=(1.0, 1.0, 1.0), black_border=False, parallel=1, voxel_graph=None):
     return _run(np.asarray(data), anisotropy, black_border, voxel_graph, False, ndim=3)
+
+
+def set_devices(devices=None):
+    """Z-shard every 3-D transform of host arrays over these GPUs of THIS process (``edt_hip_set_devices``: a host
+    thread per device, one peer-to-peer exchange over xGMI, see ``csrc/edt_multi.hip``); ``None`` / ``[]`` = back to
+    the current device alone.  ``EDT_HIP_DEVICES=0,1,...`` in the environment presets the list.  Results are
+    bit-identical either way."""
+    devs = [] if devices is None else [int(d) for d in devices]
+    arr = (ctypes.c_int * max(1, len(devs)))(*devs)
+    _lib.check(_lib.load().edt_hip_set_devices(ctypes.cast(arr, ctypes.c_void_p), len(devs)))
 
 
 def _stack(images, anisotropy, black_border, take_sqrt):

@@ -102,6 +102,20 @@ int edt_hip_edt3dsq_voxel_graph(const void *labels, int dtype, const uint8_t *gr
                                 int64_t sy, int64_t sz, float wx, float wy, float wz,
                                 int black_border, float *workspace);
 
+/* ---- one process, several GPUs ---------------------------------------------------------------------
+ * pyedt::_edt3dsq / _edt3d on host buffers, Z-sharded over the listed devices of this process (a host thread per
+ * device; X and Y passes per Z-slab, ONE exchange of slab records as peer-to-peer copies over xGMI, Z pass per
+ * Y-slab, each device copies its rows of the result straight into `output`).  Same result, bit for bit, as the
+ * single-device entry points.  The same ordinal may be listed more than once (virtual devices: tests on one GPU).
+ * Volumes the slab-record form does not cover run on devices[0] alone.
+ * edt_hip_set_devices makes the ordinary host-buffer 3-D entry points (edt_hip_edt3dsq / edt_hip_edt3d, and with
+ * them edt::edt<T>() and the Python / Cython front ends) take this route; n_devices = 0 restores the single-device
+ * behaviour.  The environment variable EDT_HIP_DEVICES="0,1,2,..." presets the list. */
+int edt_hip_edt3dsq_multi(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
+                          float wz, int black_border, int take_sqrt, float *output, const int *devices,
+                          int n_devices);
+int edt_hip_set_devices(const int *devices, int n_devices);
+
 /* sdf / sdfsq of the reference's Python layer (src/edt.pyx:121-158, :161-202): edt(labels) - edt(labels == 0)
  * (squared != 0: edtsq(labels) - edtsq(labels == 0)) on host buffers in one round trip -- labels up once, both
  * transforms and the subtraction on the device, the difference down once.  ndim in {1,2,3}, unused extents 1. */

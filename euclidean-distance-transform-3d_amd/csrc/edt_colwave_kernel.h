@@ -109,7 +109,7 @@ __device__ __forceinline__ void scan_breaks(uint32_t brk, int row0, int n, int l
 // The windowed path of one lane (edt_colwave_lane.h: brute_band) as a function of its own -- NOT inlined, so
 // that its register allocation is separate from the hull path's (inlined into one body the two paths, each
 // close to the 128-register budget of four waves per SIMD, push each other into scratch).
-template <int CW, bool BB, bool X32, int S>
+template <int CW, bool BB, bool X32>
 __device__ __attribute__((noinline)) void brute_tile(float *tile, const uint32_t *alive, const uint32_t *rsp,
                                                      const uint32_t *lohi, const uint32_t *bscan, int n, int NB,
                                                      int cols_left, int band, int col, float w, int epi,
@@ -138,7 +138,98 @@ __device__ __attribute__((noinline)) void brute_tile(float *tile, const uint32_t
   auto store = [&](int row, float v) {
     if (row < n && colok) gdst[(int64_t)row * dstride] = v;
   };
-  brute_band<CW, BB, X32, S>(BL, epi, store);
+  // (bit 8 of epi: only the even rows are evaluated and written -- the doubled grids of the voxel-graph transform;
+  // carried in an existing argument: the kernel around this call is sensitive to its signature, see hull path)
+  if (epi & 0x100) brute_band<CW, BB, X32, 2>(BL, epi & 3, store);
+  else brute_band<CW, BB, X32, 1>(BL, epi & 3, store);
+}
+
+// The hull path of one lane (phases 1-3 of edt_colwave_lane.h).  It needs 127 of the 128 vector registers four
+// waves per SIMD leave it and is INLINED into the kernel: as a callee it would save and restore 48 callee-saved
+// registers per tile (measured: cfg2 0.69 -> 1.04 ms).  The price is fragility -- a change anywhere in the kernel
+// body (another call, another argument) can tip its hot loops into scratch with byte-identical hull code (same
+// regression, measured); tools/check_spills.py counts the scratch instructions of the built kernels, run it after
+// touching this file.  It re-reads the lane's 32 rows from the LDS tile (the kernel's copy served the tile choice)
+// and leaves the results in the tile for the workgroup's write-back.
+template <int CW, bool BB>
+static __device__ __forceinline__ void hull_tile(float *tile, uint32_t *alive, const uint32_t *rsp, int colc, int band,
+                                                    int n, float w, uint32_t nzw, uint32_t rsw, int lo_in, int hi_out,
+                                                    uint32_t fl0, uint32_t need, int epi, int dbg, int lane) {
+  using namespace edt_lane;
+  constexpr int NBP = 64 / CW;
+  constexpr int TC = TileGeom<CW>::kCols;
+  Lane L;
+  L.tile = tile;
+  L.alive = alive;
+  L.rsp = rsp;
+  L.colc = colc;
+  L.band = band;
+  L.row0 = band * 32;
+  L.n = n;
+  L.w2 = (double)(w * w);
+  L.nzw = nzw;
+  L.rsw = rsw;
+  L.lo_in = lo_in;
+  L.hi_out = hi_out;
+  L.own = 0;
+  float f[32];
+  {
+    const float *own = tile + addr_tile<CW>(colc, L.row0);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) f[r] = own[r * TC];
+  }
+  const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
+  // (dbg: diagnostics only -- bit1 skips the hull build, bit2 the merges, bit3 the evaluation)
+  // All-flat shortcut (edt_colwave_lane.h: flat_word): a wave whose columns are flat wherever a run
+  // continues needs no hull at all -- every foreground row owns itself.  (debug bit 16 switches it off.)
+  bool all_flat = false;
+  if (!(dbg & (2 | 16 | 0x10000))) all_flat = __ballot((fl0 & need) != need) == 0ull;
+  uint32_t aw = L.nzw;
+  if (all_flat) {
+    L.own = L.nzw;
+  } else {
+    Hull1 H;
+    if (dbg & 2) { H.aw = L.nzw; H.flat = 0; H.nb0 = H.nb1 = H.nb31 = 0.0; }
+    else H = phase1_hull<CW>(L, f, fprev, fl0);
+    aw = H.aw;
+    const uint32_t flat = H.flat;
+    alive[addr_word<CW>(L.colc, L.band)] = aw;
+    wave_sync();
+    if (!(dbg & 4)) {
+      // the merge rounds change nothing for a wave whose band boundaries are all quiet
+      uint32_t prev_aw = __shfl_up(aw, CW), prev_rs = __shfl_up(L.rsw, CW);
+      const double prev_nb31 = __shfl_up(H.nb31, CW);
+      if (lane < CW) { prev_aw = 0; prev_rs = 0; }
+      const bool quiet = boundary_quiet(L, H, prev_aw, prev_rs, prev_nb31);
+      if (__ballot(!quiet) != 0ull || (dbg & 32)) {
+#pragma unroll
+        for (int half = 1; half < NBP; half <<= 1) {
+          phase2_merge<CW>(L, half);
+          wave_sync();
+        }
+      }
+    }
+    aw = alive[addr_word<CW>(L.colc, L.band)];
+    {
+      // self-owned rows need bit 31 of the band below and bit 0 of the band above
+      uint32_t prev31 = __shfl_up(aw >> 31, CW);
+      uint32_t next0 = __shfl_down((L.nzw & 1u) | ((L.rsw & 1u) << 1) | ((aw & 1u) << 2) | ((flat & 1u) << 3), CW);
+      if (lane < CW) prev31 = 0;
+      if (lane >= 64 - CW) next0 = 0;
+      L.own = own_mask(L.nzw, L.rsw, aw, flat, prev31, next0 & 1u, (next0 >> 1) & 1u, (next0 >> 2) & 1u,
+                       (next0 >> 3) & 1u);
+      if (dbg & 16) L.own = 0;  // diagnostics: no self-owned shortcut
+    }
+  }  // !all_flat
+  if (!(dbg & 8)) phase3_eval<CW, BB>(L, aw, f, epi);
+  wave_sync();  // every lane of the wave is done reading the tile
+
+  // ---- results -> LDS (in place); the workgroup streams the tile back after its barrier ----
+  float *own = tile + addr_tile<CW>(L.colc, L.row0);
+  if (!(dbg & 0x200)) {  // (diagnostics: bit 9 leaves the tile as it was loaded)
+#pragma unroll
+    for (int r = 0; r < 32; ++r) own[r * TC] = f[r];
+  }
 }
 
 template <int CW, bool BB, bool XF, bool SC>
@@ -320,73 +411,16 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         } else {
           dst0 = Ftile + col2;
         }
-        // (stride 2: only the even rows are evaluated and written -- the doubled grids of the voxel-graph transform)
-        if (ba.stride == 2) {
-          if (ba.x32) brute_tile<CW, BB, true, 2>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
-          else brute_tile<CW, BB, false, 2>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
-        } else {
-          if (ba.x32) brute_tile<CW, BB, true, 1>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
-          else brute_tile<CW, BB, false, 1>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, st);
-        }
+        const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0);
+        if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, st);
+        else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, st);
         return;
       }
     }
   }
 
-  // ---- phase 1 / 2 / 3 (wave-local) ----------------------------------------------------------
-  // (dbg: diagnostics only -- bit1 skips the hull build, bit2 the merges, bit3 the evaluation)
-  // All-flat shortcut (edt_colwave_lane.h: flat_word): a wave whose columns are flat wherever a run
-  // continues needs no hull at all -- every foreground row owns itself.  (debug bit 16 switches it off.)
-  bool all_flat = false;
-  if (!(dbg & (2 | 16 | 0x10000))) all_flat = __ballot((fl0 & need) != need) == 0ull;
-  uint32_t aw = L.nzw;
-  if (all_flat) {
-    L.own = L.nzw;
-  } else {
-  Hull1 H;
-  if (dbg & 2) { H.aw = L.nzw; H.flat = 0; H.nb0 = H.nb1 = H.nb31 = 0.0; }
-  else H = phase1_hull<CW>(L, f, fprev, fl0);
-  aw = H.aw;
-  const uint32_t flat = H.flat;
-  alive[addr_word<CW>(L.colc, L.band)] = aw;
-  wave_sync();
-  if (!(dbg & 4)) {
-    // the merge rounds change nothing for a wave whose band boundaries are all quiet
-    uint32_t prev_aw = __shfl_up(aw, CW), prev_rs = __shfl_up(L.rsw, CW);
-    const double prev_nb31 = __shfl_up(H.nb31, CW);
-    if (lane < CW) { prev_aw = 0; prev_rs = 0; }
-    const bool quiet = boundary_quiet(L, H, prev_aw, prev_rs, prev_nb31);
-    if (__ballot(!quiet) != 0ull || (dbg & 32)) {
-#pragma unroll
-      for (int half = 1; half < NBP; half <<= 1) {
-        phase2_merge<CW>(L, half);
-        wave_sync();
-      }
-    }
-  }
-  aw = alive[addr_word<CW>(L.colc, L.band)];
-  {
-    // self-owned rows need bit 31 of the band below and bit 0 of the band above
-    uint32_t prev31 = __shfl_up(aw >> 31, CW);
-    uint32_t next0 = __shfl_down((L.nzw & 1u) | ((L.rsw & 1u) << 1) | ((aw & 1u) << 2) | ((flat & 1u) << 3), CW);
-    if (lane < CW) prev31 = 0;
-    if (lane >= 64 - CW) next0 = 0;
-    L.own = own_mask(L.nzw, L.rsw, aw, flat, prev31, next0 & 1u, (next0 >> 1) & 1u, (next0 >> 2) & 1u,
-                     (next0 >> 3) & 1u);
-    if (dbg & 16) L.own = 0;  // diagnostics: no self-owned shortcut
-  }
-  }  // !all_flat
-  if (!(dbg & 8)) phase3_eval<CW, BB>(L, aw, f, epi);
-  wave_sync();  // every lane of the wave is done reading the tile
-
-  // ---- results -> LDS (in place) -> HBM ------------------------------------------------------
-  {
-    float *own = tile + addr_tile<CW>(L.colc, L.row0);
-    if (!(dbg & 0x200)) {  // (diagnostics: bit 9 leaves the tile as it was loaded)
-#pragma unroll
-      for (int r = 0; r < 32; ++r) own[r * TC] = f[r];
-    }
-  }
+  // ---- phase 1 / 2 / 3 (wave-local): hull_tile, a function of its own (see there) ---------------------
+  hull_tile<CW, BB>(tile, alive, rsp, L.colc, L.band, n, w, L.nzw, L.rsw, L.lo_in, L.hi_out, fl0, need, epi, dbg, lane);
   __syncthreads();
   typedef float v4f __attribute__((ext_vector_type(4)));
   if constexpr (SC) {

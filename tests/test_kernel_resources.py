@@ -1,0 +1,36 @@
+"""CPU tier (needs hipcc only): the column-pass kernels are built WITHOUT scratch traffic in their bodies and at
+four waves per SIMD.
+
+The hull path sits at the edge of the 128-VGPR budget; a change anywhere in the kernel body once tipped its hot
+loops into scratch with byte-identical hull code (cfg2 0.69 -> 1.05 ms).  tools/check_spills.py counts the
+scratch_load / scratch_store instructions of the compiled kernels; this test pins the two shapes the BASELINE
+volumes use (512-row axes: 4-column waves; 1024-row axes: 2-column waves)."""
+import os
+import shutil
+import sys
+import tempfile
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.parametrize("cw", [4, 2])
+def test_column_kernels_have_no_scratch_in_their_bodies(cw):
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    import check_spills
+    with tempfile.TemporaryDirectory() as d:
+        funcs = check_spills.scan(cw, d)
+    kernels = [f for f in funcs if f["kernel"]]
+    assert len(kernels) == 6
+    for f in kernels:
+        assert f["scratch_ops"] <= 8, f
+        assert f["occupancy"] is None or f["occupancy"] >= 4, f
+        assert f["vgprs"] is None or f["vgprs"] <= 128, f
+    # the non-inlined windowed-path functions: callee-saved registers saved once per call, nothing more
+    for f in funcs:
+        if not f["kernel"]:
+            assert f["scratch_ops"] <= 64, f

@@ -106,11 +106,19 @@ __device__ __forceinline__ void scan_breaks(uint32_t brk, int row0, int n, int l
 
 }  // namespace
 
-// The windowed path of one lane (edt_colwave_lane.h: brute_band) as a function of its own -- NOT inlined, so
-// that its register allocation is separate from the hull path's (inlined into one body the two paths, each
-// close to the 128-register budget of four waves per SIMD, push each other into scratch).
+// The windowed path of one lane (edt_colwave_lane.h: brute_band).  History of where it lives, because it matters:
+// inlined next to a hull path that kept its 32 rows in registers from the tile choice on, the two pushed each other
+// into scratch (the hull path alone needed 127 of 128 VGPRs); as a non-inlined function it had its own allocation,
+// but every call saved and restored 16-19 callee-saved registers through scratch -- 0.43 GB of extra fabric traffic
+// per 512^3 launch (PMC).  Since the hull path re-reads its rows from the LDS tile (hull_tile below), every kernel
+// builds with 114-121 VGPRs and NO scratch with both paths inlined; that is the default.  EDT_BRUTE_INLINE can
+// be set to __attribute__((noinline)) to get the call back; tools/check_spills.py / tests/test_kernel_resources.py
+// watch the scratch instructions of the built kernels.
+#ifndef EDT_BRUTE_INLINE
+#define EDT_BRUTE_INLINE __forceinline__
+#endif
 template <int CW, bool BB, bool X32>
-__device__ __attribute__((noinline)) void brute_tile(float *tile, const uint32_t *alive, const uint32_t *rsp,
+__device__ EDT_BRUTE_INLINE void brute_tile(float *tile, const uint32_t *alive, const uint32_t *rsp,
                                                      const uint32_t *lohi, const uint32_t *bscan, int n, int NB,
                                                      int cols_left, int band, int col, float w, int epi,
                                                      float *dst0, int64_t dstride) {
@@ -144,13 +152,13 @@ __device__ __attribute__((noinline)) void brute_tile(float *tile, const uint32_t
   else brute_band<CW, BB, X32, 1>(BL, epi & 3, store);
 }
 
-// The hull path of one lane (phases 1-3 of edt_colwave_lane.h).  It needs 127 of the 128 vector registers four
-// waves per SIMD leave it and is INLINED into the kernel: as a callee it would save and restore 48 callee-saved
-// registers per tile (measured: cfg2 0.69 -> 1.04 ms).  The price is fragility -- a change anywhere in the kernel
-// body (another call, another argument) can tip its hot loops into scratch with byte-identical hull code (same
-// regression, measured); tools/check_spills.py counts the scratch instructions of the built kernels, run it after
-// touching this file.  It re-reads the lane's 32 rows from the LDS tile (the kernel's copy served the tile choice)
-// and leaves the results in the tile for the workgroup's write-back.
+// The hull path of one lane (phases 1-3 of edt_colwave_lane.h), inlined into the kernel (as a callee it would save
+// and restore 48 callee-saved registers per tile: cfg2 0.69 -> 1.04 ms, measured).  It RE-READS the lane's 32 rows
+// from the LDS tile instead of inheriting the registers the tile choice loaded them into: 32 LDS reads per lane
+// that keep those 32 live ranges out of everything in between -- with the rows held from the top of the kernel the
+// hull code sat at 127 VGPRs and any change anywhere in the kernel body (another call, another argument) tipped its
+// hot loops into scratch with byte-identical hull code (cfg2 0.69 -> 1.05 ms, measured twice).  It leaves the
+// results in the tile for the workgroup's write-back.
 template <int CW, bool BB>
 static __device__ __forceinline__ void hull_tile(float *tile, uint32_t *alive, const uint32_t *rsp, int colc, int band,
                                                     int n, float w, uint32_t nzw, uint32_t rsw, int lo_in, int hi_out,
@@ -274,12 +282,16 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   // tiles it also puts the two halves of every 128-byte line back to back on one XCD (the second
   // half is an L2 hit).  The grid is rounded up to whole groups of 8 outer indices; debug bit 11
   // restores the plain order.
+  // (tile ids fit 31 bits -- the launcher checks: 32-bit divisions, not 64-bit ones, ahead of every wave's first load)
+  const uint32_t utx = (uint32_t)tiles_x;
   if (!(dbg & 0x800)) {
-    const int64_t x = tile_id & 7, j = tile_id >> 3;
-    tile_id = ((j / tiles_x) * 8 + x) * tiles_x + (j % tiles_x);
+    const uint32_t t = (uint32_t)tile_id, x = t & 7u, j = t >> 3;
+    const uint32_t jq = j / utx, jr = j - jq * utx;
+    tile_id = (int64_t)((jq * 8u + x) * utx + jr);
     if (tile_id >= (int64_t)tiles_x * g.nouter) return;
   }
-  const int64_t xt = tile_id % tiles_x, o = tile_id / tiles_x;
+  const uint32_t oq = (uint32_t)tile_id / utx;
+  const int64_t xt = (uint32_t)tile_id - oq * utx, o = oq;
   const int64_t x0 = xt * TC;
   const int64_t st = g.stride;
   float *Ftile = F + x0 + o * g.outer_stride;

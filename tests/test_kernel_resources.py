@@ -30,7 +30,5 @@ def test_column_kernels_have_no_scratch_in_their_bodies(cw):
         assert f["scratch_ops"] <= 8, f
         assert f["occupancy"] is None or f["occupancy"] >= 4, f
         assert f["vgprs"] is None or f["vgprs"] <= 128, f
-    # the non-inlined windowed-path functions: callee-saved registers saved once per call, nothing more
-    for f in funcs:
-        if not f["kernel"]:
-            assert f["scratch_ops"] <= 64, f
+    # (no non-inlined device functions in the default build: a call would push callee-saved registers through scratch)
+    assert all(f["kernel"] for f in funcs), [f["name"] for f in funcs if not f["kernel"]]

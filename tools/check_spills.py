@@ -4,8 +4,8 @@
 The hull path of k_column_pass_wave needs 127 of the 128 VGPRs that four waves per SIMD leave it; a change anywhere
 in the kernel body can tip its hot loops into scratch with byte-identical hull code (measured: cfg2 0.69 -> 1.05 ms).
 Run this after touching csrc/edt_colwave_kernel.h / edt_colwave_lane.h:  python tools/check_spills.py [cw ...]
-Kernel bodies must show 0 (a handful at most); the non-inlined windowed-path function shows ~30-40 (callee-saved
-registers saved once per call, not spills in loops)."""
+Kernel bodies must show 0 (a handful at most).  (With -DEDT_BRUTE_INLINE='__attribute__((noinline))' the windowed
+path is a function of its own and shows ~30-40: callee-saved registers saved once per call, not spills in loops.)"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

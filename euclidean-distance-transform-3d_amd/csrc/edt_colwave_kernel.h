@@ -148,8 +148,8 @@ __device__ EDT_BRUTE_INLINE void brute_tile(float *tile, const uint32_t *alive, 
   };
   // (bit 8 of epi: only the even rows are evaluated and written -- the doubled grids of the voxel-graph transform;
   // carried in an existing argument: the kernel around this call is sensitive to its signature, see hull path)
-  if (epi & 0x100) brute_band<CW, BB, X32, 2>(BL, epi & 3, store);
-  else brute_band<CW, BB, X32, 1>(BL, epi & 3, store);
+  if (epi & 0x100) brute_band<CW, BB, X32, 2>(BL, epi & 0x203, store);
+  else brute_band<CW, BB, X32, 1>(BL, epi & 0x203, store);
 }
 
 // The hull path of one lane (phases 1-3 of edt_colwave_lane.h), inlined into the kernel (as a callee it would save
@@ -423,7 +423,8 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         } else {
           dst0 = Ftile + col2;
         }
-        const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0);
+        // (bit 9, diagnostics: debug bit 0x80000 = no window at all, i.e. the fixed cost of the path; wrong results)
+        const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | ((dbg & 0x80000) ? 0x200 : 0);
         if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, st);
         else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, st);
         return;

@@ -999,6 +999,7 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
       const int D = brute_flat_reach(L, k0, NR);
       const double cD = L.w2 * (double)((D + 1) * (D + 1));
       if (!EDT_ANY(cD < bmax64)) open = false;
+      if (epi & 0x200) open = false;  // diagnostics: the fixed cost of the path (results are wrong)
     }
     // ---- the window: register-resident part (two steps per exit test), then straight from the tile ----
     if (open) {

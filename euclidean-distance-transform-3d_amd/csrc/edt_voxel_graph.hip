@@ -151,8 +151,23 @@ __global__ void k_vg_ttab(float *__restrict__ ttab, float w, int count) {
 }
 
 // Pass X of the doubled grid, even cells only: one wave per VOXEL row (y, z) produces its doubled rows
-// (Y, Z) = (2y + yp, 2z + zp) -- four in 3-D, two in 2-D -- from ONE read of the row's label and graph bytes;
-// the four independent computations also give the scalar / shuffle chains something to overlap with.
+// (Y, Z) = (2y + yp, 2z + zp) -- four in 3-D, two in 2-D -- from ONE read of the row's label and graph bytes.
+//
+// The four doubled rows differ only in WHICH half-cells the graph turns into background, so the row is described
+// by four voxel masks (bit = "this voxel contributes a background cell"):
+//   F: the voxel is background (both its cells, in every doubled row)
+//   X: F or its +x link is cut  -> the ODD  cell 2x+1 of row (yp, zp) = (0, 0)
+//   Y: F or its +y link is cut  -> the EVEN cell 2x   of row (1, 0)
+//   Z: F or its +z link is cut  -> the EVEN cell 2x   of row (0, 1)
+// and per row: (0,0): even cells F, odd cells X;  (1,0): even Y, odd F;  (0,1): even Z, odd F;  (1,1): even F, odd F.
+// Seen from the even cell 2x an even-type cell of voxel v is 2|x - v| away, an odd-type one 2(x - v) - 1 to the left
+// (v < x) and 2(v - x) + 1 to the right (v >= x: the voxel's own odd cell lies to its right).  So a lane needs, per
+// mask, the nearest member below and above its voxel: two bit scans of the chunk's ballot mask, with the carry
+// from the other chunks kept on the scalar unit -- the forward sweep (phase A) leaves the last member before each
+// chunk in lane c, the backward sweep (phase B) carries the first member after it along.  Real voxel graphs cut few
+// links: a doubled row whose mask equals F in EVERY chunk (wave-uniform test) is the (1,1) row and is not computed
+// again.  black_border: the border site left of the row is cell -1, the trimmed odd cell 2sx-1 is the nearest
+// background on the right of every row (src/edt_voxel_graph.hpp:156-187), rows 2sy-1 / slices 2sz-1 are background.
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const float *__restrict__ ttab,
@@ -162,24 +177,33 @@ k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   const int NC = (sx + 63) >> 6;  // <= 32 (launcher)
-  const int NQ = Z2 > 1 ? 4 : 2;  // doubled rows per voxel row
-  const int64_t nvrows = (int64_t)sy * (Z2 > 1 ? sz : 1);
+  const bool three = Z2 > 1;
+  const int64_t nvrows = (int64_t)sy * (three ? sz : 1);
   const uint64_t below = (1ull << lane) - 1ull;                         // lanes before this one
   const uint64_t above = lane < 63 ? ~((2ull << lane) - 1ull) : 0ull;   // lanes after it
+  const uint64_t above_own = ~below;                                    // this lane and the lanes after it
+  auto eval = [&](int il, int ir) -> float {
+    il = il < idx_inf ? il : idx_inf;
+    ir = ir < idx_inf ? ir : idx_inf;
+    const float tl = Tl[il], tr = Tl[ir];
+    const float d = tl < tr ? tl : tr;
+    float f = d * d;                                    // `d[i] *= d[i]` (src/edt.hpp:116-118)
+    if (!bb && f >= INFINITY) f = 3.402823466e+38f;     // tofinite (src/edt.hpp:39-45)
+    return f;
+  };
   for (int64_t vrow = (int64_t)blockIdx.x * 4 + wave; vrow < nvrows; vrow += (int64_t)gridDim.x * 4) {
     const int y = (int)(vrow % sy), z = (int)(vrow / sy);
     const T *lrow = labels + vrow * sx;
     const uint8_t *grow = graph + vrow * sx;
     // a doubled row trimmed by black_border is all background (src/edt_voxel_graph.hpp:156-187)
-    bool dead[4];
+    const bool deadY = bb && y == sy - 1, deadZ = bb && three && z == sz - 1;
+    // ---- phase A (forward): the masks of every 64-voxel chunk; last member before each chunk ----
+    uint32_t fl[4] = {0, 0, 0, 0};  // bit c: the lane's voxel of chunk c is in mask F / X / Y / Z
+    int prevv[4];                   // lane c: last member of the mask in the chunks before c
+    int run[4];                     // (wave-uniform)
+    uint32_t diff = 0;              // (wave-uniform) bit m: mask m differs from F somewhere in the row
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      dead[q] = bb && (((q & 1) && y == sy - 1) || ((q >> 1) && Z2 > 1 && z == sz - 1));
-    // ---- phase A: the cells of every 64-voxel chunk; last / first background cell per chunk and row ----
-    uint32_t flagsE[4] = {0, 0, 0, 0}, flagsO[4] = {0, 0, 0, 0};  // bit c: the lane's even / odd cell is FOREGROUND
-    int lastz[4], firstz[4];  // lane c: last / first background cell (doubled coordinate) of chunk c
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { lastz[q] = -kVgFar; firstz[q] = kVgFar; }
+    for (int m = 0; m < 4; ++m) { prevv[m] = -kVgFar; run[m] = -kVgFar; }
     for (int c = 0; c < NC; ++c) {
       const int x = c * 64 + lane;
       const bool valid = x < sx;
@@ -189,143 +213,188 @@ k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const
         fg = vg_fg(lrow[x]);
         g = grow[x];
       }
+      bool in[4];
+      in[0] = valid && !fg;
+      in[1] = valid && !(fg && (g & 0x01u));
+      in[2] = valid && !(fg && (g & 0x04u));
+      in[3] = valid && three && !(fg && (g & 0x10u));
+      uint64_t M[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q >= NQ) break;
-        const bool E = !dead[q] && vg_even_cell(fg, g, q & 1, q >> 1);
-        bool O = !dead[q] && vg_odd_cell(fg, g, q & 1, q >> 1);
-        if (bb && x == sx - 1) O = false;
-        flagsE[q] |= (E ? 1u : 0u) << c;
-        flagsO[q] |= (O ? 1u : 0u) << c;
-        const uint64_t zE = __ballot(valid && !E), zO = __ballot(valid && !O);
-        int lz = -kVgFar, fz = kVgFar;
-        if (zE) {
-          lz = 2 * (c * 64 + 63 - __builtin_clzll(zE));
-          fz = 2 * (c * 64 + __builtin_ctzll(zE));
-        }
-        if (zO) {
-          const int l2 = 2 * (c * 64 + 63 - __builtin_clzll(zO)) + 1, f2 = 2 * (c * 64 + __builtin_ctzll(zO)) + 1;
-          lz = l2 > lz ? l2 : lz;
-          fz = f2 < fz ? f2 : fz;
-        }
-        if (lane == c) { lastz[q] = lz; firstz[q] = fz; }
+      for (int m = 0; m < 4; ++m) {
+        M[m] = __ballot(in[m]);
+        fl[m] |= (in[m] ? 1u : 0u) << c;
+        if (lane == c) prevv[m] = run[m];
+        if (M[m]) run[m] = c * 64 + 63 - __builtin_clzll(M[m]);
       }
+      diff |= (M[1] != M[0] ? 1u : 0u) | (M[2] != M[0] ? 2u : 0u) | (M[3] != M[0] ? 4u : 0u);
     }
-    // exclusive prefix max of lastz / exclusive suffix min of firstz over the chunks (lanes), seeded with the
-    // border sites just outside the row (black_border) or "none"
-    int prev[4], next[4];
+    // ---- phase B (backward): nearest members on either side, table look-up, square ----
+    int nxt[4];  // (wave-uniform) first member of the mask in the chunks after the current one
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      prev[q] = __shfl_up(lastz[q], 1);
-      next[q] = __shfl_down(firstz[q], 1);
-      if (lane == 0) prev[q] = bb ? -1 : -kVgFar;
-      if (lane >= NC - 1) next[q] = bb ? 2 * sx : kVgFar;
-    }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int tp = __shfl_up(prev[q], d), tn = __shfl_down(next[q], d);
-        if (lane >= d) prev[q] = tp > prev[q] ? tp : prev[q];
-        if (lane + d < 64) next[q] = tn < next[q] ? tn : next[q];
-      }
-    }
-    // ---- phase B: distances to the nearest background cell on either side, table look-up, square ----
-    for (int c = 0; c < NC; ++c) {
+    for (int m = 0; m < 4; ++m) nxt[m] = kVgFar;
+    for (int c = NC - 1; c >= 0; --c) {
       const int x = c * 64 + lane;
       const bool valid = x < sx;
+      uint64_t M[4];
+      int L[4], R[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q >= NQ) break;
-        const bool E = (flagsE[q] >> c) & 1u, O = (flagsO[q] >> c) & 1u;
-        const uint64_t zE = __ballot(valid && !E), zO = __ballot(valid && !O);
-        int Xl = __shfl(prev[q], c), Xr = __shfl(next[q], c);
-        const uint64_t mE = zE & below, mO = zO & below;
-        if (mE) { const int p = 2 * (c * 64 + 63 - __builtin_clzll(mE)); Xl = p > Xl ? p : Xl; }
-        if (mO) { const int p = 2 * (c * 64 + 63 - __builtin_clzll(mO)) + 1; Xl = p > Xl ? p : Xl; }
-        const uint64_t nE = zE & above, nO = zO & (above | (1ull << lane));  // the own odd cell lies to the right
-        if (nE) { const int p = 2 * (c * 64 + __builtin_ctzll(nE)); Xr = p < Xr ? p : Xr; }
-        if (nO) { const int p = 2 * (c * 64 + __builtin_ctzll(nO)) + 1; Xr = p < Xr ? p : Xr; }
-        const int X = 2 * x;
-        int il = X - Xl, ir = Xr - X;
-        il = il < idx_inf ? il : idx_inf;
-        ir = ir < idx_inf ? ir : idx_inf;
-        const float tl = Tl[il], tr = Tl[ir];
-        const float d = tl < tr ? tl : tr;
-        float f = d * d;                                    // `d[i] *= d[i]` (src/edt.hpp:116-118)
-        if (!bb && f >= INFINITY) f = 3.402823466e+38f;     // tofinite (src/edt.hpp:39-45)
-        if (!E) f = 0.0f;
-        if (valid) F1[((int64_t)(2 * z + (q >> 1)) * Y2 + (2 * y + (q & 1))) * sx + x] = f;
+      for (int m = 0; m < 4; ++m) {
+        M[m] = __ballot(((fl[m] >> c) & 1u) != 0u);
+        L[m] = 0;
+        R[m] = 0;
       }
+      auto search = [&](int m, uint64_t right_lanes) {
+        const int p = __builtin_amdgcn_readlane(prevv[m], c);
+        const uint64_t lo = M[m] & below, hi = M[m] & right_lanes;
+        L[m] = lo ? c * 64 + 63 - __builtin_clzll(lo) : p;
+        R[m] = hi ? c * 64 + __builtin_ctzll(hi) : nxt[m];
+      };
+      search(0, above);  // (the voxel itself being background makes every one of its even cells 0: never "own")
+      const int bl = bb ? 2 * x + 1 : kVgFar, br = bb ? 2 * sx - 1 - 2 * x : kVgFar;
+      auto mn = [](int a, int b) { return a < b ? a : b; };
+      // row (1,1): even F, odd F -- the nearest cells are the odd one on the left, the even one on the right
+      const float f3 = eval(mn(bl, 2 * (x - L[0]) - 1), mn(br, 2 * (R[0] - x)));
+      const bool ownF = (fl[0] >> c) & 1u;
+      float f0 = f3, f1 = f3, f2 = f3;
+      bool own1 = ownF, own2 = ownF;
+      if (diff & 1u) {  // row (0,0): even F, odd X (own odd cell included)
+        search(1, above_own);
+        f0 = eval(mn(bl, 2 * (x - L[1]) - 1), mn(br, mn(2 * (R[0] - x), 2 * (R[1] - x) + 1)));
+      }
+      if (diff & 2u) {  // row (1,0): even Y, odd F
+        search(2, above);
+        f1 = eval(mn(bl, mn(2 * (x - L[2]), 2 * (x - L[0]) - 1)), mn(br, 2 * (R[2] - x)));
+        own1 = (fl[2] >> c) & 1u;
+      }
+      if (three && (diff & 4u)) {  // row (0,1): even Z, odd F
+        search(3, above);
+        f2 = eval(mn(bl, mn(2 * (x - L[3]), 2 * (x - L[0]) - 1)), mn(br, 2 * (R[3] - x)));
+        own2 = (fl[3] >> c) & 1u;
+      }
+      if (valid) {
+        const int64_t r00 = ((int64_t)(2 * z) * Y2 + 2 * y) * sx + x;
+        F1[r00] = ownF ? 0.0f : f0;
+        F1[r00 + sx] = (own1 || deadY) ? 0.0f : f1;
+        if (three) {
+          const int64_t r01 = r00 + (int64_t)Y2 * sx;
+          F1[r01] = (own2 || deadZ) ? 0.0f : f2;
+          F1[r01 + sx] = (ownF || deadY || deadZ) ? 0.0f : f3;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (M[m]) nxt[m] = c * 64 + __builtin_ctzll(M[m]);
     }
   }
 }
 
-// Bit planes of the column passes for the even-X columns.  Along Y: words [Z][Y/32][x] over the doubled Y
-// axis of slice Z; along Z: words [y][Z/32][x] over the doubled Z axis of the even row 2y.  nz = the cell is
-// foreground, rs = it differs from the cell below it (row 0: always set), as edt_rowwave.hip defines them.
-template <typename T, bool ALONG_Z>
+// Bit planes of the column passes for the even-X columns.  nz = the cell is foreground, rs = it differs from the
+// cell below it (row 0: always set), as edt_rowwave.hip defines them.  A word covers 32 doubled rows = 16 voxels
+// along the axis; every voxel is loaded unconditionally (clamped), all 17 loads of a thread in flight together.
+//
+// Along Y: words [Z][Y/32][x] over the doubled Y axis of slice Z.  One thread builds the words of the two slices
+// Z = 2z, 2z+1 from one read of its voxels: slice 2z holds (fg, fg && +y) per voxel, slice 2z+1 (fg && +z, fg).
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_vg_bits(const T *__restrict__ labels, const uint8_t *__restrict__ graph, uint32_t *__restrict__ nz,
-          uint32_t *__restrict__ rs, int sx, int sy, int sz, int Y2, int Z2, int nwords, int bb) {
-  // ALONG_Z: outer = y (sy of them), axis = Z2;  else: outer = Z (Z2 of them), axis = Y2.
-  // A word covers 32 doubled rows = 16 voxels along the axis, each read once (two cells per voxel).
-  const int64_t nouter = ALONG_Z ? sy : Z2;
-  const int64_t total = (int64_t)sx * nwords * nouter;
-  const int n2 = ALONG_Z ? Z2 : Y2, nvox = ALONG_Z ? sz : sy;
-  const int64_t vstride = ALONG_Z ? (int64_t)sx * sy : sx;  // between consecutive voxels along the axis
+k_vg_bits_y(const T *__restrict__ labels, const uint8_t *__restrict__ graph, uint32_t *__restrict__ nz,
+            uint32_t *__restrict__ rs, int sx, int sy, int sz, int Y2, int three, int nwords, int bb) {
+  const int64_t total = (int64_t)sx * nwords * sz;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int x = (int)(idx % sx);
     const int wd = (int)((idx / sx) % nwords);
-    const int o = (int)(idx / ((int64_t)sx * nwords));
-    // the fixed coordinates: ALONG_Z -> the even row 2*o (yp = 0); else slice Z = o (zp = o & 1, z = o >> 1)
-    const int zfix = ALONG_Z ? 0 : (o >> 1), zp = ALONG_Z ? 0 : (o & 1);
-    if (!ALONG_Z && bb && zp && Z2 > 1 && zfix == sz - 1) {  // trimmed slice: all background
-      nz[idx] = 0u;
-      rs[idx] = wd == 0 ? 1u : 0u;
-      continue;
-    }
-    const int64_t base = ALONG_Z ? x + (int64_t)sx * o : x + (int64_t)sx * sy * zfix;
-    // the two cells of voxel v along the axis: even position 2v, odd position 2v+1
-    auto cells = [&](int v, bool &c0, bool &c1) {
-      const int64_t src = base + vstride * v;
-      const bool fg = vg_fg(labels[src]);
-      const uint32_t g = graph[src];
-      if (ALONG_Z) {  // (Y even) Z = 2v: fg; Z = 2v+1: fg && +z edge
-        c0 = fg;
-        c1 = fg && (g & 0x10u);
-        if (bb && v == sz - 1) c1 = false;
-      } else {        // Y = 2v: even cell of (yp = 0, zp); Y = 2v+1: (yp = 1, zp)
-        c0 = vg_even_cell(fg, g, 0, zp);
-        c1 = vg_even_cell(fg, g, 1, zp);
-        if (bb && v == sy - 1) c1 = false;
-      }
-    };
-    uint32_t w = 0;
+    const int z = (int)(idx / ((int64_t)sx * nwords));
+    const int64_t base = x + (int64_t)sx * sy * z;
     const int v0 = wd * 16;
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-      if (v0 + k >= nvox) break;
-      bool c0, c1;
-      cells(v0 + k, c0, c1);
-      w |= (c0 ? 1u : 0u) << (2 * k) | (c1 ? 1u : 0u) << (2 * k + 1);
+    T lab[17];
+    uint8_t gr[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {  // k = 0: the voxel before the word (its odd cell is the carry)
+      int v = v0 + k - 1;
+      v = v < 0 ? 0 : (v < sy ? v : sy - 1);
+      lab[k] = labels[base + (int64_t)sx * v];
+      gr[k] = graph[base + (int64_t)sx * v];
     }
-    uint32_t carry = 0;
-    if (wd > 0) {
-      bool c0, c1;
-      cells(v0 - 1, c0, c1);
-      carry = c1 ? 1u : 0u;
+    uint32_t w0 = 0, w1 = 0, carry0 = 0, carry1 = 0;
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+      const int v = v0 + k - 1;
+      const bool fg = vg_fg(lab[k]);
+      const uint32_t g = gr[k];
+      bool e0 = fg, o0 = fg && (g & 0x04u);  // slice 2z:   Y = 2v, 2v+1
+      bool e1 = fg && (g & 0x10u), o1 = fg;  // slice 2z+1
+      if (bb && v == sy - 1) { o0 = false; o1 = false; }
+      if (k == 0) {
+        carry0 = o0 ? 1u : 0u;
+        carry1 = o1 ? 1u : 0u;
+      } else if (v < sy) {
+        w0 |= (e0 ? 1u : 0u) << (2 * k - 2) | (o0 ? 1u : 0u) << (2 * k - 1);
+        w1 |= (e1 ? 1u : 0u) << (2 * k - 2) | (o1 ? 1u : 0u) << (2 * k - 1);
+      }
     }
-    uint32_t rsw = w ^ ((w << 1) | carry);
-    if (wd == 0) rsw |= 1u;
-    const int valid = n2 - wd * 32;  // rows of this word that exist
-    if (valid < 32) rsw &= (1u << valid) - 1u;
-    nz[idx] = w;
-    rs[idx] = rsw;
+    if (wd == 0) { carry0 = 0; carry1 = 0; }
+    uint32_t r0 = w0 ^ ((w0 << 1) | carry0), r1 = w1 ^ ((w1 << 1) | carry1);
+    if (wd == 0) { r0 |= 1u; r1 |= 1u; }
+    const int valid = Y2 - wd * 32;  // rows of this word that exist
+    if (valid < 32) { r0 &= (1u << valid) - 1u; r1 &= (1u << valid) - 1u; }
+    const int64_t o0 = x + (int64_t)sx * (wd + (int64_t)nwords * (three ? 2 * z : 0));
+    nz[o0] = w0;
+    rs[o0] = r0;
+    if (three) {
+      if (bb && z == sz - 1) {  // trimmed slice: all background
+        w1 = 0u;
+        r1 = wd == 0 ? 1u : 0u;
+      }
+      nz[o0 + (int64_t)sx * nwords] = w1;
+      rs[o0 + (int64_t)sx * nwords] = r1;
+    }
   }
 }
 
+// Along Z: words [y][Z/32][x] over the doubled Z axis of the even row 2y: (fg, fg && +z) per voxel.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_vg_bits_z(const T *__restrict__ labels, const uint8_t *__restrict__ graph, uint32_t *__restrict__ nz,
+            uint32_t *__restrict__ rs, int sx, int sy, int sz, int Z2, int nwords, int bb) {
+  const int64_t total = (int64_t)sx * nwords * sy;
+  const int64_t sxy = (int64_t)sx * sy;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % sx);
+    const int wd = (int)((idx / sx) % nwords);
+    const int y = (int)(idx / ((int64_t)sx * nwords));
+    const int64_t base = x + (int64_t)sx * y;
+    const int v0 = wd * 16;
+    T lab[17];
+    uint8_t gr[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+      int v = v0 + k - 1;
+      v = v < 0 ? 0 : (v < sz ? v : sz - 1);
+      lab[k] = labels[base + sxy * v];
+      gr[k] = graph[base + sxy * v];
+    }
+    uint32_t w = 0, carry = 0;
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+      const int v = v0 + k - 1;
+      const bool fg = vg_fg(lab[k]);
+      bool o = fg && (gr[k] & 0x10u);
+      if (bb && v == sz - 1) o = false;
+      if (k == 0) carry = o ? 1u : 0u;
+      else if (v < sz) w |= (fg ? 1u : 0u) << (2 * k - 2) | (o ? 1u : 0u) << (2 * k - 1);
+    }
+    if (wd == 0) carry = 0;
+    uint32_t r = w ^ ((w << 1) | carry);
+    if (wd == 0) r |= 1u;
+    const int valid = Z2 - wd * 32;
+    if (valid < 32) r &= (1u << valid) - 1u;
+    nz[idx] = w;
+    rs[idx] = r;
+  }
+}
+
+// The even cells of the even rows of the even slices -> the caller's array.
 __global__ void k_vg_gather_even(const float *__restrict__ F1, float *__restrict__ out, int64_t sx, int64_t sy,
                                  int64_t sz, int64_t Y2, int ndim) {
   const int64_t total = sx * sy * sz;
@@ -333,6 +402,18 @@ __global__ void k_vg_gather_even(const float *__restrict__ F1, float *__restrict
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t x = idx % sx, y = (idx / sx) % sy, z = idx / (sx * sy);
     out[idx] = F1[x + sx * (2 * y + Y2 * (ndim == 3 ? 2 * z : 0))];
+  }
+}
+// (rows of whole 16-byte granules: four cells per thread)
+__global__ void k_vg_gather_even4(const float *__restrict__ F1, float *__restrict__ out, int64_t sx4, int64_t sy,
+                                  int64_t sz, int64_t Y2, int ndim) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int64_t total = sx4 * sy * sz;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t x = idx % sx4, y = (idx / sx4) % sy, z = idx / (sx4 * sy);
+    reinterpret_cast<v4f *>(out)[idx] =
+        __builtin_nontemporal_load(reinterpret_cast<const v4f *>(F1) + x + sx4 * (2 * y + Y2 * (ndim == 3 ? 2 * z : 0)));
   }
 }
 
@@ -391,11 +472,11 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
                        labels, graph, ttab, F1, (int)sx, (int)sy, (int)sz, (int)Y2, (int)Z2, bb, idx_inf);
   }
   {
-    const int64_t total = sx * nbY * Z2;
+    const int64_t total = sx * nbY * (ndim == 3 ? sz : 1);  // one thread per word of slice 2z AND of slice 2z+1
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL((k_vg_bits<T, false>), dim3((unsigned)blocks), dim3(256), 0, stream, labels, graph, nzY, rsY,
-                       (int)sx, (int)sy, (int)sz, (int)Y2, (int)Z2, (int)nbY, bb);
+    hipLaunchKernelGGL((k_vg_bits_y<T>), dim3((unsigned)blocks), dim3(256), 0, stream, labels, graph, nzY, rsY,
+                       (int)sx, (int)sy, (int)(ndim == 3 ? sz : 1), (int)Y2, ndim == 3 ? 1 : 0, (int)nbY, bb);
   }
   EDT_HIP_TRY(hipGetLastError());
   const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0);
@@ -408,18 +489,24 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
     const int64_t total = sx * nbZ * sy;
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL((k_vg_bits<T, true>), dim3((unsigned)blocks), dim3(256), 0, stream, labels, graph, nzZ, rsZ,
-                       (int)sx, (int)sy, (int)sz, (int)Y2, (int)Z2, (int)nbZ, bb);
+    hipLaunchKernelGGL((k_vg_bits_z<T>), dim3((unsigned)blocks), dim3(256), 0, stream, labels, graph, nzZ, rsZ,
+                       (int)sx, (int)sy, (int)sz, (int)Z2, (int)nbZ, bb);
     EDT_HIP_TRY(hipGetLastError());
     AxisGeom gz;  // the even rows only: outer index = y, two doubled rows apart
     gz.sx = sx; gz.n = Z2; gz.stride = sx * Y2; gz.nouter = sy; gz.outer_stride = 2 * sx; gz.nbands = nbZ;
     rc = launch_column_pass_wave(F1, nzZ, rsZ, gz, hz, bb, last_epi, stream, nullptr, 2);
     if (rc != EDT_OK) return rc;
   }
-  int64_t blocks = ceil_div(sx * sy * sz, 256);
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(k_vg_gather_even, dim3((unsigned)blocks), dim3(256), 0, stream, F1, out, sx, sy,
-                     ndim == 3 ? sz : 1, Y2, ndim);
+  const int64_t nz_out = ndim == 3 ? sz : 1;
+  if (sx % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) {
+    int64_t blocks = ceil_div(sx / 4 * sy * nz_out, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_vg_gather_even4, dim3((unsigned)blocks), dim3(256), 0, stream, F1, out, sx / 4, sy, nz_out, Y2, ndim);
+  } else {
+    int64_t blocks = ceil_div(sx * sy * nz_out, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_vg_gather_even, dim3((unsigned)blocks), dim3(256), 0, stream, F1, out, sx, sy, nz_out, Y2, ndim);
+  }
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }

@@ -52,7 +52,9 @@ static hipEvent_t log_event() {
 struct ScopedPass {
   hipStream_t stream;
   int start = -1;
-  ScopedPass(const char *name, hipStream_t s) : stream(s) {
+  bool named;
+  ScopedPass(const char *name, hipStream_t s) : stream(s), named(name != nullptr) {  // (no name: not a pass of its own)
+    if (!named) return;
     if (g_debug_mode & 0x1000) fprintf(stderr, "[edt_hip] pass start: %s\n", name);
     if (!g_log.enabled.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::mutex> lock(g_log_mutex);  // (only while profiling is switched on)
@@ -63,6 +65,7 @@ struct ScopedPass {
     g_log.names.push_back(name);
   }
   ~ScopedPass() {
+    if (!named) return;
     if (g_debug_mode & 0x1000) {  // diagnostics: name every pass as it completes
       const hipError_t e = hipStreamSynchronize(stream);
       fprintf(stderr, "[edt_hip] pass done: %s\n", hipGetErrorString(e));
@@ -104,8 +107,8 @@ struct Plan {
   float *bufB = nullptr;
   int32_t *stack = nullptr;
   uint32_t *nz_y = nullptr, *rs_y = nullptr, *zs_y = nullptr, *nz_z = nullptr, *rs_z = nullptr;
-  void *xrec = nullptr;   // per-row run records of pass 1 (fused X+Y path)
-  float *ttab = nullptr;  // T[0..sx+2]
+  uint16_t *codes = nullptr;  // 16-bit distance indices of pass 1 (index form), one slab of xy_slab slices
+  int64_t xy_slab = 0;        // slices per slab of the slab-wise X/Y passes (0: no index form for this shape)
   size_t bytes = 0;
 };
 
@@ -124,10 +127,26 @@ static AxisGeom make_geom_z(int64_t sx, int64_t sy, int64_t sz) {
 
 // What a call needs besides the bit planes: the second fp32 volume + hull stacks of the size-agnostic
 // column pass (only when an axis is too long for the in-place LDS kernels, or the caller forces the
-// generic kernels), and the row records of the fused X+Y experiment (debug bit 128).
+// generic kernels), and one slab of 16-bit distance indices for the index form of pass 1.
 static bool plan_needs_pingpong(int ndim, int64_t sx, int64_t sy, int64_t sz, int flags);
 
-static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws, int flags) {
+// Index form of pass 1 (edt_rowwave.hip C16 -> edt_colwave_kernel.h XF): pass 1 hands the first column pass 2 bytes
+// per voxel instead of 4.  The indices live in the workspace, never more than kCodeSlabVoxels of them: passes X and
+// Y touch one z-slice at a time, so larger volumes run them slab by slab (a slab of 2^27 voxels is a whole 512^3
+// volume's worth of parallelism) -- 256 MiB of scratch whatever the volume.  Shapes: the register-resident pass 1
+// and the wave column kernel, rows of whole 8-byte granules.  (debug bit 0x100000 switches the form off.)
+constexpr int64_t kCodeSlabVoxels = (int64_t)1 << 27;
+constexpr int EDT_FLAG_NO_INDEX_FORM = 0x8000;  // internal: plan without the index buffer
+static bool env_force_generic();
+static int64_t plan_code_slab(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
+  if (ndim < 2 || sx % 4 != 0 || sx * sy > kCodeSlabVoxels || (flags & EDT_FLAG_NO_INDEX_FORM)) return 0;
+  if ((flags & EDT_FLAG_FORCE_GENERIC) || env_force_generic() || (g_debug_mode & (0x100000 | 64 | 32))) return 0;
+  if (!row_pass_wave_supported(dtype, sx, sy, sz) || !column_pass_wave_supported(make_geom_y(sx, sy, sz))) return 0;
+  const int64_t slab = kCodeSlabVoxels / (sx * sy);
+  return slab < sz ? slab : sz;
+}
+
+static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws, int flags) {
   Plan p;
   p.ndim = ndim; p.sx = sx; p.sy = sy; p.sz = sz; p.voxels = sx * sy * sz;
   p.gy = make_geom_y(sx, sy, sz);
@@ -152,9 +171,9 @@ static Plan make_plan(int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws, in
     else p.rs_z = c.take<uint32_t>(wz);
     p.zs_y = c.take<uint32_t>(wy);
   }
-  if (ndim >= 2 && (g_debug_mode & 128)) {
-    p.xrec = c.take<unsigned char>(row_records_bytes(sx, sy, sz));
-    p.ttab = c.take<float>((size_t)sx + 3);
+  if (ndim >= 2) {
+    p.xy_slab = plan_code_slab(dtype, ndim, sx, sy, sz, flags);
+    if (p.xy_slab > 0) p.codes = c.take<uint16_t>((size_t)(p.xy_slab * sx * sy));
   }
   if (ndim == 1) (void)c.take<unsigned char>(line_workspace_bytes(sx));  // block scan + table of the 1-D pipeline
   p.bytes = align_up(c.off, 256) + 256;
@@ -230,7 +249,9 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   if (rc != EDT_OK) return rc;
   if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
   if (!d_labels || !d_out) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
-  Plan p = make_plan(ndim, sx, sy, sz, d_ws, flags);
+  Plan p = make_plan(dtype, ndim, sx, sy, sz, d_ws, flags);
+  // (a workspace sized while the index form of pass 1 was switched off still serves: fp32 form)
+  if (d_ws && ws_bytes < p.bytes && p.codes != nullptr) p = make_plan(dtype, ndim, sx, sy, sz, d_ws, flags | EDT_FLAG_NO_INDEX_FORM);
   if (!d_ws || ws_bytes < p.bytes) {
     set_error("workspace too small: need " + std::to_string(p.bytes) +
               " bytes (edt_hip_workspace_bytes_flags with the flags of this call)");
@@ -264,18 +285,34 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   float *cur = (swaps % 2 == 0) ? d_out : p.bufB;
   float *other = (cur == d_out) ? p.bufB : d_out;
   const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
-  // Fused X+Y: pass 1 only emits bit planes and per-row run records, the first column pass rebuilds
-  // F from them (no fp32 volume is written by pass 1 or read by pass 2).  MEASURED SLOWER on MI355X
-  // (0.905 vs 0.83 ms per 512^3 step: both kernels are bound by instruction issue, not by HBM, so
-  // trading 1 GB of traffic for ~25 more instructions per voxel loses) -- kept behind debug bit 128.
-  const bool fused_xy = !force_generic && (g_debug_mode & 128) && p.xrec != nullptr && !(g_debug_mode & (64 | 32)) && sx <= 512 && sx % 4 == 0 && p.gy.nbands <= 16 &&
-                        row_pass_wave_supported(dtype, sx, sy, sz) && column_pass_wave_supported(p.gy);
-  if (fused_xy) {
-    {
-      ScopedPass t("x_bits", stream);
-      rc = launch_row_records(dtype, d_labels, p.xrec, p.ttab, p.nz_y, p.rs_y, zpass ? p.zs_y : nullptr,
-                              sx, sy, sz, wx, bb, stream);
-      if (rc != EDT_OK) return rc;
+  // Index form of pass 1 (see plan_code_slab): pass 1 stores 16-bit distance indices, the first column pass turns
+  // them into F while it fills its tile -- 2 B less written and 2 B less read per voxel.  Bit-identical only where
+  // every multiple k * wx of the row is exact in fp32 (row_codes_exact); other voxel sizes keep the fp32 form.
+  const bool index_form = p.codes != nullptr && tiled_x && tiled_y && row_codes_exact(wx, sx);
+  if (index_form) {
+    const int64_t sxy = sx * sy, wpl = p.gy.sx * p.gy.nbands;  // voxels / bit words per slice
+    const size_t lsz = dtype_size(dtype);
+    const bool one = p.xy_slab >= sz;
+    ScopedPass whole(one ? nullptr : "xy_pass", stream);
+    for (int64_t z0 = 0; z0 < sz; z0 += p.xy_slab) {
+      const int64_t zc = std::min<int64_t>(p.xy_slab, sz - z0);
+      const char *lab = static_cast<const char *>(d_labels) + (size_t)(z0 * sxy) * lsz;
+      {
+        // (slice 0 of a later slab compares against the slice below it through the halo pointer of the sharded path)
+        ScopedPass t(one ? "x_pass" : nullptr, stream);
+        rc = launch_row_pass_wave(dtype, lab, nullptr, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl,
+                                  zpass ? p.zs_y + z0 * wpl : nullptr, sx, sy, zc, wx, bb, bb ? 0 : 1, stream,
+                                  z0 > 0 ? lab - (size_t)sxy * lsz : nullptr, p.codes);
+        if (rc != EDT_OK) return rc;
+      }
+      {
+        ScopedPass t(one ? "y_pass" : nullptr, stream);
+        AxisGeom g = p.gy;
+        g.nouter = zc;
+        rc = launch_column_pass_wave_codes(cur + z0 * sxy, p.codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
+                                           zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream);
+        if (rc != EDT_OK) return rc;
+      }
     }
   } else if (tiled_x) {
     // labels are read once: pass 1 also emits the run bit-planes of the y and z axes
@@ -297,13 +334,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
       if (rc != EDT_OK) return rc;
     }
   }
-  {
+  if (!index_form) {
     ScopedPass t("y_pass", stream);
     const int epi = zpass ? 0 : last_epi;
-    if (fused_xy) {
-      rc = launch_column_pass_wave_xfused(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, p.xrec, p.ttab,
-                                          bb ? 0 : 1, stream);
-    } else if (tiled_y) {
+    if (tiled_y) {
       rc = launch_column_inplace(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, stream);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_y, p.rs_y, p.stack, p.gy, wy, bb, epi, stream);
@@ -314,7 +348,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   if (zpass) {
     // z-packed planes (after the y pass: rs_z may live in the y pass's run-start plane)
     ScopedPass t("z_bits", stream);
-    if (fused_xy || tiled_x) rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
+    if (tiled_x) rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
     else rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
     if (rc != EDT_OK) return rc;
   }
@@ -743,7 +777,7 @@ int edt_hip_sdf(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy,
 size_t edt_hip_workspace_bytes_flags(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
   if (check_shape(dtype, ndim, sx, sy, sz) != EDT_OK) return 0;
   if (sx == 0 || sy == 0 || sz == 0) return 256;
-  return make_plan(ndim, sx, sy, sz, nullptr, flags).bytes;
+  return make_plan(dtype, ndim, sx, sy, sz, nullptr, flags).bytes;
 }
 
 size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {

@@ -42,8 +42,8 @@ static int launch_wave_any(float *F, const uint32_t *nz, const uint32_t *rs, con
   if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
   if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
   if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
-  if (NB <= 32 && xf == nullptr) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, nullptr, stream, sc, sc_al, out_stride);
-  if (NB <= 64 && xf == nullptr) return launch_wave_c<1>(F, nz, rs, g, w, bb, epi, nullptr, stream, sc, sc_al, out_stride);
+  if (NB <= 32) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
+  if (NB <= 64) return launch_wave_c<1>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
   set_error("axis too long for the wave column pass");
   return EDT_ERR_UNSUPPORTED;
 }
@@ -54,16 +54,13 @@ int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, co
   return launch_wave_any(F, nz, rs, g, w, bb, epi, nullptr, stream, scatter, scatter != nullptr, out_stride);
 }
 
-// First column pass with pass 1 fused in: F is only written.  `meta` = row records of k_row_bits,
-// `ttab` = T[0..sx+2] (sequential fp32 sums of wx, +inf at sx+2), to_finite as in pass 1.
-int launch_column_pass_wave_xfused(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                                   float w, int bb, int epi, const void *meta, const float *ttab,
-                                   int to_finite, hipStream_t stream) {
+// First column pass reading pass 1 as 16-bit distance indices (edt_rowwave.hip, C16): F is only written.
+int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_t *nz, const uint32_t *rs,
+                                  const AxisGeom &g, float w, int bb, int epi, float wx, int to_finite,
+                                  hipStream_t stream) {
   XFuse xf;
-  xf.meta = meta;
-  xf.ttab = ttab;
-  xf.nchunks = (int)ceil_div(g.sx, 64);
-  xf.idx_inf = (int)g.sx + 2;
+  xf.codes = codes;
+  xf.w = wx;
   xf.flim = to_finite ? 0x7f7fffff : 0x7f800000;
   return launch_wave_any(F, nz, rs, g, w, bb, epi, &xf, stream);
 }

@@ -253,21 +253,17 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   constexpr int W = TC / CW;     // waves per workgroup
   using IO = TileIO<CW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS image: [one band of padding][the tile: NBP bands][one band of padding][alive][rsp][lohi][1 word]; the
-  // padding bands hold +inf for the windowed path (edt_colwave_lane.h: brute_band), the XF kernels have none
-  constexpr int kPad = XF ? 0 : TG::kBandFloats;
+  // LDS image: [one band of padding][the tile: NBP bands][one band of padding][alive][rsp][lohi][bscan]; the
+  // padding bands hold +inf for the windowed path (edt_colwave_lane.h: brute_band)
+  constexpr int kPad = TG::kBandFloats;
   float *tile = reinterpret_cast<float *>(smem) + kPad;                            // [NBP*32][TC] (+ band padding)
   uint32_t *alive = reinterpret_cast<uint32_t *>(tile + NBP * TG::kBandFloats + kPad);  // [NBP][TC]
   uint32_t *rsp = alive + NBP * TG::kBandWords;                                    // [NBP][TC]
   uint32_t *lohi = rsp + NBP * TG::kBandWords;     // [NBP][TC]: (lo_in + 1) | (hi_out + 1) << 16 (windowed path)
-  uint32_t *bscan = lohi + (XF ? 0 : NBP * TG::kBandWords);  // [NBP][TC]: the same for the breaks
+  uint32_t *bscan = lohi + NBP * TG::kBandWords;   // [NBP][TC]: the same for the breaks
   // 2 words: largest field value of the tile, "some link of the tile is not flat".  They sit in the lower padding band (so that the LDS image of the
   // 512-row shape is exactly half of a CU's 160 KiB), which is only filled with +inf once every thread has read them.
-  uint32_t *tmax = XF ? lohi : reinterpret_cast<uint32_t *>(smem);
-  // XF only: row records, one spare slot per band so that the bands of a half-wave read
-  // different banks ([33*NBP] x 16 B), then the table T ([sx+3] floats)
-  XRowMeta *xrec = reinterpret_cast<XRowMeta *>(tmax + 4);
-  float *xT = reinterpret_cast<float *>(xrec + 33 * NBP);
+  uint32_t *tmax = reinterpret_cast<uint32_t *>(smem);
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
@@ -300,6 +296,30 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   // cache policy of the tile fill: streaming (nt) for whole-line tiles; the 16-column tiles must leave
   // their lines in L2 for the workgroup that takes the other half
   constexpr int kLoadAux = CW <= 2 ? 0 : EDT_TILE_LOAD_AUX;
+  Lane L;
+  L.tile = tile;
+  L.alive = alive;
+  L.rsp = rsp;
+  L.colc = wave * CW + (lane % CW);
+  L.band = lane / CW;
+  L.row0 = L.band * 32;
+  L.n = n;
+  L.w2 = (double)(w * w);  // fp32 product widened (src/edt.hpp:181, :258)
+  L.nzw = 0;
+  L.rsw = 0;
+  const bool active = L.colc < cols_left && L.band < NB;
+  auto load_bits = [&] {
+    if (active) {
+      const int64_t widx = (o * g.nbands + L.band) * g.sx + x0 + L.colc;
+      L.nzw = nzbits[widx];
+      L.rsw = rsbits[widx];
+    }
+  };
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  constexpr int NI = IO::count(NBP, 4) / W;  // 16-byte tile instructions per wave (8 for every wave shape)
+  static_assert(NI * W == IO::count(NBP, 4), "tile instructions divide evenly among the waves");
+  v2u q[XF ? NI : 1];  // XF: the wave's share of the tile as 16-bit indices, four per lane and instruction
   if constexpr (!XF) {
     // ---- phase 0: the whole tile, HBM -> LDS --------------------------------------------
     // one instruction = 64 lanes x G floats = 2*G rows of 128 B, all rows in one band
@@ -323,69 +343,81 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
               (__attribute__((address_space(3))) void *)(tile + io_lds_word<CW, 1>(i, 0)), 4, 0, kLoadAux);
       }
     }
+    load_bits();
   } else {
-    // ---- phase 0 (fused pass 1): the row records of this tile's chunk and the table T -> LDS ----
-    const XRowMeta *recs = static_cast<const XRowMeta *>(xf.meta) + ((int64_t)o * xf.nchunks + (x0 >> 6)) * n;
-    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) xrec[i + (i >> 5)] = recs[i];
-    for (int i = (int)threadIdx.x; i < xf.idx_inf + 1; i += (int)blockDim.x) xT[i] = xf.ttab[i];
-  }
-
-  Lane L;
-  L.tile = tile;
-  L.alive = alive;
-  L.rsp = rsp;
-  L.colc = wave * CW + (lane % CW);
-  L.band = lane / CW;
-  L.row0 = L.band * 32;
-  L.n = n;
-  L.w2 = (double)(w * w);  // fp32 product widened (src/edt.hpp:181, :258)
-  L.nzw = 0;
-  L.rsw = 0;
-  const bool active = L.colc < cols_left && L.band < NB;
-  if (active) {
-    const int64_t widx = (o * g.nbands + L.band) * g.sx + x0 + L.colc;
-    L.nzw = nzbits[widx];
-    L.rsw = rsbits[widx];
+    // ---- phase 0 (index form of pass 1), first half: the bit words, then the indices of the whole tile are
+    // requested (8 bytes per lane and instruction); they are turned into the fp32 tile further down, after the run
+    // scan, which only waits for the bit words
+    load_bits();
+    if (IO::kGran == 4 && aligned16) {
+      const uint16_t *Ctile = xf.codes + x0 + o * g.outer_stride;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int i = wave + j * W;
+        const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+        q[j] = (v2u){0u, 0u};
+        if (row < n && gc < cols_left)
+          q[j] = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(Ctile + (int64_t)row * st + gc));
+      }
+    }
   }
   rsp[addr_word<CW>(L.colc, L.band)] = L.rsw;
   scan_runs<CW>(L, lane);
-  if constexpr (!XF) {
-    // the rows that complete the last band are not part of the column: 0 for the tile maximum below
-    for (int i = (int)threadIdx.x; i < (NB * 32 - n) * TC; i += (int)blockDim.x)
-      tile[addr_tile<CW>(i % TC, n + i / TC)] = 0.0f;
-    if (threadIdx.x < 2) tmax[threadIdx.x] = 0u;
+  if constexpr (XF) {
+    // ---- phase 0, second half: indices -> fp32 tile (edt_colwave_lane.h: code_value, four at a time) ----
+    const uint16_t *Ctile = xf.codes + x0 + o * g.outer_stride;
+    if (IO::kGran == 4 && aligned16) {
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      const v2f ww = {xf.w, xf.w};
+      const bool finite_only = xf.flim == 0x7f800000;  // black border: no "no boundary" index, no tofinite (wave-uniform)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int i = wave + j * W;
+        const uint32_t q0 = q[j][0], q1 = q[j][1];
+        v2f a = {(float)(q0 & 0xFFFFu), (float)(q0 >> 16)};
+        v2f b = {(float)(q1 & 0xFFFFu), (float)(q1 >> 16)};
+        a = a * ww;  // exact products (row_codes_exact)
+        b = b * ww;
+        a = a * a;
+        b = b * b;
+        v4f v = {a.x, a.y, b.x, b.y};
+        if (!finite_only) {
+          v.x = __int_as_float(min((q0 & 0xFFFFu) == kCodeInf ? 0x7f800000 : __float_as_int(v.x), xf.flim));
+          v.y = __int_as_float(min((q0 >> 16) == kCodeInf ? 0x7f800000 : __float_as_int(v.y), xf.flim));
+          v.z = __int_as_float(min((q1 & 0xFFFFu) == kCodeInf ? 0x7f800000 : __float_as_int(v.z), xf.flim));
+          v.w = __int_as_float(min((q1 >> 16) == kCodeInf ? 0x7f800000 : __float_as_int(v.w), xf.flim));
+        }
+        *reinterpret_cast<v4f *>(tile + io_lds_word<CW, 4>(i, lane)) = v;
+      }
+    } else {
+      for (int i = wave; i < IO::count(NBP, 1); i += W) {
+        const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+        if (row < n && gc < cols_left)
+          tile[io_lds_word<CW, 1>(i, lane)] = code_value(Ctile[(int64_t)row * st + gc], xf.w, xf.flim);
+      }
+    }
   }
+  // the rows that complete the last band are not part of the column: 0 for the tile maximum below
+  for (int i = (int)threadIdx.x; i < (NB * 32 - n) * TC; i += (int)blockDim.x)
+    tile[addr_tile<CW>(i % TC, n + i / TC)] = 0.0f;
+  if (threadIdx.x < 2) tmax[threadIdx.x] = 0u;
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // ---- own rows -> registers ---------------------------------------------------------------
   float f[32];
-  if constexpr (!XF) {
+  {
     const float *own = tile + addr_tile<CW>(L.colc, L.row0);
 #pragma unroll
     for (int r = 0; r < 32; ++r) f[r] = own[r * TC];
-  } else {
-    // pass 1 rebuilt from the row records (edt_colwave_lane.h: xpass_value), published in the tile
-    // for the hull look-ups of the other lanes of this wave
-    float *own = tile + addr_tile<CW>(L.colc, L.row0);
-    const int h = (int)((x0 >> 5) & 1), cbase = (int)(x0 & ~(int64_t)63);
-    const XRowMeta *rec = xrec + L.row0 + L.band;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      float v = 0.0f;
-      if (L.row0 + r < n) v = xpass_value(rec[r], h, cbase, L.colc, xT, xf.idx_inf, xf.flim, (L.nzw >> r) & 1u);
-      f[r] = v;
-      own[r * TC] = v;
-    }
-    wave_sync();
   }
 
   // ---- tiles whose field is small everywhere take the windowed path (edt_colwave_lane.h: brute_band) ------
   const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
   const uint32_t fl0 = (dbg & 2) ? 0u : flat_word(L, f, fprev);
   const uint32_t need = L.nzw & ~(L.rsw | (L.band == 0 ? 1u : 0u));  // rows that continue a run
-  if constexpr (!XF) {
+  {
     if (ba.limit_bits != 0u) {  // (wave-uniform: kernel argument)
       uint32_t fm = 0;
 #pragma unroll
@@ -484,16 +516,14 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   constexpr int NBP = 64 / CW;
   using TG = edt_lane::TileGeom<CW>;
   constexpr int TC = TG::kCols;
-  size_t lds = (size_t)NBP * TG::kBandFloats * sizeof(float) + 2 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
-  if (XF) lds += 16 + (size_t)33 * NBP * sizeof(edt_lane::XRowMeta) + (size_t)(xf.idx_inf + 1) * sizeof(float);
-  else lds += 2 * (size_t)TG::kBandFloats * sizeof(float) + 2 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
+  const size_t lds = (size_t)(NBP + 2) * TG::kBandFloats * sizeof(float) + 4 * (size_t)NBP * TG::kBandWords * sizeof(uint32_t);
   // the windowed path (edt_colwave_lane.h: brute_band): tiles whose largest field value is at most c_T
   BruteArgs ba;
   ba.limit_bits = 0u;
   ba.x32 = 0;
   ba.force = 0;
   ba.stride = (out_stride == 2 && !(debug_mode() & 0x40000)) ? 2 : 1;  // (debug bit 0x40000: evaluate every row)
-  if (!XF && !(debug_mode() & 0x2000) && w * w >= 1.17549435e-38f && (double)w * (double)w < 1.0e30) {
+  if (!(debug_mode() & 0x2000) && w * w >= 1.17549435e-38f && (double)w * (double)w < 1.0e30) {
     const bool force = (debug_mode() & 0x4000) != 0;
     // The window limit: tools/window_sweep.py (smooth Voronoi cells of growing size, 512^3) puts the
     // crossover with the hull path between windows of ~170 and ~270 rows.  fp32 candidates need c_d exact in
@@ -522,7 +552,8 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   if (!(debug_mode() & 0x800)) tiles = tiles_x * (ceil_div(g.nouter, 8) * 8);  // XCD-aware order
   // 16-byte granules need 16-byte aligned rows; otherwise the tile moves float by float
   const int aligned16 = (g.sx % 4) == 0 && (g.stride % 4) == 0 && (g.outer_stride % 4) == 0 &&
-                        (reinterpret_cast<uintptr_t>(F) % 16) == 0 && (scatter == nullptr || scatter_aligned);
+                        (reinterpret_cast<uintptr_t>(F) % 16) == 0 && (scatter == nullptr || scatter_aligned) &&
+                        (!XF || reinterpret_cast<uintptr_t>(xf.codes) % 8 == 0);
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF, SC>), dim3((unsigned)tiles), dim3(64 * TC / CW), lds, stream,
                      F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), aligned16, xf, scatter, ba);
@@ -546,8 +577,8 @@ template <int CW>
 int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                          int bb, int epi, const XFuse *xf, hipStream_t stream, const BandScatter *scatter,
                          bool sc_al, int out_stride) {
-  // the border rule and the fused pass 1 are compile-time variants, the epilogue a run-time one
-  const XFuse none = {nullptr, nullptr, 0, 0, 0};
+  // the border rule and the index form of pass 1 are compile-time variants, the epilogue a run-time one
+  const XFuse none = {nullptr, 0.0f, 0};
   if (xf)
     return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride)
               : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride);

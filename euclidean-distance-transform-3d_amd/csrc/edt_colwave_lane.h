@@ -135,55 +135,23 @@ struct Lane {
 };
 
 // ---------------------------------------------------------------------------------------
-// Pass 1 fused into the first column pass.  Pass 1 (src/edt.hpp:70-119) has the closed form
-//     F = fl32(d*d),  d = min(T[x-s+1], T[e-x+1]),  T[k] = k-fold sequential fp32 sum of wx,
-// for a voxel x inside the maximal run [s,e] of one non-zero label (a side without a boundary
-// contributes +inf).  So a row of pass-1 output is fully described by its run-start bits:
-// the bit kernel (edt_rowwave.hip) stores, per row and 64-voxel chunk, 16 bytes
-//     { start mask (64 bits), last start before the chunk, first start after the chunk }
-// and the column kernel rebuilds F for its 32 columns of the row from ONE such record instead
-// of reading 128 bytes of fp32 -- pass 1 never writes F to HBM and pass 2 never reads it.
-// "No boundary on this side" is a start position far outside the row (+-2^20): the table index
-// saturates at idx_inf, where T holds +inf.
+// Index form of pass 1.  Pass 1 (src/edt.hpp:70-119) has the closed form
+//     F = fl32(d*d),  d = T[k],  k = min(x-s+1, e-x+1),  T[k] = k-fold sequential fp32 sum of wx,
+// for a voxel x inside the maximal run [s,e] of one non-zero label (a side without a boundary does not count;
+// no boundary at all: +inf).  When k*wx is exactly representable for every k of the row (edt_rowwave.hip:
+// row_codes_exact) the sequential sums are exact, T[k] = k*wx, and pass 1 may hand the first column pass the 16-bit
+// index k instead of the fp32 value: 2 bytes less written and 2 bytes less read per voxel.  The column kernel turns
+// the index back into F while it fills its tile: k = 0 (background) -> 0, kCodeInf -> +inf, then tofinite
+// (src/edt.hpp:39-45) as pass 1 applies it.  flim = bit pattern of FLT_MAX (tofinite) or of +inf; with a black
+// border every run has two borders, no index is kCodeInf and flim is +inf.
 // ---------------------------------------------------------------------------------------
-struct XRowMeta {
-  uint32_t lo, hi;  // run starts of the chunk's voxels 0..31 / 32..63
-  int pre;          // position of the last run start before the chunk
-  int suf;          // position of the first run start after the chunk
-};
-
-// F(x0 + col) for the row described by `m`; the tile covers half `h` (0/1) of the chunk that
-// begins at voxel `cbase`; T / idx_inf as above; flim = bit pattern of FLT_MAX (tofinite,
-// src/edt.hpp:39-45) or of +inf; nz = the voxel is foreground.
-EDT_LANE float xpass_value(const XRowMeta &m, int h, int cbase, int col, const float *T, int idx_inf,
-                           int flim, bool nz) {
-  const uint32_t W = h ? m.hi : m.lo;
-  const int x0 = cbase + 32 * h;
-  const int fpre = h ? (m.lo ? cbase + 31 - clz32(m.lo) : m.pre) : m.pre;
-  const int fsuf = h ? m.suf : (m.hi ? cbase + 32 + ctz32(m.hi) : m.suf);
-  const uint32_t m1 = W & (0xFFFFFFFFu >> (31 - col));            // starts at or before the voxel
-  const uint32_t m2 = col < 31 ? (W & (0xFFFFFFFEu << col)) : 0u;  // starts after it
-  const int x = x0 + col;
-  const int s = m1 ? x0 + 31 - clz32(m1) : fpre;  // first voxel of the run
-  const int e1 = m2 ? x0 + ctz32(m2) : fsuf;      // one past its last voxel
-  int il = x - s + 1, ir = e1 - x;
-  il = il < idx_inf ? il : idx_inf;
-  ir = ir < idx_inf ? ir : idx_inf;
-  // non-negative floats order like their bit patterns: integer min / clamp, no NaN handling
-  int dl, dr;
-  {
-    const float tl = T[il], tr = T[ir];
-    memcpy(&dl, &tl, 4);
-    memcpy(&dr, &tr, 4);
-  }
-  const int dbits = dl < dr ? dl : dr;
-  float d;
-  memcpy(&d, &dbits, 4);
-  const float sq = d * d;
+constexpr uint32_t kCodeInf = 0xFFFFu;
+EDT_LANE float code_value(uint32_t k, float w, int flim) {
+  const float d = k == kCodeInf ? INFINITY : (float)k * w;  // exact product
+  const float sq = d * d;                                   // `d[i] *= d[i]` (src/edt.hpp:116-118)
   int f;
   memcpy(&f, &sq, 4);
-  f = f < flim ? f : flim;
-  f = nz ? f : 0;
+  f = f < flim ? f : flim;  // non-negative floats order like their bit patterns
   float out;
   memcpy(&out, &f, 4);
   return out;

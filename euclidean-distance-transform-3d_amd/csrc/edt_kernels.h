@@ -93,15 +93,13 @@ int launch_bits_transpose_yz(const uint32_t *nz_y, const uint32_t *zs_y, uint32_
 }  // namespace edt_amd
 
 namespace edt_amd {
-// Arguments of the fused pass 1 (XF kernels of edt_colwave_kernel.h): the per-row run records written by
-// k_row_records ([outer][chunk][row], 16 B each: edt_lane::XRowMeta), the table T of sequential fp32 sums
-// of wx, and its limits.
+// Arguments of the index form of pass 1 (XF kernels of edt_colwave_kernel.h): pass 1 stored 16-bit distance
+// indices k (edt_rowwave.hip, C16) instead of F; the first column pass rebuilds F = fl32(fl32(k * w)^2) while it fills
+// its tile.  codes = nullptr: the ordinary in-place pass.
 struct XFuse {
-  const void *meta;
-  const float *ttab;
-  int nchunks;   // 64-voxel chunks per row
-  int idx_inf;   // index of the +inf entry of T (= sx + 2)
-  int flim;      // bit pattern of FLT_MAX (tofinite) or +inf
+  const uint16_t *codes;  // [outer][row][x], same strides (in elements) as F
+  float w;                // voxel size of pass 1 (k * w exact: row_codes_exact)
+  int flim;               // bit pattern of FLT_MAX (tofinite) or +inf
 };
 // ---- wave-autonomous LDS-tiled column pass: edt_colwave.hip -----------------------------------
 bool column_pass_wave_supported(const AxisGeom &g);
@@ -111,24 +109,22 @@ bool column_pass_wave_supported(const AxisGeom &g);
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                             float w, int bb, int epi, hipStream_t stream,
                             const BandScatter *scatter = nullptr, int out_stride = 1);
-// the same with pass 1 fused in (F is write-only): needs the row records + T of edt_rowwave.hip
-int launch_column_pass_wave_xfused(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                                   float w, int bb, int epi, const void *meta, const float *ttab,
-                                   int to_finite, hipStream_t stream);
+// the same reading pass 1 as 16-bit distance indices (F is write-only): see XFuse
+int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_t *nz, const uint32_t *rs,
+                                  const AxisGeom &g, float w, int bb, int epi, float wx, int to_finite,
+                                  hipStream_t stream);
 }  // namespace edt_amd
 
 namespace edt_amd {
 // ---- register-resident pass 1 (rows up to 512 voxels): edt_rowwave.hip -------------------------
 bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz);
 // halo: the xy-slice below slice 0 (Z-sharded slabs), or nullptr = slice 0 starts every z-run
+// codes != nullptr: 16-bit distance indices are written there INSTEAD of `out` (see XFuse)
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                         int to_finite, hipStream_t stream, const void *halo = nullptr);
-// bit planes + per-row run records only (pass 1 is then rebuilt inside the first column pass);
-// `ttab` receives T[0..sx+2].  Scratch sizes: row_records_bytes / (sx+3)*4.
-size_t row_records_bytes(int64_t sx, int64_t sy, int64_t sz);
-int launch_row_records(int dtype, const void *labels, void *meta, float *ttab, uint32_t *nz_y, uint32_t *ys_y,
-                    uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb, hipStream_t stream);
+                         int to_finite, hipStream_t stream, const void *halo = nullptr, uint16_t *codes = nullptr);
+// k * w exact for every k of a row of sx voxels: the 16-bit index form (codes) is bit-identical
+bool row_codes_exact(float w, int64_t sx);
 }  // namespace edt_amd
 
 namespace edt_amd {

@@ -25,6 +25,8 @@
 #include "edt_common.h"
 #include "edt_kernels.h"
 
+#include <cmath>
+
 #pragma clang fp contract(off)
 
 // cache policy of the result stores (experiment knob; 0 = default, 2 = nt)
@@ -80,7 +82,11 @@ static int row_xcd_schedule(int64_t nby, int64_t sz, int64_t *blocks) {
   return 1;
 }
 
-template <typename T, int NC, bool HAS_Z, bool FULL>
+// C16: the kernel stores, instead of F, the 16-bit INDEX k = min(i-s+1, e-i+1) of the voxel's distance (0 for
+// background, 0xFFFF where neither side has a boundary): half the bytes of the fp32 value, and the first column pass
+// rebuilds F = fl32(fl32(k*w)^2) while it fills its tile (edt_colwave_kernel.h, XF).  Only used when k*w is exact for
+// every k of the row (row_codes_exact): the sequential sums T[k] of the reference then ARE k*w.
+template <typename T, int NC, bool HAS_Z, bool FULL, bool C16>
 __global__ void __launch_bounds__(kRowWaves * 64)
 k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t *__restrict__ nz_y,
                 uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, float w,
@@ -91,7 +97,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
   const int lane = (int)(threadIdx.x & 63);
 
   // The reference's sequential fp32 sums of the voxel size (src/edt.hpp:97, :113).
-  if (threadIdx.x == 0) {
+  if (!C16 && threadIdx.x == 0) {
     float acc = 0.0f;
     Ttab[0] = 0.0f;
     for (int k = 1; k <= sx + 1; ++k) {
@@ -128,7 +134,8 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
     const int y0 = yb * 32;
     const int nrows = (sy - y0) < 32 ? (sy - y0) : 32;
     const T *base = labels + ((int64_t)z * sy + y0) * sx;  // row y0 of this slice
-    float *obase = out + ((int64_t)z * sy + y0) * sx;
+    constexpr uint32_t OB = C16 ? 2u : 4u;  // bytes per stored voxel
+    char *obase = reinterpret_cast<char *>(out) + (size_t)(((int64_t)z * sy + y0) * sx) * OB;
     const rsrc_t rs_lab = make_rsrc(base);
     // the slice below: inside the volume, or -- for slice 0 of a Z-sharded slab -- the halo slice
     const rsrc_t rs_bel = make_rsrc((HAS_Z && z > 0) ? base - sxy
@@ -184,11 +191,14 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
       // ---- the previous row's results leave now: issued after this row's loads have been waited
       //      for and a whole distance stage before the next wait, they retire off the critical path
       if (r > 0) {
-        const uint32_t poff = (uint32_t)((r - 1) * sx) * 4u;
+        const uint32_t poff = (uint32_t)((r - 1) * sx) * OB;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           const int x = c * 64 + lane;
-          if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, EDT_ROW_STORE_AUX);
+          if (FULL || x < sx) {
+            if (C16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pend[c], rs_out, (uint32_t)x * 2u, poff, EDT_ROW_STORE_AUX);
+            else __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, EDT_ROW_STORE_AUX);
+          }
         }
       }
       // ---- next row's loads (the last row reloads itself: those hits cost nothing) ---------------
@@ -240,22 +250,33 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
           il = x - s + 1;
           ir = e1 - x;
         }
-        il = il < idx_inf ? il : idx_inf;
-        ir = ir < idx_inf ? ir : idx_inf;
-        const int dL = as_int(Ttab[il]), dR = as_int(Ttab[ir]);
-        const float d = __int_as_float(dL < dR ? dL : dR);  // positive floats order like integers
-        int f = as_int(d * d);
-        f = f < flim ? f : flim;                             // tofinite (src/edt.hpp:39-45)
+        int f;
+        if (C16) {
+          // T is non-decreasing: min(T[il], T[ir]) = T[min(il, ir)] -- the index is all the next pass needs
+          const int k = il < ir ? il : ir;
+          // ("no boundary" is an index far beyond the row: 0xFFFF = +inf; edt_colwave_lane.h: code_value)
+          f = k < 0xFFFF ? k : 0xFFFF;
+        } else {
+          il = il < idx_inf ? il : idx_inf;
+          ir = ir < idx_inf ? ir : idx_inf;
+          const int dL = as_int(Ttab[il]), dR = as_int(Ttab[ir]);
+          const float d = __int_as_float(dL < dR ? dL : dR);  // positive floats order like integers
+          f = as_int(d * d);
+          f = f < flim ? f : flim;                             // tofinite (src/edt.hpp:39-45)
+        }
         if (!((all_fg >> c) & 1u)) f = cur[c] != T(0) ? f : 0;  // (wave-uniform test)
         pend[c] = f;
       }
     }
     {
-      const uint32_t poff = (uint32_t)((nrows - 1) * sx) * 4u;
+      const uint32_t poff = (uint32_t)((nrows - 1) * sx) * OB;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int x = c * 64 + lane;
-        if (FULL || x < sx) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, EDT_ROW_STORE_AUX);
+        if (FULL || x < sx) {
+          if (C16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pend[c], rs_out, (uint32_t)x * 2u, poff, EDT_ROW_STORE_AUX);
+          else __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, EDT_ROW_STORE_AUX);
+        }
       }
     }
 
@@ -277,219 +298,17 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// Pass 1 WITHOUT its output: when the first column pass runs the wave kernel, the fp32 result
-// of pass 1 is never materialised in HBM.  This kernel reads the labels (once), writes the three
-// bit planes as above, and -- instead of 4 bytes per voxel -- one 16-byte record per row and
-// 64-voxel chunk { run-start mask, last start before the chunk, first start after it }, laid out
-// [z][chunk][y] so that a column tile finds the records of its rows contiguous.  The column
-// kernel rebuilds F from them (edt_colwave_lane.h: xpass_value).  k_build_ttab writes the table
-// of sequential fp32 sums of wx that the closed form indexes.
-// ---------------------------------------------------------------------------------------
-__global__ void k_build_ttab(float *__restrict__ ttab, int sx, float w) {
-  // the reference's own accumulation order (src/edt.hpp:97, :113): T[k] = fl32(T[k-1] + w)
-  float acc = 0.0f;
-  ttab[0] = 0.0f;
-  for (int k = 1; k <= sx + 1; ++k) {
-    acc = acc + w;
-    ttab[k] = acc;
-  }
-  ttab[sx + 2] = INFINITY;
-}
-
-template <typename T, int NC, bool HAS_Z>
-__global__ void __launch_bounds__(kRowWaves * 64)
-k_row_records(const T *__restrict__ labels, uint4 *__restrict__ meta, uint32_t *__restrict__ nz_y,
-              uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, int bb,
-              int nby, int ngroups, int ncr, int xcd_sched) {
-  // the records of a wave's 32 rows are collected in LDS ([chunk][row], 16 B each) and leave as
-  // 512-byte runs at the end: the row loop then holds loads only, so the next row's loads can be
-  // in flight during this row's compares (stores would serialise behind them, see k_row_pass_wave)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = (int)(threadIdx.x & 63);
-  uint4 *recbuf = reinterpret_cast<uint4 *>(smem) + (size_t)wave * NC * 32;
-  const int64_t sxy = (int64_t)sx * sy;
-
-  // Work distribution.  The `zs` bits need the labels of slice z-1, which some other wave reads as
-  // ITS slice: when both run on the same XCD at about the same time the second read hits in that
-  // XCD's L2 instead of crossing the fabric again (observed placement: workgroup b runs on XCD
-  // b % 8 -- used for speed only).  So every XCD takes the y-bands congruent to its index and
-  // walks z in order: slices z-1 and z of one band are then neighbouring waves of one XCD.
-  const bool by_xcd = xcd_sched != 0;
-  const int xcd = (int)(blockIdx.x & 7), nyk = by_xcd ? (nby - xcd + 7) >> 3 : 0;
-  const int first = by_xcd ? (int)(blockIdx.x >> 3) * kRowWaves + wave : (int)blockIdx.x * kRowWaves + wave;
-  const int step = by_xcd ? (int)(gridDim.x >> 3) * kRowWaves : (int)gridDim.x * kRowWaves;
-  const int count = by_xcd ? nyk * sz : ngroups;
-  for (int i = first; i < count; i += step) {
-    const int z = by_xcd ? i / nyk : i / nby;
-    const int yb = by_xcd ? xcd + 8 * (i - z * nyk) : i - z * nby;
-    const int y0 = yb * 32;
-    const int nrows = (sy - y0) < 32 ? (sy - y0) : 32;
-    const T *base = labels + ((int64_t)z * sy + y0) * sx;  // row y0 of this slice
-    const rsrc_t rs_lab = make_rsrc(base);
-    const rsrc_t rs_bel = make_rsrc((HAS_Z && z > 0) ? base - sxy : base);
-
-    uint32_t xs[NC], xl[NC];  // per-lane BYTE offsets inside a row
-    T above[NC];
-    uint32_t nzw[NC], ysw[NC], zsw[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int x = c * 64 + lane;
-      // every load is unconditional, clamped to a voxel that exists; lanes past the end of the row
-      // read the last voxel as their own AND as their left neighbour, so they never mark a start
-      xs[c] = (uint32_t)(x < sx ? x : sx - 1) * (uint32_t)sizeof(T);
-      xl[c] = (uint32_t)(x < sx ? (x > 0 ? x - 1 : 0) : sx - 1) * (uint32_t)sizeof(T);
-      nzw[c] = 0; ysw[c] = 0; zsw[c] = 0;
-      above[c] = y0 > 0 ? buf_load<T>(make_rsrc(base - sx), xs[c], 0) : T(0);
-    }
-
-    T lab[NC], left[NC], below[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      lab[c] = buf_load<T>(rs_lab, xs[c], 0);
-      left[c] = buf_load<T>(rs_lab, xl[c], 0);
-      below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], 0) : lab[c];
-    }
-#pragma unroll 1
-    for (int r = 0; r < nrows; ++r) {
-      unsigned long long M[NC];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        M[c] = __ballot(lab[c] != left[c]);
-        shift_in(nzw[c], __ballot(lab[c] != T(0)));
-        shift_in(ysw[c], __ballot(lab[c] != above[c]));
-        if (HAS_Z) shift_in(zsw[c], __ballot(lab[c] != below[c]));
-        above[c] = lab[c];
-      }
-      {  // next row's loads (the last row reloads itself)
-        const int rn = r + 1 < nrows ? r + 1 : r;
-        const uint32_t soff = (uint32_t)(rn * sx) * (uint32_t)sizeof(T);  // wave-uniform row offset
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          lab[c] = buf_load<T>(rs_lab, xs[c], soff);
-          left[c] = buf_load<T>(rs_lab, xl[c], soff);
-          below[c] = HAS_Z ? buf_load<T>(rs_bel, xs[c], soff) : lab[c];
-        }
-      }
-      // run starts / ends carried across chunks (scalar unit).  Voxel 0 never marks itself: the
-      // start of the row is the initial carry -- position 0 with a black border, far away without.
-      int pre[NC], suf[NC];
-      {
-        int last = bb ? 0 : -(1 << 20);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          pre[c] = last;
-          if (M[c]) last = c * 64 + 63 - __builtin_clzll(M[c]);
-        }
-        int nxt = bb ? sx : (1 << 20);
-#pragma unroll
-        for (int c = NC - 1; c >= 0; --c) {
-          suf[c] = nxt;
-          if (M[c]) nxt = c * 64 + __builtin_ctzll(M[c]);
-        }
-      }
-      // the records of this row: lane c stores chunk c's
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        if (lane == c && c < ncr) {
-          uint4 rec;
-          rec.x = (uint32_t)M[c];
-          rec.y = (uint32_t)(M[c] >> 32);
-          rec.z = (uint32_t)pre[c];
-          rec.w = (uint32_t)suf[c];
-          recbuf[c * 32 + r] = rec;
-        }
-      }
-    }
-    // records out: chunk c, rows y0..y0+nrows-1 are contiguous in [z][chunk][y]
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c2 = 0; c2 < NC; c2 += 2) {
-      const int c = c2 + (lane >> 5), rr = lane & 31;
-      if (c < ncr && c < NC && rr < nrows) meta[((int64_t)z * ncr + c) * sy + (y0 + rr)] = recbuf[c * 32 + rr];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- the three bit words of this (z, y-band) -----------------------------------------------
-    const int sh = 32 - nrows;
-    const int64_t wbase = ((int64_t)z * nby + yb) * sx;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int x = c * 64 + lane;
-      if (x < sx) {
-        // row 0 of the volume starts a run along y, slice 0 starts every run along z
-        const uint32_t ys = (__brev(ysw[c]) >> sh) | (y0 == 0 ? 1u : 0u);
-        const uint32_t zs = z == 0 ? (0xFFFFFFFFu >> sh) : (__brev(zsw[c]) >> sh);
-        nz_y[wbase + x] = __brev(nzw[c]) >> sh;
-        ys_y[wbase + x] = ys;
-        if (HAS_Z) zs_y[wbase + x] = zs;
-      }
-    }
-  }
-}
-
-size_t row_records_bytes(int64_t sx, int64_t sy, int64_t sz) {
-  return (size_t)(ceil_div(sx, 64) * sy * sz) * sizeof(uint4);
-}
-
-template <typename T, int NC>
-static int launch_row_records_tn(const void *labels, void *meta, uint32_t *nz_y, uint32_t *ys_y,
-                                 uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, int bb,
-                                 hipStream_t stream) {
-  const int64_t nby = ceil_div(sy, kBandRows);
-  const int64_t ngroups = nby * sz;
-  if (ngroups <= 0) return EDT_OK;
-  int64_t blocks = ceil_div(ngroups, kRowWaves);
-  const int64_t resident = 256 * 8;
-  if (blocks > resident) blocks = resident;
-  const int xcd_sched = row_xcd_schedule(nby, sz, &blocks);
-  const int ncr = (int)ceil_div(sx, 64);
-  if (zs_y != nullptr)
-    hipLaunchKernelGGL((k_row_records<T, NC, true>), dim3((unsigned)blocks), dim3(kRowWaves * 64),
-                       (size_t)kRowWaves * NC * 32 * sizeof(uint4), stream,
-                       (const T *)labels, (uint4 *)meta, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, bb,
-                       (int)nby, (int)ngroups, ncr, xcd_sched);
-  else
-    hipLaunchKernelGGL((k_row_records<T, NC, false>), dim3((unsigned)blocks), dim3(kRowWaves * 64),
-                       (size_t)kRowWaves * NC * 32 * sizeof(uint4), stream,
-                       (const T *)labels, (uint4 *)meta, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, bb,
-                       (int)nby, (int)ngroups, ncr, xcd_sched);
-  EDT_HIP_TRY(hipGetLastError());
-  return EDT_OK;
-}
-
-template <typename T>
-static int launch_row_records_t(const void *labels, void *meta, uint32_t *nz_y, uint32_t *ys_y,
-                                uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, int bb,
-                                hipStream_t stream) {
-  const int64_t nc = ceil_div(sx, 64);
-#define GO(N) return launch_row_records_tn<T, N>(labels, meta, nz_y, ys_y, zs_y, sx, sy, sz, bb, stream)
-  if (nc <= 1) GO(1);
-  if (nc <= 2) GO(2);
-  if (nc <= 4) GO(4);
-  GO(8);
-#undef GO
-}
-
-int launch_row_records(int dtype, const void *labels, void *meta, float *ttab, uint32_t *nz_y, uint32_t *ys_y,
-                       uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                       hipStream_t stream) {
-  hipLaunchKernelGGL(k_build_ttab, dim3(1), dim3(1), 0, stream, ttab, (int)sx, w);
-  EDT_HIP_TRY(hipGetLastError());
-#define ROW_REC(T) return launch_row_records_t<T>(labels, meta, nz_y, ys_y, zs_y, sx, sy, sz, bb, stream)
-  switch (dtype) {
-    case EDT_U8: case EDT_BOOL: ROW_REC(uint8_t);
-    case EDT_U16: ROW_REC(uint16_t);
-    case EDT_U32: ROW_REC(uint32_t);
-    case EDT_U64: ROW_REC(uint64_t);
-    case EDT_F32: ROW_REC(float);
-    case EDT_F64: ROW_REC(double);
-    default: set_error("unknown dtype"); return EDT_ERR_BAD_ARG;
-  }
-#undef ROW_REC
+// k * w is exactly representable for every k <= sx + 1 (w = m * 2^e with an odd integer m and m * (sx + 1) < 2^24):
+// the reference's sequential sums T[k] = fl32(T[k-1] + w) are then exact too, i.e. T[k] = k * w, and the 16-bit
+// index form of pass 1 may be used.
+bool row_codes_exact(float w, int64_t sx) {
+  if (!(w >= 1.0e-30f) || !(w <= 1.0e30f) || sx + 2 >= 0xFFFF) return false;  // (normal range: no flushed products)
+  int e = 0;
+  const float fr = std::frexp(w, &e);                  // w = fr * 2^e, fr in [0.5, 1)
+  uint64_t m = (uint64_t)std::ldexp((double)fr, 24);   // the 24-bit significand as an integer
+  while (m != 0 && !(m & 1u)) m >>= 1;
+  if (m * (uint64_t)(sx + 1) >= (1ull << 24)) return false;
+  return (double)w * (double)(sx + 1) < 3.0e38;         // (no overflow before the square)
 }
 
 bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
@@ -499,7 +318,7 @@ bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
 template <typename T, int NC>
 static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                               uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                              int to_finite, hipStream_t stream, const void *halo) {
+                              int to_finite, hipStream_t stream, const void *halo, bool codes) {
   const int64_t nby = ceil_div(sy, kBandRows);
   const int64_t ngroups = nby * sz;
   if (ngroups <= 0) return EDT_OK;
@@ -508,13 +327,15 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
   const int64_t resident = 256 * 8;  // persistent grid: the T table is built once per workgroup
   if (blocks > resident) blocks = resident;
   const int xcd_sched = row_xcd_schedule(nby, sz, &blocks);
-#define LAUNCH(Z, F)                                                                                      \
-  hipLaunchKernelGGL((k_row_pass_wave<T, NC, Z, F>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds, stream,  \
+#define LAUNCH(Z, F, C)                                                                                   \
+  hipLaunchKernelGGL((k_row_pass_wave<T, NC, Z, F, C>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds, stream,  \
                      (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb, to_finite, \
                      (int)nby, (int)ngroups, xcd_sched, (const T *)halo)
+#define LAUNCH_C(Z, F) do { if (codes) LAUNCH(Z, F, true); else LAUNCH(Z, F, false); } while (0)
   const bool full = sx == 64 * NC;
-  if (zs_y != nullptr) { if (full) LAUNCH(true, true); else LAUNCH(true, false); }
-  else { if (full) LAUNCH(false, true); else LAUNCH(false, false); }
+  if (zs_y != nullptr) { if (full) LAUNCH_C(true, true); else LAUNCH_C(true, false); }
+  else { if (full) LAUNCH_C(false, true); else LAUNCH_C(false, false); }
+#undef LAUNCH_C
 #undef LAUNCH
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
@@ -523,9 +344,9 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
 template <typename T>
 static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                              uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                             int to_finite, hipStream_t stream, const void *halo) {
+                             int to_finite, hipStream_t stream, const void *halo, bool codes) {
   const int64_t nc = ceil_div(sx, 64);
-#define GO(N) return launch_row_wave_tn<T, N>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo)
+#define GO(N) return launch_row_wave_tn<T, N>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes)
   if (nc <= 1) GO(1);
   if (nc <= 2) GO(2);
   if (nc <= 4) GO(4);
@@ -536,9 +357,11 @@ static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uin
 
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                         int to_finite, hipStream_t stream, const void *halo) {
+                         int to_finite, hipStream_t stream, const void *halo, uint16_t *codes) {
+  // codes != nullptr: the 16-bit distance indices go there and `out` is not touched
+  if (codes != nullptr) out = reinterpret_cast<float *>(codes);
 #define ROW_WAVE(T) \
-  return launch_row_wave_t<T>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo)
+  return launch_row_wave_t<T>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes != nullptr)
   switch (dtype) {
     case EDT_U8: case EDT_BOOL: ROW_WAVE(uint8_t);
     case EDT_U16: ROW_WAVE(uint16_t);

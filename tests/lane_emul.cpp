@@ -32,8 +32,8 @@ namespace {
 
 template <int CW, bool BB>
 void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t sx, int n, int NB,
-               int64_t rstride, int64_t x0, float w, int epi, const XRowMeta *meta = nullptr,
-               const float *Ttab = nullptr, int idx_inf = 0, int flim = 0, int mode = 0) {
+               int64_t rstride, int64_t x0, float w, int epi, const uint16_t *codes = nullptr,
+               float wx = 0.0f, int flim = 0, int mode = 0) {
   constexpr int NBP = 64 / CW;
   using TG = TileGeom<CW>;
   constexpr int TC = TG::kCols;
@@ -97,17 +97,15 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
       }
     }
   }
-  if (meta) {
-    // fused pass 1: every lane rebuilds F for its rows from the row records, then publishes them
-    // in the LDS tile (the kernel does exactly this instead of the HBM fill)
+  if (codes) {
+    // index form of pass 1: the tile is filled from the 16-bit distance indices (edt_colwave_lane.h: code_value;
+    // the kernel does exactly this instead of the HBM -> LDS copy)
     for (auto &P : lanes) {
       float *own = tile + addr_tile<CW>(P.L.colc, P.L.row0);
       for (int r = 0; r < 32; ++r) {
         const int row = P.L.row0 + r;
         float v = 0.0f;
-        if (row < n && P.L.colc < cols_left)
-          v = xpass_value(meta[row], (int)((x0 >> 5) & 1), (int)(x0 & ~63), P.L.colc, Ttab, idx_inf, flim,
-                          (P.L.nzw >> r) & 1u);
+        if (row < n && P.L.colc < cols_left) v = code_value(codes[(int64_t)row * rstride + x0 + P.L.colc], wx, flim);
         P.f[r] = v;
         own[r * TC] = v;
       }
@@ -125,7 +123,7 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
   const int stride = (mode == 4 || mode == 5) ? 2 : 1;
   if (mode == 4) mode = 1;
   if (mode == 5) mode = 2;
-  if (mode != 0 && meta == nullptr) {
+  if (mode != 0) {
     const int want = mode == 3 ? 96 : n;
     bool x32 = brute_exact32(w, want);
     if (mode == 2) x32 = false;
@@ -271,12 +269,10 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
 
 template <int CW>
 void pass_cw(float *F, const uint32_t *nz, const uint32_t *rs, int64_t sx, int n, int NB, int64_t stride,
-             float w, int bb, int epi, const XRowMeta *meta = nullptr, const float *Ttab = nullptr,
-             int idx_inf = 0, int flim = 0, int mode = 0) {
+             float w, int bb, int epi, const uint16_t *codes = nullptr, float wx = 0.0f, int flim = 0, int mode = 0) {
   for (int64_t x0 = 0; x0 < sx; x0 += TileGeom<CW>::kCols) {
-    const XRowMeta *m = meta ? meta + (x0 >> 6) * n : nullptr;  // records are [chunk][row]
-    if (bb) tile_pass<CW, true>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim, mode);
-    else tile_pass<CW, false>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, m, Ttab, idx_inf, flim, mode);
+    if (bb) tile_pass<CW, true>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, codes, wx, flim, mode);
+    else tile_pass<CW, false>(F, nz, rs, sx, n, NB, stride, x0, w, epi & 3, codes, wx, flim, mode);
   }
 }
 
@@ -296,12 +292,12 @@ extern "C" int lane_emul_column_pass_mode(const uint32_t *labels, float *F, int6
       if (lab != 0) nz[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
       if (start) rs[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
     }
-  if (NB <= 2) pass_cw<32>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
-  else if (NB <= 4) pass_cw<16>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
-  else if (NB <= 8) pass_cw<8>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
-  else if (NB <= 16) pass_cw<4>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
-  else if (NB <= 32) pass_cw<2>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
-  else pass_cw<1>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, nullptr, 0, 0, mode);
+  if (NB <= 2) pass_cw<32>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, 0.0f, 0, mode);
+  else if (NB <= 4) pass_cw<16>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, 0.0f, 0, mode);
+  else if (NB <= 8) pass_cw<8>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, 0.0f, 0, mode);
+  else if (NB <= 16) pass_cw<4>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, 0.0f, 0, mode);
+  else if (NB <= 32) pass_cw<2>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, 0.0f, 0, mode);
+  else pass_cw<1>(F, nz.data(), rs.data(), sx, (int)n, NB, sx, w, bb, epi, nullptr, 0.0f, 0, mode);
   return 0;
 }
 
@@ -315,8 +311,7 @@ extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t s
 extern "C" int lane_emul_fused_xy(const uint32_t *labels, float *out, int64_t sx, int64_t n, float wx,
                                   float wy, int bb, int epi) {
   const int NB = (int)((n + 31) / 32);
-  if (NB < 1 || NB > 16 || sx % 4 != 0 || sx > 512) return -1;
-  const int NC = (int)((sx + 63) / 64);
+  if (NB < 1 || NB > 64 || sx + 2 >= (int64_t)kCodeInf) return -1;
   std::vector<uint32_t> nz((size_t)NB * sx, 0), rs((size_t)NB * sx, 0);
   for (int64_t x = 0; x < sx; ++x)
     for (int64_t y = 0; y < n; ++y) {
@@ -325,37 +320,29 @@ extern "C" int lane_emul_fused_xy(const uint32_t *labels, float *out, int64_t sx
       if (lab != 0) nz[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
       if (start) rs[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
     }
-  std::vector<XRowMeta> meta((size_t)NC * n);
-  for (int64_t y = 0; y < n; ++y) {
-    std::vector<uint64_t> M(NC, 0);
-    for (int64_t x = 1; x < sx; ++x)  // voxel 0 never marks itself
-      if (labels[y * sx + x] != labels[y * sx + x - 1]) M[x >> 6] |= 1ull << (x & 63);
-    int last = bb ? 0 : -(1 << 20);
-    std::vector<int> pre(NC), suf(NC);
-    for (int c = 0; c < NC; ++c) {
-      pre[c] = last;
-      if (M[c]) last = c * 64 + 63 - __builtin_clzll(M[c]);
-    }
-    int nxt = bb ? (int)sx : (1 << 20);
-    for (int c = NC - 1; c >= 0; --c) {
-      suf[c] = nxt;
-      if (M[c]) nxt = c * 64 + __builtin_ctzll(M[c]);
-    }
-    for (int c = 0; c < NC; ++c) meta[(size_t)c * n + y] = XRowMeta{(uint32_t)M[c], (uint32_t)(M[c] >> 32), pre[c], suf[c]};
-  }
-  std::vector<float> T((size_t)sx + 3);
-  {
-    float acc = 0.0f;
-    T[0] = 0.0f;
-    for (int64_t k = 1; k <= sx + 1; ++k) { acc = acc + wx; T[k] = acc; }
-    T[sx + 2] = INFINITY;
-  }
+  // pass 1 as distance indices (edt_rowwave.hip, C16): k = min(i - s + 1, e - i + 1) inside the maximal run [s, e] of
+  // one non-zero label, a side without a boundary not counting, ; 0 for background, 0xFFFF for "no boundary at all"
+  std::vector<uint16_t> codes((size_t)sx * n, 0);
   const int idx_inf = (int)sx + 2;
+  for (int64_t y = 0; y < n; ++y) {
+    const uint32_t *row = labels + y * sx;
+    for (int64_t x = 0; x < sx; ++x) {
+      if (row[x] == 0) continue;
+      int64_t s0 = x, e0 = x;
+      while (s0 > 0 && row[s0 - 1] == row[x]) --s0;
+      while (e0 < sx - 1 && row[e0 + 1] == row[x]) ++e0;
+      const int64_t il = (s0 > 0 || bb) ? x - s0 + 1 : idx_inf, ir = (e0 < sx - 1 || bb) ? e0 - x + 1 : idx_inf;
+      const int64_t k = il < ir ? il : ir;
+      codes[(size_t)(y * sx + x)] = (uint16_t)(k < idx_inf ? (uint32_t)k : kCodeInf);
+    }
+  }
   const int flim = bb ? 0x7f800000 : 0x7f7fffff;
   std::fill(out, out + sx * n, -777.0f);
-  if (NB <= 2) pass_cw<32>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, meta.data(), T.data(), idx_inf, flim);
-  else if (NB <= 4) pass_cw<16>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, meta.data(), T.data(), idx_inf, flim);
-  else if (NB <= 8) pass_cw<8>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, meta.data(), T.data(), idx_inf, flim);
-  else pass_cw<4>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, meta.data(), T.data(), idx_inf, flim);
+  if (NB <= 2) pass_cw<32>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, codes.data(), wx, flim);
+  else if (NB <= 4) pass_cw<16>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, codes.data(), wx, flim);
+  else if (NB <= 8) pass_cw<8>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, codes.data(), wx, flim);
+  else if (NB <= 16) pass_cw<4>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, codes.data(), wx, flim);
+  else if (NB <= 32) pass_cw<2>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, codes.data(), wx, flim);
+  else pass_cw<1>(out, nz.data(), rs.data(), sx, (int)n, NB, sx, wy, bb, epi, codes.data(), wx, flim);
   return 0;
 }

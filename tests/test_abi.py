@@ -46,9 +46,14 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.edt_hip_workspace_bytes(99, 3, 4, 4, 4) == 0
     assert lib.edt_hip_workspace_bytes(_lib.U32, 4, 4, 4, 4) == 0
     assert lib.edt_hip_workspace_bytes(_lib.U32, 2, 4, 4, 4) == 0
-    # the wave / tiled kernels work in place: scratch = four bit planes (1/8 byte per voxel each) ...
-    assert 4 * 64 * 64 * 64 // 8 <= lib.edt_hip_workspace_bytes(_lib.U32, 3, 64, 64, 64) <= 4 * 64 * 64 * 64 // 8 + 4096
-    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 1024, 1024, 1024) <= (1 << 29) + 4096   # 0.5 GiB for 1024^3
+    # the wave / tiled kernels work in place: scratch = four bit planes (1/8 byte per voxel each) + the 16-bit
+    # distance indices of pass 1, one slab of at most 2^27 voxels of them (256 MiB) whatever the volume ...
+    v = 64 * 64 * 64
+    assert 4 * v // 8 + 2 * v <= lib.edt_hip_workspace_bytes(_lib.U32, 3, 64, 64, 64) <= 4 * v // 8 + 2 * v + 4096
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 1024, 1024, 1024) <= (1 << 29) + (1 << 28) + 4096   # 0.75 GiB for 1024^3
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 2048, 2048, 512) <= (1 << 30) + (1 << 28) + 4096
+    # (rows that are not whole 8-byte granules of indices keep the fp32 form of pass 1: bit planes only)
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 63, 64, 64) <= 4 * 64 * 64 * 64 // 8 + 4096
     # ... only the size-agnostic kernels need a second fp32 volume and the hull stacks
     assert (lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 64, 64, 64, _lib.FLAG_FORCE_GENERIC)
             >= 2 * 64 * 64 * 64 * 4)

@@ -101,7 +101,44 @@ def test_column_pass_matches_oracle(emul, oracle_port, n, sx, kind, mode):
                 assert np.array_equal(got[1::2], f1[1::2])
 
 
-def fused_xy(lib, labels_yx, wx, wy, bb, epi):
+def codes_exact(w, sx):
+    """mirror of edt_rowwave.hip: row_codes_exact -- k * w is exact in fp32 for every k <= sx + 1"""
+    w = float(np.float32(w))
+    if not (1.0e-30 <= w <= 1.0e30) or sx + 2 >= 0xFFFF:
+        return False
+    m, _ = np.frexp(np.float32(w))
+    m = int(float(m) * 2 ** 24)
+    while m and not m & 1:
+        m >>= 1
+    return m * (sx + 1) < 2 ** 24 and w * (sx + 1) < 3.0e38
+
+
+def test_exactness_criterion_implies_exact_sums():
+    """whenever the criterion holds, the reference's sequential fp32 sums T[k] = fl32(T[k-1] + w) equal k * w"""
+    rng = np.random.default_rng(3)
+    seen = 0
+    for t in range(4000):
+        sx = int(rng.integers(1, 1100))
+        if t % 4 == 0:
+            w = np.float32(rng.integers(1, 40000) * 2.0 ** int(rng.integers(-30, 8)))
+        elif t % 4 == 1:
+            w = np.float32(rng.integers(1, 64) / 8.0)
+        else:
+            w = np.float32(rng.uniform(0.01, 50.0))
+        if not codes_exact(w, sx):
+            continue
+        seen += 1
+        acc = np.float32(0)
+        k = np.arange(sx + 2, dtype=np.float32)
+        sums = np.empty(sx + 2, dtype=np.float32)
+        for i in range(sx + 2):
+            sums[i] = acc
+            acc = np.float32(acc + w)
+        assert np.array_equal(sums, k * w), (w, sx)
+    assert seen > 500
+
+
+def index_form_xy(lib, labels_yx, wx, wy, bb, epi):
     n, sx = labels_yx.shape
     lab = np.ascontiguousarray(labels_yx, dtype=np.uint32)
     out = np.empty((n, sx), dtype=np.float32)
@@ -112,15 +149,18 @@ def fused_xy(lib, labels_yx, wx, wy, bb, epi):
     return out
 
 
-@pytest.mark.parametrize("n,sx,kind", CASES)
-def test_fused_xy_matches_oracle(emul, oracle_port, n, sx, kind):
-    """Pass 1 rebuilt inside the column pass from the per-row run records (no pass-1 buffer)."""
-    if n > 512 or sx % 4:
-        pytest.skip("the fused path covers axes up to 512 rows and x extents that are multiples of 4")
+@pytest.mark.parametrize("n,sx,kind", CASES + [(40, 1000, "blocky"), (33, 1024, "membrane"), (8, 1021, "ones")])
+def test_index_form_of_pass_1_matches_oracle(emul, oracle_port, n, sx, kind):
+    """Pass 1 handed over as 16-bit distance indices and rebuilt while the column pass fills its tile
+    (edt_colwave_lane.h: code_value) -- for voxel sizes whose multiples are exact in fp32."""
+    if kind == "ones" and n > 600:
+        pytest.skip("whole-axis hulls in the host emulation: covered by the column-pass test")
     rng = np.random.default_rng(n * 1000 + sx + 7)
     lab = make_labels(n, sx, kind, rng)
-    for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (0.7, 1.3)):
+    for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (0.375, 1.3), (16383.0, 2.0), (2.0 ** -20, 2.0 ** -19)):
+        if not codes_exact(wx, sx):
+            continue  # (the library keeps the fp32 form of pass 1 for such voxel sizes)
         for bb in (True, False):
             want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
-            got = fused_xy(emul, lab, wx, wy, bb, 0 if bb else 1)
+            got = index_form_xy(emul, lab, wx, wy, bb, 0 if bb else 1)
             assert np.array_equal(got, want), (n, sx, kind, wx, wy, bb)

@@ -985,10 +985,14 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
     aligned = aligned && (reinterpret_cast<uintptr_t>(blk) % 16) == 0;
   }
   if (!aligned && (sx % 4) == 0) { set_error("destination blocks must be 16-byte aligned"); return EDT_ERR_BAD_ARG; }
+  // (index form of pass 1 where the voxel size allows it, see run_device: the slab's pass-1 buffer then holds 16-bit
+  // indices in its first half)
+  const bool index_form = (sx % 4) == 0 && !(g_debug_mode & 0x100000) && row_codes_exact(wx, sx);
+  uint16_t *codes = index_form ? reinterpret_cast<uint16_t *>(p.F) : nullptr;
   {
     ScopedPass t("x_pass", stream);
     rc = launch_row_pass_wave(dtype, d_labels, p.F, p.nz_y, p.ys_y, p.zs_y, sx, sy, sz_local, wx, bb,
-                              bb ? 0 : 1, stream, d_halo);
+                              bb ? 0 : 1, stream, d_halo, codes);
     if (rc != EDT_OK) return rc;
   }
   {
@@ -997,6 +1001,8 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
     if (rc != EDT_OK) return rc;
   }
   ScopedPass t("y_pass", stream);
+  if (index_form)
+    return launch_column_pass_wave_codes(p.F, codes, p.nz_y, p.ys_y, gy, wy, bb, 0, wx, bb ? 0 : 1, stream, p.table);
   return launch_column_pass_wave(p.F, p.nz_y, p.ys_y, gy, wy, bb, 0, stream, p.table);
 }
 

@@ -565,11 +565,9 @@ template <int CW, bool BB, bool XF>
 static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
                            bool scatter_aligned, int out_stride) {
-  // the scattering epilogue (Z-sharded path) is a compile-time variant of the unfused kernel
-  if constexpr (!XF) {
-    if (scatter != nullptr)
-      return launch_wave_cbx_sc<CW, BB, false, true>(F, nz, rs, g, w, epi, xf, stream, scatter, scatter_aligned, out_stride);
-  }
+  // the scattering epilogue (Z-sharded path) is a compile-time variant
+  if (scatter != nullptr)
+    return launch_wave_cbx_sc<CW, BB, XF, true>(F, nz, rs, g, w, epi, xf, stream, scatter, scatter_aligned, out_stride);
   return launch_wave_cbx_sc<CW, BB, XF, false>(F, nz, rs, g, w, epi, xf, stream, nullptr, false, out_stride);
 }
 

@@ -112,7 +112,7 @@ int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, co
 // the same reading pass 1 as 16-bit distance indices (F is write-only): see XFuse
 int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_t *nz, const uint32_t *rs,
                                   const AxisGeom &g, float w, int bb, int epi, float wx, int to_finite,
-                                  hipStream_t stream);
+                                  hipStream_t stream, const BandScatter *scatter = nullptr);
 }  // namespace edt_amd
 
 namespace edt_amd {

@@ -16,9 +16,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 def scan(cw, workdir):
     src = os.path.join(CSRC, f"edt_colwave_cw{cw}.hip")
-    subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-c", "-o", os.path.join(workdir, f"cw{cw}.o"), src,
-                    "--save-temps=obj"], check=True, capture_output=True, cwd=workdir)
-    asm = open(os.path.join(workdir, f"edt_colwave_cw{cw}-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    out_s = os.path.join(workdir, f"cw{cw}.s")
+    subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-S", "--cuda-device-only", "-o", out_s, src],
+                   check=True, capture_output=True, cwd=workdir)
+    asm = open(out_s).read()
     out = []
     for m in re.finditer(r"^(_ZN\w+):\s*; @", asm, re.M):
         end = asm.index(".Lfunc_end", m.start())

@@ -17,6 +17,8 @@ for cfg in cfg2 cfg3; do
   done
   python tools/pmc_summary.py r02$cfg > gpurun_out/pmc_r02${cfg}_summary.txt
 done
+python tools/traffic_from_pmc.py r02
+if [ -z "$SKIP_CAL" ]; then  # (the calibration does not depend on the library: once per round)
 i=0
 for ctrs in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
   i=$((i+1))
@@ -25,6 +27,7 @@ for ctrs in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
 done
 python tools/pmc_summary.py r02cal > gpurun_out/pmc_r02cal_summary.txt
 cat gpurun_out/pmc_r02cal_summary.txt
+fi
 python bench.py > gpurun_out/bench_r02.json 2> gpurun_out/bench_r02.err
 python - <<'PY'
 import json

@@ -10,13 +10,13 @@ namespace edt_amd {
 
 template <int CW>
 int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w, int bb, int epi,
-                  const XFuse *xf, hipStream_t stream, const BandScatter *scatter, bool sc_al, int out_stride);
-extern template int launch_wave_c<32>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
-extern template int launch_wave_c<16>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
-extern template int launch_wave_c<8>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
-extern template int launch_wave_c<4>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
-extern template int launch_wave_c<2>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
-extern template int launch_wave_c<1>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, int);
+                  const XFuse *xf, hipStream_t stream, const BandScatter *scatter, bool sc_al, const ColumnOut &out_stride);
+extern template int launch_wave_c<32>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
+extern template int launch_wave_c<16>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
+extern template int launch_wave_c<8>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
+extern template int launch_wave_c<4>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
+extern template int launch_wave_c<2>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
+extern template int launch_wave_c<1>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
 
 // Largest window of the windowed path (edt_colwave_lane.h: brute_band): a tile takes it when no row can be
 // improved by a row further than this away.  EDT_HIP_WINDOW_LIMIT overrides the default (experiments).
@@ -36,7 +36,7 @@ bool column_pass_wave_supported(const AxisGeom &g) {
 
 static int launch_wave_any(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int bb, int epi, const XFuse *xf, hipStream_t stream,
-                           const BandScatter *sc = nullptr, bool sc_al = false, int out_stride = 1) {
+                           const BandScatter *sc = nullptr, bool sc_al = false, const ColumnOut &out_stride = ColumnOut()) {
   const int64_t NB = g.nbands;
   if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
   if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
@@ -49,7 +49,7 @@ static int launch_wave_any(float *F, const uint32_t *nz, const uint32_t *rs, con
 }
 
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                            float w, int bb, int epi, hipStream_t stream, const BandScatter *scatter, int out_stride) {
+                            float w, int bb, int epi, hipStream_t stream, const BandScatter *scatter, const ColumnOut &out_stride) {
   // (the caller of the scattering variant guarantees 16-byte aligned destinations when sx % 4 == 0)
   return launch_wave_any(F, nz, rs, g, w, bb, epi, nullptr, stream, scatter, scatter != nullptr, out_stride);
 }

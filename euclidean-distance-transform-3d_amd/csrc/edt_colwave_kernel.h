@@ -53,6 +53,11 @@ struct BruteArgs {
   int x32;              // candidates are fp32 sums (c_d exactly representable up to the limit)
   int force;            // diagnostics: every tile takes the path
   int stride;           // 1: every row is evaluated; 2: only the even rows are (and written), see BruteSteps
+  // stride 2 only, or nullptr: the even rows leave for a compact array instead of their places in F --
+  // row r of column (x, outer o) -> compact[x + o * c_outer + (r / 2) * c_row2]   (edt_kernels.h: ColumnOut)
+  float *compact;
+  int64_t c_outer, c_row2;
+  int c_al;             // its rows are whole 16-byte granules
 };
 int window_limit();  // edt_colwave.hip: largest window (rows) the windowed path is used for
 
@@ -143,8 +148,10 @@ __device__ EDT_BRUTE_INLINE void brute_tile(float *tile, const uint32_t *alive, 
   const bool colok = col < cols_left;
   // (a pointer that crosses a call is generic: say that it is global memory, or the rows leave through flat stores)
   auto *gdst = (__attribute__((address_space(1))) float *)dst0;
+  // (bit 10 of epi: dstride is the distance between EVEN rows of a compact destination)
+  const bool compact = (epi & 0x400) != 0;
   auto store = [&](int row, float v) {
-    if (row < n && colok) gdst[(int64_t)row * dstride] = v;
+    if (row < n && colok) gdst[(int64_t)(compact ? row >> 1 : row) * dstride] = v;
   };
   // (bit 8 of epi: only the even rows are evaluated and written -- the doubled grids of the voxel-graph transform;
   // carried in an existing argument: the kernel around this call is sensitive to its signature, see hull path)
@@ -449,16 +456,23 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         // (its own function: the windowed path and the hull path each get a register allocation of their own)
         const int band2 = wave * (64 / TC) + lane / TC, col2 = lane % TC;
         float *dst0;  // row 0 of the column this lane writes
+        int64_t dstep = st;
+        bool compact = false;
         if constexpr (SC) {
           const int b = band2 < BandScatter::kBands ? band2 : 0;
           dst0 = scatter->rows[b] + o * scatter->ostride[b] + x0 + col2 - (int64_t)band2 * 32 * st;
         } else {
           dst0 = Ftile + col2;
+          if (ba.compact != nullptr) {  // (wave-uniform: kernel argument)
+            dst0 = ba.compact + x0 + col2 + o * ba.c_outer;
+            dstep = ba.c_row2;
+            compact = true;
+          }
         }
         // (bit 9, diagnostics: debug bit 0x80000 = no window at all, i.e. the fixed cost of the path; wrong results)
-        const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | ((dbg & 0x80000) ? 0x200 : 0);
-        if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, st);
-        else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, st);
+        const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | ((dbg & 0x80000) ? 0x200 : 0) | (compact ? 0x400 : 0);
+        if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
+        else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
         return;
       }
     }
@@ -490,6 +504,21 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         }
       }
     }
+  } else if (ba.compact != nullptr) {
+    // only the even rows are read again, from a compact array (ColumnOut): float by float, the destination
+    // rows need not be 16-byte aligned
+    float *cdst = ba.compact + x0 + o * ba.c_outer;
+    if (IO::kGran == 4 && aligned16 && ba.c_al) {
+      for (int i = wave; i < IO::count(NBP, 4); i += W) {
+        const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
+        if (row < n && !(row & 1) && gc < cols_left)
+          *reinterpret_cast<v4f *>(cdst + (int64_t)(row >> 1) * ba.c_row2 + gc) = *reinterpret_cast<const v4f *>(tile + io_lds_word<CW, 4>(i, lane));
+      }
+    } else
+    for (int i = wave; i < IO::count(NBP, 1); i += W) {
+      const int row = io_row<CW, 1>(i, lane), gc = io_gcol<CW, 1>(i, lane);
+      if (row < n && !(row & 1) && gc < cols_left) cdst[(int64_t)(row >> 1) * ba.c_row2 + gc] = tile[io_lds_word<CW, 1>(i, lane)];
+    }
   } else if (IO::kGran == 4 && aligned16) {
     for (int i = wave; i < IO::count(NBP, 4); i += W) {
       const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
@@ -512,7 +541,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 template <int CW, bool BB, bool XF, bool SC>
 static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
-                           bool scatter_aligned, int out_stride) {
+                           bool scatter_aligned, const ColumnOut &out_stride) {
   constexpr int NBP = 64 / CW;
   using TG = edt_lane::TileGeom<CW>;
   constexpr int TC = TG::kCols;
@@ -522,7 +551,12 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   ba.limit_bits = 0u;
   ba.x32 = 0;
   ba.force = 0;
-  ba.stride = (out_stride == 2 && !(debug_mode() & 0x40000)) ? 2 : 1;  // (debug bit 0x40000: evaluate every row)
+  ba.stride = (out_stride.stride == 2 && !(debug_mode() & 0x40000)) ? 2 : 1;  // (debug bit 0x40000: evaluate every row)
+  ba.compact = (out_stride.stride == 2 && !SC) ? out_stride.compact : nullptr;
+  ba.c_outer = out_stride.outer;
+  ba.c_row2 = out_stride.row2;
+  ba.c_al = (reinterpret_cast<uintptr_t>(out_stride.compact) % 16) == 0 && (out_stride.outer % 4) == 0 && (out_stride.row2 % 4) == 0;
+  if (ba.compact != nullptr) ba.stride = 2;  // (a compact destination has room for the even rows only)
   if (!(debug_mode() & 0x2000) && w * w >= 1.17549435e-38f && (double)w * (double)w < 1.0e30) {
     const bool force = (debug_mode() & 0x4000) != 0;
     // The window limit: tools/window_sweep.py (smooth Voronoi cells of growing size, 512^3) puts the
@@ -564,7 +598,7 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
 template <int CW, bool BB, bool XF>
 static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
-                           bool scatter_aligned, int out_stride) {
+                           bool scatter_aligned, const ColumnOut &out_stride) {
   // the scattering epilogue (Z-sharded path) is a compile-time variant
   if (scatter != nullptr)
     return launch_wave_cbx_sc<CW, BB, XF, true>(F, nz, rs, g, w, epi, xf, stream, scatter, scatter_aligned, out_stride);
@@ -574,7 +608,7 @@ static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, con
 template <int CW>
 int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                          int bb, int epi, const XFuse *xf, hipStream_t stream, const BandScatter *scatter,
-                         bool sc_al, int out_stride) {
+                         bool sc_al, const ColumnOut &out_stride) {
   // the border rule and the index form of pass 1 are compile-time variants, the epilogue a run-time one
   const XFuse none = {nullptr, 0.0f, 0};
   if (xf)

@@ -103,12 +103,20 @@ struct XFuse {
 };
 // ---- wave-autonomous LDS-tiled column pass: edt_colwave.hip -----------------------------------
 bool column_pass_wave_supported(const AxisGeom &g);
+// Which rows of a column the caller reads again, and where they go (the doubled grids of the voxel-graph transform).
+struct ColumnOut {
+  int stride = 1;            // 2: only the even rows of every column are needed (tiles on the windowed path evaluate
+                             // just those; tiles on the hull path evaluate every row)
+  float *compact = nullptr;  // stride 2 only: the even rows are written HERE instead of in place -- row r of the
+                             // column (x, outer index o) goes to compact[x + o * outer + (r / 2) * row2]
+  int64_t outer = 0, row2 = 0;
+};
 // scatter != nullptr (device table): the rows are written to the slab records instead of F
-// out_stride = 2: only the even rows of every column are needed (tiles on the windowed path evaluate and write
+// out: see ColumnOut (default: every row, in place) -- (tiles on the windowed path evaluate and write
 // just those; tiles on the hull path still write every row)
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                             float w, int bb, int epi, hipStream_t stream,
-                            const BandScatter *scatter = nullptr, int out_stride = 1);
+                            const BandScatter *scatter = nullptr, const ColumnOut &out = ColumnOut());
 // the same reading pass 1 as 16-bit distance indices (F is write-only): see XFuse
 int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_t *nz, const uint32_t *rs,
                                   const AxisGeom &g, float w, int bb, int epi, float wx, int to_finite,

@@ -441,6 +441,8 @@ size_t vg_native_workspace_bytes(int ndim, int64_t sx, int64_t sy, int64_t sz) {
   return b + 256;
 }
 
+static bool g_vg_debug_gather() { return (debug_mode() & 0x200000) != 0; }
+
 template <typename T>
 static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int64_t sx, int64_t sy, int64_t sz,
                        float wx, float wy, float wz, int bb, int want_sqrt, float *out, void *ws, hipStream_t stream) {
@@ -482,8 +484,16 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
   const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0);
   AxisGeom gy;
   gy.sx = sx; gy.n = Y2; gy.stride = sx; gy.nouter = Z2; gy.outer_stride = sx * Y2; gy.nbands = nbY;
-  // (only the even rows of the doubled columns are read again: by the z pass / the gather)
-  int rc = launch_column_pass_wave(F1, nzY, rsY, gy, hy, bb, ndim == 2 ? last_epi : 0, stream, nullptr, 2);
+  // Only the even rows of the doubled columns are read again: by the z pass (in place), or -- last pass -- by the
+  // caller, whose array the column kernel writes them to directly (ColumnOut: no gather pass)
+  ColumnOut even;
+  even.stride = 2;
+  ColumnOut last = even;
+  last.compact = out;
+  last.outer = ndim == 3 ? sx : 0;          // 3-D: outer index of the z pass = y
+  last.row2 = ndim == 3 ? sx * sy : sx;     // two doubled rows = one voxel slice / one voxel row
+  if (g_vg_debug_gather()) last = even;     // (diagnostics: debug bit 0x200000 keeps the separate gather pass)
+  int rc = launch_column_pass_wave(F1, nzY, rsY, gy, hy, bb, ndim == 2 ? last_epi : 0, stream, nullptr, ndim == 2 ? last : even);
   if (rc != EDT_OK) return rc;
   if (ndim == 3) {
     const int64_t total = sx * nbZ * sy;
@@ -494,9 +504,10 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
     EDT_HIP_TRY(hipGetLastError());
     AxisGeom gz;  // the even rows only: outer index = y, two doubled rows apart
     gz.sx = sx; gz.n = Z2; gz.stride = sx * Y2; gz.nouter = sy; gz.outer_stride = 2 * sx; gz.nbands = nbZ;
-    rc = launch_column_pass_wave(F1, nzZ, rsZ, gz, hz, bb, last_epi, stream, nullptr, 2);
+    rc = launch_column_pass_wave(F1, nzZ, rsZ, gz, hz, bb, last_epi, stream, nullptr, last);
     if (rc != EDT_OK) return rc;
   }
+  if (last.compact != nullptr) return EDT_OK;
   const int64_t nz_out = ndim == 3 ? sz : 1;
   if (sx % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) {
     int64_t blocks = ceil_div(sx / 4 * sy * nz_out, 256);

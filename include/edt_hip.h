@@ -133,10 +133,12 @@ int edt_hip_release_cache(void);
  * allocation), so they can be timed with events and captured into a hipGraph.
  */
 
-/* bytes of scratch edt_hip_edtsq_device needs for a volume of this shape: the bit planes of the column
- * passes (5/32 of a byte per voxel and plane -- about 0.16 GiB for 1024^3).  Only a call that has to use
- * the size-agnostic column kernels (an axis longer than 4095 voxels, or EDT_FLAG_FORCE_GENERIC) needs a
- * second fp32 volume and the hull stacks as well (+ 8 bytes per voxel): ask with the flags of the call. */
+/* bytes of scratch edt_hip_edtsq_device needs for a volume of this shape: the four bit planes of the column
+ * passes (1/8 of a byte per voxel each: 0.5 GiB for 1024^3) plus one slab of 16-bit distance indices between
+ * passes X and Y (2 bytes per voxel, never more than 256 MiB: larger volumes run those passes slab by slab).
+ * Only a call that has to use the size-agnostic column kernels (an axis longer than 4095 voxels, or
+ * EDT_FLAG_FORCE_GENERIC) needs a second fp32 volume and the hull stacks as well (+ 8 bytes per voxel): ask
+ * with the flags of the call. */
 size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz);
 size_t edt_hip_workspace_bytes_flags(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags);
 
@@ -226,8 +228,10 @@ int edt_hip_is_background_device(const void *d_labels, int dtype, uint8_t *d_mas
 
 /* pyedt::_edt2dsq_voxel_graph / _edt3dsq_voxel_graph (src/edt_voxel_graph.hpp:54-117, :120-214) on
  * device-resident data: labels, graph (one byte per voxel, bits as in the host entry points above) and
- * output live in HBM; enqueue-only on `stream`.  Scratch: edt_hip_voxel_graph_workspace_bytes (it holds the
- * 2x uint8 volume, its fp32 transform and the ordinary workspace of that volume). */
+ * output live in HBM; enqueue-only on `stream`.  Scratch: edt_hip_voxel_graph_workspace_bytes (native form: the
+ * even-x cells of the doubled grid as fp32, 4 x voxels floats, and the bit planes of its two column passes; the
+ * up-sampled fallback for doubled axes beyond 2048 rows: the 2x uint8 volume, its fp32 transform and the
+ * ordinary workspace of that volume). */
 size_t edt_hip_voxel_graph_workspace_bytes(int ndim, int64_t sx, int64_t sy, int64_t sz);
 int edt_hip_edtsq_voxel_graph_device(const void *d_labels, int dtype, const uint8_t *d_graph, int ndim,
                                      int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,

@@ -306,9 +306,9 @@ extern "C" int lane_emul_column_pass(const uint32_t *labels, float *F, int64_t s
   return lane_emul_column_pass_mode(labels, F, sx, n, w, bb, epi, 0);
 }
 
-// Fused passes 1+2 on a 2-D image: labels [n][sx] uint32 -> out [n][sx] fp32 (no pass-1 buffer at all).
-// The per-row records are built here the way the bit kernel builds them.
-extern "C" int lane_emul_fused_xy(const uint32_t *labels, float *out, int64_t sx, int64_t n, float wx,
+// Passes 1+2 on a 2-D image with pass 1 in its index form: labels [n][sx] uint32 -> 16-bit distance indices (built here
+// the way k_row_pass_wave<..., C16> builds them) -> out [n][sx] fp32 through the tile fill of the XF column kernel.
+extern "C" int lane_emul_index_form_xy(const uint32_t *labels, float *out, int64_t sx, int64_t n, float wx,
                                   float wy, int bb, int epi) {
   const int NB = (int)((n + 31) / 32);
   if (NB < 1 || NB > 64 || sx + 2 >= (int64_t)kCodeInf) return -1;

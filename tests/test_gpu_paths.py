@@ -2,7 +2,8 @@
 
 1. Every column / row kernel variant against the oracle on the same inputs: the default path
    (register-resident pass 1 + wave-autonomous column pass), the workgroup-phased LDS kernels
-   (debug bit 64 / 32), the fused X+Y path (bit 128) and the size-agnostic fallback.
+   (debug bit 64 / 32), the fp32 form of pass 1 (bit 0x100000: no 16-bit indices between passes X and Y) and the
+   size-agnostic fallback.
 2. The two shard phases (edt_hip_shard_xy_device / edt_hip_shard_z_device) driven as VIRTUAL ranks
    on one device: slabs, one-slice label halo, Z-slab -> Y-slab re-partition (done with plain tensor
    slicing here; torch.distributed does it across GPUs), compared with the oracle on the whole volume.
@@ -25,7 +26,7 @@ SHAPES = [(512, 40, 36), (256, 96, 20), (100, 130, 70), (64, 64, 64), (36, 500, 
 
 
 @pytest.mark.parametrize("mode,name", [(0, "default"), (64, "phased-column"), (32, "lds-row"),
-                                        (96, "phased-both"), (128, "fused-xy")])
+                                        (96, "phased-both"), (0x100000, "fp32-pass-1")])
 def test_kernel_families_agree_with_the_oracle(edt_gpu, oracle_port, mode, name):
     from edt import _lib
     lib = _lib.load()

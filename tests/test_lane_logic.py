@@ -142,7 +142,7 @@ def index_form_xy(lib, labels_yx, wx, wy, bb, epi):
     n, sx = labels_yx.shape
     lab = np.ascontiguousarray(labels_yx, dtype=np.uint32)
     out = np.empty((n, sx), dtype=np.float32)
-    rc = lib.lane_emul_fused_xy(lab.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+    rc = lib.lane_emul_index_form_xy(lab.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
                                 ctypes.c_int64(sx), ctypes.c_int64(n), ctypes.c_float(wx), ctypes.c_float(wy),
                                 ctypes.c_int(int(bb)), ctypes.c_int(epi))
     assert rc == 0

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 # voxel sizes along x: exact multiples up to the row length (index form), just not (fp32 form), tiny, squares that overflow
 WX = [16381.0, 16383.0, 2.0 ** -60, 3.0 * 2.0 ** 40, 1.0e19, 0.7, 0.375]
-SHAPES = [(1024, 40, 3), (1000, 33, 2), (516, 70, 5), (130, 64, 9), (64, 300, 4), (8, 8, 1100), (512, 96)]
+SHAPES = [(1024, 40, 3), (1000, 33, 2), (516, 70, 5), (130, 64, 9), (64, 300, 4), (8, 8, 1100), (512, 96),
+          (8, 12, 4200), (16, 2100, 3)]  # (z beyond the in-place kernels: index form + ping-pong z pass; y beyond the wave kernel)
 
 
 def _labels(shape, kind, rng):

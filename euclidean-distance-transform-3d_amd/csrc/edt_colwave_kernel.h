@@ -19,13 +19,17 @@
 //   lane      = (column c, band b): its 32 rows live in VGPRs for the whole kernel.
 // The tile is read from HBM exactly once and written exactly once (8 B/voxel of traffic
 // against 12 B/voxel in the reference's data-movement model, which re-reads the labels).
+// Two forms per tile after the fill: hulls (hull_tile) or, where the field is small everywhere, a branch-free
+// window over the rows (brute_tile).  Variants: XF -- the FIRST column pass reads pass 1 as 16-bit distance indices
+// (6 B/voxel) and turns them into the fp32 tile through VGPRs (edt_colwave_lane.h: code_value); SC -- the rows leave
+// for the slab records of a Z-sharded run instead of their places in F.
 //
 // LDS image: fp32 tile [rows][32], the columns of a wave XOR-rotated by CW columns per band
 // (edt_colwave_lane.h: addr_tile) so that "every lane reads its own row" is bank-conflict free;
 // because global_load_lds writes LDS linearly (lane i -> base + 16*i, or 4*i for the 2-column waves
 // of 1024-row axes and for rows that are not 16-byte aligned), the rotation is applied to the
 // per-lane SOURCE address, and again when the results are streamed back.
-// Axes: up to 1024 rows (NBP = 2..32 bands per column, CW = 32..2 columns per wave).
+// Axes: up to 2048 rows (NBP = 2..64 bands per column, CW = 32..1 columns per wave; 16-column tiles for CW <= 2).
 #include "edt_common.h"
 #include "edt_kernels.h"
 

@@ -390,8 +390,8 @@ def _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=512, help="edge length of the per-GPU volume")
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg3m", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

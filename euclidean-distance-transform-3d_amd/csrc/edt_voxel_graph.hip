@@ -171,9 +171,12 @@ __global__ void k_vg_ttab(float *__restrict__ ttab, float w, int count) {
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const float *__restrict__ ttab,
-          float *__restrict__ F1, int sx, int sy, int sz, int Y2, int Z2, int bb, int idx_inf) {
+          float *__restrict__ F1, int sx, int sy, int sz, int Y2, int Z2, int bb, int idx_inf, float exact_w) {
   extern __shared__ float Tl[];
-  for (int i = (int)threadIdx.x; i <= idx_inf; i += (int)blockDim.x) Tl[i] = ttab[i];
+  // (exact_w > 0: every multiple of the half voxel size is exact in fp32 -- row_codes_exact --, so the sequential sums
+  // ARE the multiples and no table kernel ran)
+  for (int i = (int)threadIdx.x; i <= idx_inf; i += (int)blockDim.x)
+    Tl[i] = exact_w > 0.0f ? (i < idx_inf ? (float)i * exact_w : INFINITY) : ttab[i];
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   const int NC = (sx + 63) >> 6;  // <= 32 (launcher)
@@ -463,7 +466,8 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
   const int idx_inf = (int)(2 * sx + 2);
   // half voxel size on the doubled grid (src/edt_voxel_graph.hpp:96-101, :189-193)
   const float hx = wx / 2, hy = wy / 2, hz = wz / 2;
-  hipLaunchKernelGGL(k_vg_ttab, dim3(1), dim3(64), 0, stream, ttab, hx, idx_inf);
+  const bool exact = row_codes_exact(hx, idx_inf);  // k * hx exact for every index of the table
+  if (!exact) hipLaunchKernelGGL(k_vg_ttab, dim3(1), dim3(64), 0, stream, ttab, hx, idx_inf);
   {
     const int64_t nvrows = sy * (ndim == 3 ? sz : 1);  // one wave per voxel row (its 2 or 4 doubled rows)
     int64_t blocks = ceil_div(nvrows, 4);
@@ -471,7 +475,7 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
     static std::atomic<uint64_t> attr_done{0};
     EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_vg_rows<T>)));
     hipLaunchKernelGGL(k_vg_rows<T>, dim3((unsigned)blocks), dim3(256), (size_t)(idx_inf + 1) * sizeof(float), stream,
-                       labels, graph, ttab, F1, (int)sx, (int)sy, (int)sz, (int)Y2, (int)Z2, bb, idx_inf);
+                       labels, graph, ttab, F1, (int)sx, (int)sy, (int)sz, (int)Y2, (int)Z2, bb, idx_inf, exact ? hx : 0.0f);
   }
   {
     const int64_t total = sx * nbY * (ndim == 3 ? sz : 1);  // one thread per word of slice 2z AND of slice 2z+1

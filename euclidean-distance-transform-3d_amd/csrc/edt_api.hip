@@ -139,7 +139,7 @@ constexpr int64_t kCodeSlabVoxels = (int64_t)1 << 27;
 constexpr int EDT_FLAG_NO_INDEX_FORM = 0x8000;  // internal: plan without the index buffer
 static bool env_force_generic();
 static int64_t plan_code_slab(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
-  if (ndim < 2 || sx % 4 != 0 || sx * sy > kCodeSlabVoxels || (flags & EDT_FLAG_NO_INDEX_FORM)) return 0;
+  if (ndim < 2 || sx % 4 != 0 || sx * sy > kCodeSlabVoxels || (flags & (EDT_FLAG_NO_INDEX_FORM | EDT_FLAG_SMALL_WORKSPACE))) return 0;
   if ((flags & EDT_FLAG_FORCE_GENERIC) || env_force_generic() || (g_debug_mode & (0x100000 | 64 | 32))) return 0;
   if (!row_pass_wave_supported(dtype, sx, sy, sz) || !column_pass_wave_supported(make_geom_y(sx, sy, sz))) return 0;
   const int64_t slab = kCodeSlabVoxels / (sx * sy);

@@ -21,6 +21,7 @@ FLAG_BLACK_BORDER = 1
 FLAG_SQRT = 2
 FLAG_FORCE_GENERIC = 4
 FLAG_BATCH_2D = 8
+FLAG_SMALL_WORKSPACE = 16
 
 OK = 0
 ERR_NO_DEVICE = -1

@@ -42,14 +42,17 @@ def _stream_ptr() -> ctypes.c_void_p:
 class Plan:
     """Pre-sized scratch for volumes of one shape/dtype (x-fastest extents ``(sx, sy, sz)``)."""
 
-    def __init__(self, extents_xyz, code: int, device=None):
+    def __init__(self, extents_xyz, code: int, device=None, small_workspace=False):
+        """small_workspace: scratch = the four bit planes only (EDT_FLAG_SMALL_WORKSPACE: passes X and Y exchange
+        fp32 values instead of 16-bit distance indices -- no index slab of up to 256 MiB, a few per cent slower)"""
         self.lib = _lib.load()
         ext = tuple(int(e) for e in extents_xyz)
         self.ndim = len(ext)
         self.ext = ext + (1,) * (3 - self.ndim)
         self.code = code
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-        nbytes = self.lib.edt_hip_workspace_bytes(code, self.ndim, *self.ext)
+        self.base_flags = _lib.FLAG_SMALL_WORKSPACE if small_workspace else 0
+        nbytes = self.lib.edt_hip_workspace_bytes_flags(code, self.ndim, *self.ext, self.base_flags)
         if nbytes == 0:
             _lib.check(-2)
         self.workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
@@ -80,7 +83,7 @@ class Plan:
         w = tuple(float(np.float32(v)) for v in weights_xyz) + (1.0,) * (3 - self.ndim)
         flags = ((_lib.FLAG_BLACK_BORDER if black_border else 0) | (_lib.FLAG_SQRT if sqrt else 0)
                  | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
-                 | (_lib.FLAG_BATCH_2D if batch2d else 0))
+                 | (_lib.FLAG_BATCH_2D if batch2d else 0) | self.base_flags)
         ws = self._workspace_for(flags)
         rc = self.lib.edt_hip_edtsq_device(
             ctypes.c_void_p(labels.data_ptr()), self.code, self.ndim, *self.ext, w[0], w[1], w[2],

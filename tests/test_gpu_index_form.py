@@ -66,6 +66,10 @@ def test_workspace_sized_without_the_index_buffer_still_serves(edt_gpu, oracle_p
         lib.edt_hip_set_debug_mode(0)
     got = small_plan.run(t, (6.0, 6.0, 30.0), black_border=False).cpu().numpy().T
     assert np.array_equal(got, want)
+    lean_plan = device.Plan(shape, _lib.U32, small_workspace=True)  # the public way to decline the index buffer
+    assert lean_plan.workspace.numel() == small_plan.workspace.numel()
+    got = lean_plan.run(t, (6.0, 6.0, 30.0), black_border=False).cpu().numpy().T
+    assert np.array_equal(got, want)
     big_plan = device.Plan(shape, _lib.U32)
     assert big_plan.workspace.numel() == full
     got = big_plan.run(t, (6.0, 6.0, 30.0), black_border=False).cpu().numpy().T

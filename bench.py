@@ -185,6 +185,29 @@ class DeviceRun:
         }, kernels, bpv
 
 
+def voxel_graph_secondary(n, dev, steps, warmup):
+    """BASELINE configs[4]: the voxel-connectivity-graph transform of an n^3 uint8 blob volume (1 % of the +x links
+    cut), device-resident.  Full-size parity of this path: tests/test_gpu_voxel_graph.py."""
+    from edt import device
+    rng = np.random.default_rng(5)
+    small = (rng.random((n // 16,) * 3) < 0.6).astype(np.uint8)
+    lab = torch.from_numpy(np.ascontiguousarray(small.repeat(16, 0).repeat(16, 1).repeat(16, 2))).to(dev)
+    g = torch.full((n, n, n), 0b00111111, dtype=torch.uint8, device=dev)
+    g[torch.rand((n, n, n), device=dev) < 0.01] = 0b00111110
+    an = (30.0, 6.0, 6.0)  # (z, y, x)
+    for _ in range(max(2, warmup // 4)):
+        device.edtsq_voxel_graph(lab, g, anisotropy=an, black_border=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        device.edtsq_voxel_graph(lab, g, anisotropy=an, black_border=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"config": "cfg5", "workload": f"{n}^3 uint8 blobs + voxel graph (1 % of the +x links cut), anisotropy (6, 6, 30), "
+                                          "black_border=True, device-resident in/out, 1 GPU",
+            "ms_per_step": round(ms, 4), "mvox_per_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1), "output_verified": None}
+
+
 # ------------------------------------------------------------------------------------------
 # the N > 1 leg: one process per GPU, the volume Z-sharded (edt/distributed.py)
 # ------------------------------------------------------------------------------------------
@@ -488,6 +511,10 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # pragma: no cover  (a secondary must never take the headline down)
                 secondary.append({"config": name, "error": repr(e)})
+        try:
+            secondary.append(voxel_graph_secondary(n, dev, max(5, args.steps // 4), args.warmup))
+        except Exception as e:  # pragma: no cover
+            secondary.append({"config": "cfg5", "error": repr(e)})
 
     result = {
         "metric": "Mvox/s edt3dsq 512^3 uint32", "value": summary["mvox_per_s"], "unit": "Mvox/s",

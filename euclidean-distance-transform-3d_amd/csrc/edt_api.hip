@@ -690,6 +690,8 @@ int edt_hip_device_count(void) {
 
 const char *edt_hip_last_error(void) { return g_last_error.c_str(); }
 
+int edt_hip_index_form_exact(float wx, int64_t sx) { return (sx >= 1 && row_codes_exact(wx, sx)) ? 1 : 0; }
+
 const char *edt_hip_version(void) { return "edt_hip 0.1 (gfx950)"; }
 
 int edt_hip_squared_edt_1d_multi_seg(const void *labels, int dtype, float *dest, int64_t n,

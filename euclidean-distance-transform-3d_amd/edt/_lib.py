@@ -56,6 +56,7 @@ SIGNATURES = {
     "edt_hip_sdf": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp]),
     "edt_hip_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i64]),
     "edt_hip_workspace_bytes_flags": (_sz, [_i, _i, _i64, _i64, _i64, _i]),
+    "edt_hip_index_form_exact": (_i, [_f, _i64]),
     "edt_hip_edtsq_device": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _vp, _vp, _sz, _vp]),
     "edt_hip_set_profiling": (_i, [_i]),
     "edt_hip_set_debug_mode": (_i, [_i]),

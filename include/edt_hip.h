@@ -65,6 +65,10 @@ enum {
 
 /* ---- introspection -------------------------------------------------------------- */
 int edt_hip_device_count(void);         /* number of visible HIP devices (0 if none)  */
+/* 1 if every multiple k * wx, k <= sx + 1, is exactly representable in fp32 -- the reference's sequential fp32 sums
+ * of the voxel size (src/edt.hpp:97, :113) then ARE the multiples, and pass X may hand pass Y 16-bit distance indices
+ * instead of fp32 values (needs no device; exported so that tests can hold the criterion against its property). */
+int edt_hip_index_form_exact(float wx, int64_t sx);
 const char *edt_hip_last_error(void);   /* thread-local, never NULL                   */
 const char *edt_hip_version(void);
 

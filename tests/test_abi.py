@@ -127,3 +127,39 @@ def test_cpp_header_is_a_drop_in(tmp_path):
     else:
         assert res.returncode == 3, res.stdout
         assert "no HIP device" in res.stdout
+
+
+def test_index_form_criterion_of_the_library_implies_exact_sums(lib):
+    """edt_hip_index_form_exact (the criterion the library uses to hand pass Y 16-bit distance indices): whenever it
+    says yes, the reference's sequential fp32 sums of the voxel size (src/edt.hpp:97, :113) ARE the exact multiples;
+    and it agrees with the mirror the lane-logic tests use."""
+    from test_lane_logic import codes_exact
+    rng = np.random.default_rng(11)
+    yes = 0
+    for t in range(6000):
+        sx = int(rng.integers(1, 1100))
+        kind = t % 5
+        if kind == 0:
+            w = np.float32(rng.integers(1, 40000) * 2.0 ** int(rng.integers(-40, 20)))
+        elif kind == 1:
+            w = np.float32(rng.integers(1, 64) / 8.0)
+        elif kind == 2:
+            w = np.float32(rng.uniform(0.01, 50.0))
+        elif kind == 3:
+            w = np.float32([0.0, -1.0, np.inf, np.nan, 1e-38, 3e38, 1e-31, 1e31][int(rng.integers(0, 8))])
+        else:
+            w = np.float32(2.0 ** 24 / (sx + 1) * rng.choice([0.5, 1.0, 1.0 + 2.0 ** -20]))
+        got = lib.edt_hip_index_form_exact(float(w), sx)
+        assert got == int(codes_exact(w, sx)), (w, sx)
+        if not got:
+            continue
+        yes += 1
+        if t % 3:
+            continue  # (the sequential sums of every third accepted case)
+        acc = np.float32(0)
+        sums = np.empty(sx + 2, dtype=np.float32)
+        for i in range(sx + 2):
+            sums[i] = acc
+            acc = np.float32(acc + w)
+        assert np.array_equal(sums, np.arange(sx + 2, dtype=np.float32) * w), (w, sx)
+    assert yes > 1500

@@ -93,30 +93,44 @@ float* _edt2d(T* labels, const int64_t sx, const int64_t sy, const float wx, con
   return output;
 }
 
-// The binary variants give the same values as the multi-label ones on 0/1 input
-// (src/edt.hpp:487-576, :681-755); the GPU serves both through the same kernels.
+// The binary route (src/edt.hpp:487-576, :607-629, :681-755): pass X splits runs at label changes, passes Y and Z
+// scan every column as ONE envelope from its first non-zero value (background voxels are height-0 sites).  On 0/1
+// (and bool) input that equals the multi-label transform; on multi-valued T it does not, and the C ABI reproduces
+// the reference's values (edt_hip_binary_edtsq / EDT_FLAG_BINARY_YZ).
 template <typename T>
 float* _binary_edt3dsq(T* img, const int64_t sx, const int64_t sy, const int64_t sz, const float wx,
                        const float wy, const float wz, const bool black_border = false,
                        const int parallel = 1, float* workspace = NULL) {
-  return _edt3dsq<T>(img, sx, sy, sz, wx, wy, wz, black_border, parallel, workspace);
+  (void)parallel;
+  if (workspace == NULL) workspace = new float[sx * sy * sz]();
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 0, workspace));
+  return workspace;
 }
 template <typename T>
 float* _binary_edt3d(T* img, const int64_t sx, const int64_t sy, const int64_t sz, const float wx,
                      const float wy, const float wz, const bool black_border = false,
                      const int parallel = 1, float* workspace = NULL) {
-  return _edt3d<T>(img, sx, sy, sz, wx, wy, wz, black_border, parallel, workspace);
+  (void)parallel;
+  if (workspace == NULL) workspace = new float[sx * sy * sz]();
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 1, workspace));
+  return workspace;
 }
 template <typename T>
 float* _binary_edt2dsq(T* img, const int64_t sx, const int64_t sy, const float wx, const float wy,
                        const bool black_border = false, const int parallel = 1,
                        float* workspace = NULL) {
-  return _edt2dsq<T>(img, sx, sy, wx, wy, black_border, parallel, workspace);
+  (void)parallel;
+  if (workspace == NULL) workspace = new float[sx * sy]();
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 0, workspace));
+  return workspace;
 }
 template <typename T>
 float* _binary_edt2d(T* img, const int64_t sx, const int64_t sy, const float wx, const float wy,
                      const bool black_border = false, const int parallel = 1, float* output = NULL) {
-  return _edt2d<T>(img, sx, sy, wx, wy, black_border, parallel, output);
+  (void)parallel;
+  if (output == NULL) output = new float[sx * sy]();
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 1, output));
+  return output;
 }
 
 // src/edt_voxel_graph.hpp:54-117, :120-214, :216-236 (GRAPH_TYPE is always uint8_t upstream)

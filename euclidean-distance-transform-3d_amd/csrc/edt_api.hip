@@ -17,15 +17,24 @@
 namespace edt_amd {
 
 static thread_local std::string g_last_error = "";
-// diagnostics bit mask (edt_hip_set_debug_mode); EDT_HIP_DEBUG_MODE presets it, e.g. 0x4000 = every tile
-// of the wave column pass takes the windowed path, 0x2000 = none does
-static int g_debug_mode = [] {
-  const char *e = std::getenv("EDT_HIP_DEBUG_MODE");
-  return e ? (int)std::strtol(e, nullptr, 0) : 0;
-}();
+// diagnostics mode: thread-local, preset per thread from EDT_HIP_DEBUG_MODE; see edt_common.h for the bits
+#ifdef EDT_DIAG
+constexpr int kDiagMask = ~0;
+#else
+constexpr int kDiagMask = kDiagFormBits;
+#endif
+static int env_debug_mode() {
+  static const int v = [] {
+    const char *e = std::getenv("EDT_HIP_DEBUG_MODE");
+    return e ? (int)std::strtol(e, nullptr, 0) : 0;
+  }();
+  return v;
+}
+static thread_local int g_debug_mode = env_debug_mode() & kDiagMask;
 
 void set_error(const std::string &msg) { g_last_error = msg; }
 int debug_mode() { return g_debug_mode; }
+void set_thread_debug_mode(int mode) { g_debug_mode = mode & kDiagMask; }
 
 
 
@@ -263,6 +272,9 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   // a stack of 2-D images is a volume without a z pass
   if ((flags & EDT_FLAG_BATCH_2D) && ndim != 3) { set_error("EDT_FLAG_BATCH_2D needs ndim = 3 (sz = image count)"); return EDT_ERR_BAD_ARG; }
   const bool zpass = ndim == 3 && !(flags & EDT_FLAG_BATCH_2D);
+  // the reference's binary route for multi-valued labels: labels split runs in pass 1 only (edt_generic.hip:
+  // k_planes_one_run).  Boolean input gives the same values either way and keeps the ordinary planes.
+  const bool binary_yz = (flags & EDT_FLAG_BINARY_YZ) != 0 && dtype != EDT_BOOL;
 
   // the pass log is process-wide and only touched (under its mutex) while profiling is switched on
   if (g_log.enabled.load(std::memory_order_relaxed)) {
@@ -304,6 +316,12 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
                                   zpass ? p.zs_y + z0 * wpl : nullptr, sx, sy, zc, wx, bb, bb ? 0 : 1, stream,
                                   z0 > 0 ? lab - (size_t)sxy * lsz : nullptr, p.codes);
         if (rc != EDT_OK) return rc;
+        if (binary_yz) {
+          AxisGeom gb = p.gy;
+          gb.nouter = zc;
+          rc = launch_planes_one_run(p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, zpass ? p.zs_y + z0 * wpl : nullptr, gb, z0, stream);
+          if (rc != EDT_OK) return rc;
+        }
       }
       {
         ScopedPass t(one ? "y_pass" : nullptr, stream);
@@ -321,6 +339,8 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
       rc = launch_row_bits(dtype, d_labels, cur, p.nz_y, p.rs_y, zpass ? p.zs_y : nullptr, sx, sy, sz,
                            wx, bb, bb ? 0 : 1, stream);
       if (rc != EDT_OK) return rc;
+      if (binary_yz) rc = launch_planes_one_run(p.nz_y, p.rs_y, zpass ? p.zs_y : nullptr, p.gy, 0, stream);
+      if (rc != EDT_OK) return rc;
     }
   } else {
     {
@@ -331,6 +351,8 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     {
       ScopedPass t("y_bits", stream);
       rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_y, p.rs_y, p.gy, stream);
+      if (rc != EDT_OK) return rc;
+      if (binary_yz) rc = launch_planes_one_run(p.nz_y, p.rs_y, nullptr, p.gy, 0, stream);
       if (rc != EDT_OK) return rc;
     }
   }
@@ -349,7 +371,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     // z-packed planes (after the y pass: rs_z may live in the y pass's run-start plane)
     ScopedPass t("z_bits", stream);
     if (tiled_x) rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
-    else rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
+    else {
+      rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
+      if (rc == EDT_OK && binary_yz) rc = launch_planes_one_run(p.nz_z, p.rs_z, nullptr, p.gz, 0, stream);
+    }
     if (rc != EDT_OK) return rc;
   }
   if (zpass) {
@@ -513,7 +538,7 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
   rc = require_device();
   if (rc != EDT_OK) return rc;
   if (env_force_generic()) flags |= EDT_FLAG_FORCE_GENERIC;
-  if (ndim == 3 && !(flags & (EDT_FLAG_FORCE_GENERIC | EDT_FLAG_BATCH_2D | EDT_FLAG_SINGLE_DEVICE))) {
+  if (ndim == 3 && !(flags & (EDT_FLAG_FORCE_GENERIC | EDT_FLAG_BATCH_2D | EDT_FLAG_SINGLE_DEVICE | EDT_FLAG_BINARY_YZ))) {
     std::vector<int> devs;
     {
       std::lock_guard<std::mutex> lock(g_devices_mutex);
@@ -728,6 +753,14 @@ int edt_hip_edt3d(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t
                   (black_border ? EDT_FLAG_BLACK_BORDER : 0) | EDT_FLAG_SQRT, output);
 }
 
+int edt_hip_binary_edtsq(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx,
+                         float wy, float wz, int black_border, int take_sqrt, float *output) {
+  if (ndim != 2 && ndim != 3) { set_error("binary route: ndim must be 2 or 3"); return EDT_ERR_BAD_ARG; }
+  return run_host(labels, dtype, ndim, sx, sy, sz, wx, wy, wz,
+                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (take_sqrt ? EDT_FLAG_SQRT : 0) | EDT_FLAG_BINARY_YZ,
+                  output);
+}
+
 int edt_hip_edt2dsq_batch(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t count, float wx, float wy,
                           int black_border, int take_sqrt, float *output) {
   return run_host(labels, dtype, 3, sx, sy, count, wx, wy, 1.0f,
@@ -809,9 +842,11 @@ int edt_hip_release_cache(void) {
 }
 
 int edt_hip_set_debug_mode(int mode) {
-  g_debug_mode = mode;
+  set_thread_debug_mode(mode);
   return EDT_OK;
 }
+
+int edt_hip_get_debug_mode(void) { return debug_mode(); }
 
 int edt_hip_set_profiling(int enabled) {
   std::lock_guard<std::mutex> lock(g_log_mutex);

@@ -202,19 +202,19 @@ static __device__ __forceinline__ void hull_tile(float *tile, uint32_t *alive, c
   // All-flat shortcut (edt_colwave_lane.h: flat_word): a wave whose columns are flat wherever a run
   // continues needs no hull at all -- every foreground row owns itself.  (debug bit 16 switches it off.)
   bool all_flat = false;
-  if (!(dbg & (2 | 16 | 0x10000))) all_flat = __ballot((fl0 & need) != need) == 0ull;
+  if (!(EDT_DIAG_BITS(dbg, 2) | (dbg & (16 | 0x10000)))) all_flat = __ballot((fl0 & need) != need) == 0ull;
   uint32_t aw = L.nzw;
   if (all_flat) {
     L.own = L.nzw;
   } else {
     Hull1 H;
-    if (dbg & 2) { H.aw = L.nzw; H.flat = 0; H.nb0 = H.nb1 = H.nb31 = 0.0; }
+    if (EDT_DIAG_BITS(dbg, 2)) { H.aw = L.nzw; H.flat = 0; H.nb0 = H.nb1 = H.nb31 = 0.0; }
     else H = phase1_hull<CW>(L, f, fprev, fl0);
     aw = H.aw;
     const uint32_t flat = H.flat;
     alive[addr_word<CW>(L.colc, L.band)] = aw;
     wave_sync();
-    if (!(dbg & 4)) {
+    if (!EDT_DIAG_BITS(dbg, 4)) {
       // the merge rounds change nothing for a wave whose band boundaries are all quiet
       uint32_t prev_aw = __shfl_up(aw, CW), prev_rs = __shfl_up(L.rsw, CW);
       const double prev_nb31 = __shfl_up(H.nb31, CW);
@@ -240,12 +240,12 @@ static __device__ __forceinline__ void hull_tile(float *tile, uint32_t *alive, c
       if (dbg & 16) L.own = 0;  // diagnostics: no self-owned shortcut
     }
   }  // !all_flat
-  if (!(dbg & 8)) phase3_eval<CW, BB>(L, aw, f, epi);
+  if (!EDT_DIAG_BITS(dbg, 8)) phase3_eval<CW, BB>(L, aw, f, epi);
   wave_sync();  // every lane of the wave is done reading the tile
 
   // ---- results -> LDS (in place); the workgroup streams the tile back after its barrier ----
   float *own = tile + addr_tile<CW>(L.colc, L.row0);
-  if (!(dbg & 0x200)) {  // (diagnostics: bit 9 leaves the tile as it was loaded)
+  if (!EDT_DIAG_BITS(dbg, 0x200)) {  // (diagnostics: bit 9 leaves the tile as it was loaded)
 #pragma unroll
     for (int r = 0; r < 32; ++r) own[r * TC] = f[r];
   }
@@ -426,7 +426,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 
   // ---- tiles whose field is small everywhere take the windowed path (edt_colwave_lane.h: brute_band) ------
   const float fprev = __shfl_up(f[31], CW);  // last row of the band below (unused for band 0)
-  const uint32_t fl0 = (dbg & 2) ? 0u : flat_word(L, f, fprev);
+  const uint32_t fl0 = EDT_DIAG_BITS(dbg, 2) ? 0u : flat_word(L, f, fprev);
   const uint32_t need = L.nzw & ~(L.rsw | (L.band == 0 ? 1u : 0u));  // rows that continue a run
   {
     if (ba.limit_bits != 0u) {  // (wave-uniform: kernel argument)
@@ -474,7 +474,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
           }
         }
         // (bit 9, diagnostics: debug bit 0x80000 = no window at all, i.e. the fixed cost of the path; wrong results)
-        const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | ((dbg & 0x80000) ? 0x200 : 0) | (compact ? 0x400 : 0);
+        const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | (EDT_DIAG_BITS(dbg, 0x80000) ? 0x200 : 0) | (compact ? 0x400 : 0);
         if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
         else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
         return;
@@ -555,7 +555,7 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   ba.limit_bits = 0u;
   ba.x32 = 0;
   ba.force = 0;
-  ba.stride = (out_stride.stride == 2 && !(debug_mode() & 0x40000)) ? 2 : 1;  // (debug bit 0x40000: evaluate every row)
+  ba.stride = (out_stride.stride == 2 && !EDT_DIAG_BITS(debug_mode(), 0x40000)) ? 2 : 1;  // (debug bit 0x40000: evaluate every row)
   ba.compact = (out_stride.stride == 2 && !SC) ? out_stride.compact : nullptr;
   ba.c_outer = out_stride.outer;
   ba.c_row2 = out_stride.row2;

@@ -995,7 +995,9 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
       const int D = brute_flat_reach(L, k0, NR);
       const double cD = L.w2 * (double)((D + 1) * (D + 1));
       if (!EDT_ANY(cD < bmax64)) open = false;
+#ifdef EDT_DIAG
       if (epi & 0x200) open = false;  // diagnostics: the fixed cost of the path (results are wrong)
+#endif
     }
     // ---- the window: register-resident part (two steps per exit test), then straight from the tile ----
     if (open) {

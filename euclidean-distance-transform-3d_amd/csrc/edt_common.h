@@ -22,7 +22,27 @@ constexpr int kBandRows = 32;    // rows of the scan axis covered by one bit-wor
 
 // ---- error plumbing ---------------------------------------------------------------
 void set_error(const std::string &msg);
-int debug_mode();  // edt_hip_set_debug_mode(): bit0 = column pass moves data only (diagnostics)
+// Diagnostics mode (edt_hip_set_debug_mode / EDT_HIP_DEBUG_MODE).  THREAD-LOCAL: a call sees the mode of the thread
+// that makes it.  The default build honours only the bits that select between RESULT-PRESERVING forms of the same
+// computation (kDiagFormBits: used by the test tiers to drive every kernel family and both per-tile forms over the
+// whole parity suite); the bits that switch phases off and produce wrong results (1, 2, 4, 8, 0x200, 0x40000,
+// 0x80000: measuring what a phase costs) exist only in a library built with -DEDT_DIAG and are compiled out of the
+// kernels otherwise.
+//   16 / 0x10000  no all-flat shortcut / no self-owned rows      32 / 64   tiled row pass / tiled column pass
+//   256           plain group order in pass X                    0x800     plain tile order in the column pass
+//   0x1000        name every pass on stderr                      0x2000    no tile takes the windowed path
+//   0x4000        every tile takes the windowed path             0x8000    fp64 candidates on the windowed path
+//   0x20000       voxel graph: up-sampled formulation            0x100000  fp32 form of pass X (no 16-bit indices)
+//   0x200000      voxel graph: separate gather pass
+constexpr int kDiagFormBits = 16 | 32 | 64 | 256 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |
+                              0x100000 | 0x200000;
+#ifdef EDT_DIAG
+#define EDT_DIAG_BITS(dbg, bits) ((dbg) & (bits))
+#else
+#define EDT_DIAG_BITS(dbg, bits) 0
+#endif
+int debug_mode();                 // the calling thread's mode (masked with kDiagFormBits unless EDT_DIAG)
+void set_thread_debug_mode(int);  // (worker threads of one call inherit the caller's mode)
 
 #define EDT_HIP_TRY(expr)                                                              \
   do {                                                                                 \

@@ -164,6 +164,39 @@ int launch_axis_bits(int dtype, const void *labels, const void *halo, uint32_t *
 }
 
 // ------------------------------------------------------------------------------------
+// Bit planes of the reference's *binary* route (EDT_FLAG_BINARY_YZ; pyedt::_binary_edt{2,3}dsq<T>,
+// src/edt.hpp:528-567, :722-755): passes 2 and 3 do not split a column at label changes -- every column is ONE
+// envelope from its first non-zero value to its end, background voxels taking part as height-0 parabolas.  Rows
+// before that first value hold 0 and keep it (their own parabola), and the border site the reference puts just
+// before the first value is such a row, so the whole column [0, n) as a single all-foreground run gives the same
+// values.  The planes therefore do not depend on the labels: foreground everywhere, one run start at row 0.
+// zs (y-packed "differs from z-1" plane of a slab starting at slice o0, or nullptr): set on slice 0 only.
+// ------------------------------------------------------------------------------------
+__global__ void k_planes_one_run(uint32_t *__restrict__ nzbits, uint32_t *__restrict__ rsbits,
+                                 uint32_t *__restrict__ zsbits, AxisGeom g, int64_t o0) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = g.sx * g.nbands * g.nouter;
+  if (idx >= total) return;
+  const int64_t b = (idx / g.sx) % g.nbands;
+  const int64_t o = idx / (g.sx * g.nbands);
+  const int64_t left = g.n - b * kBandRows;  // rows of this band that exist (>= 1)
+  const uint32_t mask = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u);
+  nzbits[idx] = mask;
+  rsbits[idx] = b == 0 ? 1u : 0u;
+  if (zsbits != nullptr) zsbits[idx] = (o + o0 == 0) ? mask : 0u;
+}
+
+int launch_planes_one_run(uint32_t *nz, uint32_t *rs, uint32_t *zs, const AxisGeom &g, int64_t o0, hipStream_t stream) {
+  const int threads = 256;
+  const int64_t total = g.sx * g.nbands * g.nouter;
+  if (total <= 0) return EDT_OK;
+  hipLaunchKernelGGL(k_planes_one_run, dim3((unsigned)ceil_div(total, threads)), dim3(threads), 0, stream, nz, rs, zs,
+                     g, o0);
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // Passes 2/3, one thread per column, hull vertices kept in a global-memory stack that
 // shares the volume's addressing (entry k of column c lives at stack[c + k*stride], so
 // lanes that agree on k access it coalesced).  Not in place: reads `fin`, writes `fout`.

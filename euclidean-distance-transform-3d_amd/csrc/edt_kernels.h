@@ -44,6 +44,8 @@ int launch_extract_runs(int dtype, const void *labels, int64_t n, int64_t *start
                         void *ws, hipStream_t stream);
 int launch_axis_bits(int dtype, const void *labels, const void *halo, uint32_t *nz, uint32_t *rs,
                      const AxisGeom &g, hipStream_t stream);
+// planes of the binary route (EDT_FLAG_BINARY_YZ): every column one all-foreground run
+int launch_planes_one_run(uint32_t *nz, uint32_t *rs, uint32_t *zs, const AxisGeom &g, int64_t o0, hipStream_t stream);
 int launch_column_pass_serial(const float *fin, float *fout, const uint32_t *nz, const uint32_t *rs,
                               int32_t *stack, const AxisGeom &g, float w, int bb, int epi,
                               hipStream_t stream);

@@ -102,7 +102,9 @@ int run_multi(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz,
   sh.msg.assign(n, "");
   Barrier barrier(n);
 
+  const int caller_mode = debug_mode();
   auto worker = [&](int g) {
+    set_thread_debug_mode(caller_mode);  // (the diagnostics mode is thread-local)
     int rc = EDT_OK;
     std::string err;
     const int dev = devices[g];

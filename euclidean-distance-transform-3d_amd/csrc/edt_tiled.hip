@@ -151,7 +151,7 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     }
     rsp[b * C + c] = rsword;
 
-    if (debug_mode & 1) {
+    if (EDT_DIAG_BITS(debug_mode, 1)) {
       // diagnostics: memory-only variant (tile -> LDS -> store back), the access-pattern floor
       // that the roofline analysis in DESIGN.md compares the full kernel against
       __syncthreads();
@@ -168,7 +168,7 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   // index, data-dependent repetition (pops) is a loop on __any(), and per-lane decisions are
   // selects.  This keeps the scalar unit out of the way (no exec-mask bookkeeping per branch).
   uint32_t aw = 0;
-  if (debug_mode & 2) {  // diagnostics: pretend every foreground row is a hull vertex
+  if (EDT_DIAG_BITS(debug_mode, 2)) {  // diagnostics: pretend every foreground row is a hull vertex
     aw = nzword;
     acol[b * C] = aw;
   } else {
@@ -220,7 +220,7 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 
   // ---- phase 2: merge hulls across band-group boundaries ------------------------------------
   for (int half = 1; half < NB; half <<= 1) {
-    if (debug_mode & 4) break;  // diagnostics: no merges
+    if (EDT_DIAG_BITS(debug_mode, 4)) break;  // diagnostics: no merges
     if (active && (b & (2 * half - 1)) == half) {
       const int R = row0;  // first row of the right group
       // a non-background run crosses the boundary iff row R is foreground and not a run start
@@ -269,7 +269,7 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   // ---- phase 3: evaluate the envelope on this band's rows, in place -------------------------
   aw = acol[b * C];  // this band's vertices after the merges
   if (!active) { nzword = 0; }
-  if (debug_mode & 8) {  // diagnostics: skip the evaluation, store the tile back
+  if (EDT_DIAG_BITS(debug_mode, 8)) {  // diagnostics: skip the evaluation, store the tile back
     float *dstp = Fcol + (int64_t)row0 * st;
 #pragma unroll
     for (int r = 0; r < 32; ++r) {

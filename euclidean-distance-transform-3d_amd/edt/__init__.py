@@ -30,7 +30,7 @@ from ._lib import EdtHipError  # noqa: F401  (re-export)
 __all__ = [
     "edt", "edtsq", "sdf", "sdfsq",
     "edt1d", "edt1dsq", "edt2d", "edt2dsq", "edt3d", "edt3dsq",
-    "each", "edt_stack", "edtsq_stack", "set_devices", "EdtHipError",
+    "each", "edt_stack", "edtsq_stack", "binary_edt", "binary_edtsq", "set_devices", "EdtHipError",
 ]
 
 _DTYPE_CODE = {
@@ -137,6 +137,26 @@ def edt3dsq(data, anisotropy=(1.0, 1.0, 1.0), black_border=False, parallel=1, vo
     return _run(np.asarray(data), anisotropy, black_border, voxel_graph, False, ndim=3)
 
 
+def binary_edtsq(data, anisotropy=None, black_border=False, parallel=1):
+    """The C++ facade's ``edt::binary_edtsq`` for 2-D / 3-D arrays of ANY label type (reference:
+    src/edt.hpp:895-951 -> ``pyedt::_binary_edt{2,3}dsq<T>``, :487-576, :681-755): labels split runs along x only;
+    along y and z every non-zero voxel is one foreground.  Equal to ``edtsq`` on 0/1 input.  (The reference's Python
+    module reaches this route for ``bool`` arrays only; exposed here so the facade's semantics can be tested.)"""
+    data = np.asarray(data)
+    if data.ndim not in (2, 3):
+        raise TypeError("binary_edtsq: 2-D or 3-D arrays")
+    an = (1.0,) * data.ndim if anisotropy is None else anisotropy
+    return _run(data, an, black_border, None, False, ndim=data.ndim, binary=True)
+
+
+def binary_edt(data, anisotropy=None, black_border=False, parallel=1):
+    data = np.asarray(data)
+    if data.ndim not in (2, 3):
+        raise TypeError("binary_edt: 2-D or 3-D arrays")
+    an = (1.0,) * data.ndim if anisotropy is None else anisotropy
+    return _run(data, an, black_border, None, True, ndim=data.ndim, binary=True)
+
+
 def set_devices(devices=None):
     """Z-shard every 3-D transform of host arrays over these GPUs of THIS process (``edt_hip_set_devices``: a host
     thread per device, one peer-to-peer exchange over xGMI, see ``csrc/edt_multi.hip``); ``None`` / ``[]`` = back to
@@ -208,7 +228,7 @@ def _transform(data, anisotropy, black_border, parallel, voxel_graph, take_sqrt,
     return _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim=dims, signed=signed)
 
 
-def _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim, signed=False):
+def _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim, signed=False, binary=False):
     if data.ndim != ndim:
         raise TypeError(f"expected a {ndim}-D array, got {data.ndim}-D")
     if data.size == 0:
@@ -261,6 +281,11 @@ def _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim, signed=Fa
         ww = tuple(w) + (1.0,) * (3 - ndim)
         _lib.check(lib.edt_hip_sdf(_ptr(buf), code, ndim, e[0], e[1], e[2], ww[0], ww[1], ww[2], bb,
                                    0 if take_sqrt else 1, _ptr(out)))
+    elif binary:
+        e = tuple(extents) + (1,) * (3 - ndim)
+        ww = tuple(w) + (1.0,) * (3 - ndim)
+        _lib.check(lib.edt_hip_binary_edtsq(_ptr(buf), code, ndim, e[0], e[1], e[2], ww[0], ww[1], ww[2], bb,
+                                            1 if take_sqrt else 0, _ptr(out)))
     elif ndim == 1:
         rc = lib.edt_hip_squared_edt_1d_multi_seg(_ptr(buf), code, _ptr(out), data.size, 1, w[0], bb)
         _lib.check(rc)

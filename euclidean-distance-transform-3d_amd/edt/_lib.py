@@ -22,6 +22,7 @@ FLAG_SQRT = 2
 FLAG_FORCE_GENERIC = 4
 FLAG_BATCH_2D = 8
 FLAG_SMALL_WORKSPACE = 16
+FLAG_BINARY_YZ = 32
 
 OK = 0
 ERR_NO_DEVICE = -1
@@ -48,6 +49,7 @@ SIGNATURES = {
     "edt_hip_edt3d": (_i, [_vp, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp]),
     "edt_hip_edt2dsq_voxel_graph": (_i, [_vp, _i, _vp, _i64, _i64, _f, _f, _i, _vp]),
     "edt_hip_edt3dsq_voxel_graph": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _f, _f, _f, _i, _vp]),
+    "edt_hip_binary_edtsq": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp]),
     "edt_hip_edt2dsq_batch": (_i, [_vp, _i, _i64, _i64, _i64, _f, _f, _i, _i, _vp]),
     "edt_hip_runs_workspace_bytes": (_sz, [_i64]),
     "edt_hip_extract_runs_device": (_i, [_vp, _i, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
@@ -60,6 +62,7 @@ SIGNATURES = {
     "edt_hip_edtsq_device": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _vp, _vp, _sz, _vp]),
     "edt_hip_set_profiling": (_i, [_i]),
     "edt_hip_set_debug_mode": (_i, [_i]),
+    "edt_hip_get_debug_mode": (_i, []),
     "edt_hip_release_cache": (_i, []),
     "edt_hip_get_pass_times": (_i, [_vp, _i]),
     "edt_hip_get_pass_name": (ctypes.c_char_p, [_i]),

@@ -58,6 +58,10 @@ enum {
   EDT_FLAG_FORCE_GENERIC = 4, /* use the size-agnostic fallback kernels (test hook)     */
   EDT_FLAG_BATCH_2D = 8,     /* edt_hip_edtsq_device with ndim = 3: the volume is a STACK of sz independent
                                 2-D images (sx x sy each) -- x and y passes only, one launch for all images */
+  EDT_FLAG_BINARY_YZ = 32,   /* the reference's *binary* route for a multi-valued label type (pyedt::_binary_edt{2,3}dsq<T>,
+                                src/edt.hpp:487-576, :681-755): labels split runs in pass X only; passes Y and Z treat every
+                                column as one envelope from its first non-zero value on, background voxels as height-0
+                                sites.  Identical to the ordinary transform on 0/1 input. */
   EDT_FLAG_SMALL_WORKSPACE = 16 /* scratch = the four bit planes only (1/2 byte per voxel): passes X and Y then
                                 exchange fp32 values instead of 16-bit distance indices (no 256 MiB index slab,
                                 about 7 % slower at 512^3); pass it to edt_hip_workspace_bytes_flags as well */
@@ -108,6 +112,13 @@ int edt_hip_edt2dsq_voxel_graph(const void *labels, int dtype, const uint8_t *gr
 int edt_hip_edt3dsq_voxel_graph(const void *labels, int dtype, const uint8_t *graph, int64_t sx,
                                 int64_t sy, int64_t sz, float wx, float wy, float wz,
                                 int black_border, float *workspace);
+
+/* replaces pyedt::_binary_edt2dsq<T> / _binary_edt2d<T> / _binary_edt3dsq<T> / _binary_edt3d<T> (src/edt.hpp:681-755,
+ * :487-576, :607-629 -- what edt::binary_edt / edt::binary_edtsq instantiate for ANY label type): pass X splits runs
+ * at label changes like the multi-label transform, passes Y and Z do not (one envelope per column, zeros as
+ * height-0 sites).  ndim in {2,3} (sz = 1 for 2-D); take_sqrt != 0: distances instead of squared distances. */
+int edt_hip_binary_edtsq(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx,
+                         float wy, float wz, int black_border, int take_sqrt, float *output);
 
 /* ---- one process, several GPUs ---------------------------------------------------------------------
  * pyedt::_edt3dsq / _edt3d on host buffers, Z-sharded over the listed devices of this process (a host thread per
@@ -167,9 +178,16 @@ int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, 
  * edt_hip_get_pass_times copies the durations (ms) of the last call, in launch order,
  * into `ms` and returns how many there were (names via edt_hip_get_pass_name). */
 int edt_hip_set_profiling(int enabled);
-/* Diagnostics only (never set in production): bit0 makes the column passes move their tile
- * HBM -> LDS -> HBM without computing, which measures the access-pattern floor of that kernel. */
+/* Diagnostics / test hook.  The mode belongs to the CALLING THREAD (EDT_HIP_DEBUG_MODE in the environment presets
+ * every thread's).  The shipped library honours only bits that choose between result-preserving forms of the same
+ * computation -- e.g. 0x2000: no tile of the column pass takes the windowed path, 0x4000: every tile does, 0x8000:
+ * fp64 candidates there, 0x100000: fp32 instead of 16-bit indices between passes X and Y, 0x20000: up-sampled
+ * voxel-graph formulation, 32 / 64: workgroup-phased row / column kernels (csrc/edt_common.h lists them); results
+ * are bit-identical under every one of them, which is what the GPU test tier uses them for.  Bits that switch
+ * phases off (wrong results, for cost measurements) exist only in a build with -DEDT_DIAG and are ignored here.
+ * edt_hip_get_debug_mode returns the effective (masked) mode of the calling thread. */
 int edt_hip_set_debug_mode(int mode);
+int edt_hip_get_debug_mode(void);
 int edt_hip_get_pass_times(float *ms, int capacity);
 const char *edt_hip_get_pass_name(int index);
 

@@ -195,7 +195,34 @@ static void envelope_scan(float *f, int64_t n, int64_t stride, float w,
     }                                                                                     \
     scratch_free(&s);                                                                     \
     return 0;                                                                             \
+  }                                                                                       \
+                                                                                          \
+  /* The reference's *binary* route for label type T: pass 1 still splits runs by label  \
+   * (multi_seg), passes 2/3 scan every column as ONE envelope from its first non-zero   \
+   * pass-1 value.  Reference: _binary_edt3dsq src/edt.hpp:487-576 (pass 1 :507-517,      \
+   * pass 2 :528-543, pass 3 :550-567), _binary_edt2dsq :681-732. */                      \
+  static int volume_binary_##SUF(const T *seg, int64_t sx, int64_t sy, int64_t sz,        \
+                                 float wx, float wy, float wz, int bb, float *out,        \
+                                 int ndim) {                                              \
+    const int64_t sxy = sx * sy, voxels = sxy * sz;                                       \
+    int64_t longest = sy > sz ? sy : sz;                                                  \
+    scratch_t s;                                                                          \
+    if (scratch_init(&s, longest) != 0) return -2;                                        \
+    for (int64_t r = 0; r < sy * sz; r++) row_pass_##SUF(seg + r * sx, out + r * sx, sx, wx, bb); \
+    if (ndim >= 2) {                                                                      \
+      if (!bb) inf_to_sentinel(out, voxels);                                              \
+      for (int64_t z = 0; z < sz; z++)                                                    \
+        for (int64_t x = 0; x < sx; x++) binary_column(out + x + sxy * z, sy, sx, wy, bb, &s); \
+      if (ndim >= 3)                                                                      \
+        for (int64_t y = 0; y < sy; y++)                                                  \
+          for (int64_t x = 0; x < sx; x++) binary_column(out + x + sx * y, sz, sxy, wz, bb, &s); \
+      if (!bb) sentinel_to_inf(out, voxels);                                              \
+    }                                                                                     \
+    scratch_free(&s);                                                                     \
+    return 0;                                                                             \
   }
+
+static void binary_column(float *f, int64_t n, int64_t stride, float w, int bb, scratch_t *s);
 
 DEFINE_TYPED(uint8_t, u8)
 DEFINE_TYPED(uint16_t, u16)
@@ -246,6 +273,23 @@ static int dispatch_volume(const void *labels, int dtype, int64_t sx, int64_t sy
     case DT_U64:  return volume_u64((const uint64_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
     case DT_F32:  return volume_f32((const float *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
     case DT_F64:  return volume_f64((const double *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_BOOL: return volume_bool((const uint8_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    default: return -1;
+  }
+}
+
+/* binary route for any label type (the C++ templates pyedt::_binary_edt{2,3}dsq<T>, reached
+ * through edt::binary_edt* -- src/edt.hpp:846-951) */
+int oracle_binary_edtsq(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz,
+                        float wx, float wy, float wz, int bb, float *out, int ndim) {
+  if (sx <= 0 || sy <= 0 || sz <= 0) return 0;
+  switch (dtype) {
+    case DT_U8:   return volume_binary_u8((const uint8_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_U16:  return volume_binary_u16((const uint16_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_U32:  return volume_binary_u32((const uint32_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_U64:  return volume_binary_u64((const uint64_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_F32:  return volume_binary_f32((const float *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
+    case DT_F64:  return volume_binary_f64((const double *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
     case DT_BOOL: return volume_bool((const uint8_t *)labels, sx, sy, sz, wx, wy, wz, bb, out, ndim);
     default: return -1;
   }

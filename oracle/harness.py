@@ -132,6 +132,41 @@ class _Lib:
             return out.reshape(arr.shape, order=order)
         raise TypeError(f"Multi-Label EDT library only supports up to 3 dimensions got {dims}.")
 
+    def binary_edtsq(self, data, anisotropy=None, black_border=False, parallel=1):
+        """pyedt::_binary_edt{2,3}dsq<T> for ANY label type (what edt::binary_edt* instantiates,
+        src/edt.hpp:487-576, :681-732): labels split runs in pass 1 only.  2-D / 3-D."""
+        data = np.asarray(data)
+        if data.size == 0:
+            return np.zeros(data.shape, dtype=np.float32)
+        arr, order, code = _canonical(data)
+        dims = arr.ndim
+        assert dims in (2, 3)
+        a = (1.0,) * dims if anisotropy is None else tuple(float(v) for v in anisotropy)
+        ext = list(arr.shape if order == "F" else arr.shape[::-1])
+        w = list(a if order == "F" else a[::-1])
+        out = np.zeros(arr.size, dtype=np.float32)
+        lp, op = arr.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)
+        if self.is_ref:
+            if dims == 3:
+                rc = self.lib.ref_binary_edt3dsq(
+                    lp, ctypes.c_int(code), ctypes.c_int64(ext[0]), ctypes.c_int64(ext[1]), ctypes.c_int64(ext[2]),
+                    ctypes.c_float(w[0]), ctypes.c_float(w[1]), ctypes.c_float(w[2]), ctypes.c_int(int(black_border)),
+                    ctypes.c_int(parallel), op)
+            else:
+                rc = self.lib.ref_binary_edt2dsq(
+                    lp, ctypes.c_int(code), ctypes.c_int64(ext[0]), ctypes.c_int64(ext[1]),
+                    ctypes.c_float(w[0]), ctypes.c_float(w[1]), ctypes.c_int(int(black_border)),
+                    ctypes.c_int(parallel), op)
+        else:
+            ext += [1] * (3 - dims)
+            w += [1.0] * (3 - dims)
+            rc = self.lib.oracle_binary_edtsq(
+                lp, ctypes.c_int(code), ctypes.c_int64(ext[0]), ctypes.c_int64(ext[1]), ctypes.c_int64(ext[2]),
+                ctypes.c_float(w[0]), ctypes.c_float(w[1]), ctypes.c_float(w[2]), ctypes.c_int(int(black_border)),
+                op, ctypes.c_int(dims))
+        assert rc == 0, rc
+        return out.reshape(arr.shape, order=order)
+
     def edt(self, data, anisotropy=None, black_border=False, parallel=1, voxel_graph=None):
         dt = self.edtsq(data, anisotropy, black_border, parallel, voxel_graph)
         return np.sqrt(dt, dt)

@@ -8,6 +8,7 @@
 //   pyedt::squared_edt_1d_multi_seg<T>   (src/edt.hpp:70-119)
 //   pyedt::_edt2dsq<T>                   (src/edt.hpp:632-678, bool: :758-772)
 //   pyedt::_edt3dsq<T>                   (src/edt.hpp:411-484, bool: :580-587)
+//   pyedt::_binary_edt{2,3}dsq<T>        (src/edt.hpp:681-732, :487-576)
 //   pyedt::_edt2dsq_voxel_graph<T,u8>    (src/edt_voxel_graph.hpp:54-117)
 //   pyedt::_edt3dsq_voxel_graph<T,u8>    (src/edt_voxel_graph.hpp:120-214)
 // exactly as the reference Cython binding does (src/edt.pyx:62-113).
@@ -47,6 +48,18 @@ int ref_edt2dsq(void* labels, int dtype, int64_t sx, int64_t sy, float wx, float
 int ref_edt3dsq(void* labels, int dtype, int64_t sx, int64_t sy, int64_t sz,
                 float wx, float wy, float wz, int bb, int parallel, float* out) {
   DISPATCH(pyedt::_edt3dsq<T>((T*)labels, sx, sy, sz, wx, wy, wz, bb != 0, parallel, out))
+}
+
+// the binary route as the C++ facade reaches it for ANY label type (edt::binary_edt* -> pyedt::_binary_edt{2,3}dsq<T>,
+// src/edt.hpp:487-576, :681-732): labels split runs in pass 1 only
+int ref_binary_edt2dsq(void* labels, int dtype, int64_t sx, int64_t sy, float wx, float wy,
+                       int bb, int parallel, float* out) {
+  DISPATCH(pyedt::_binary_edt2dsq<T>((T*)labels, sx, sy, wx, wy, bb != 0, parallel, out))
+}
+
+int ref_binary_edt3dsq(void* labels, int dtype, int64_t sx, int64_t sy, int64_t sz,
+                       float wx, float wy, float wz, int bb, int parallel, float* out) {
+  DISPATCH(pyedt::_binary_edt3dsq<T>((T*)labels, sx, sy, sz, wx, wy, wz, bb != 0, parallel, out))
 }
 
 int ref_edt2dsq_voxel_graph(void* labels, int dtype, uint8_t* graph, int64_t sx, int64_t sy,

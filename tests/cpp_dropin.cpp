@@ -17,12 +17,35 @@
 namespace {
 
 template <typename T>
-bool run_case(const std::vector<char>& lab, const std::vector<uint8_t>& graph, bool has_graph, int ndim, int64_t sx,
+bool run_case(const std::vector<char>& lab, const std::vector<uint8_t>& graph, int mode, int ndim, int64_t sx,
               int64_t sy, int64_t sz, float wx, float wy, float wz, bool bb, const std::vector<float>& want) {
   T* l = reinterpret_cast<T*>(const_cast<char*>(lab.data()));
   const int64_t vox = sx * sy * sz;
   std::vector<float> got(vox, -1.0f);
   float* owned = nullptr;
+  const bool has_graph = mode == 1;
+  if (mode == 2) {
+    // the binary route through the facade (edt::binary_edtsq / binary_edt -> pyedt::_binary_edt{2,3}d[sq]<T>):
+    // `want` holds the reference's values for a MULTI-VALUED image (labels split runs along x only)
+    if (ndim == 2) {
+      owned = edt::binary_edtsq<T>(l, (int)sx, (int)sy, wx, wy, bb, 1);
+      std::memcpy(got.data(), owned, vox * sizeof(float));
+      delete[] owned;
+      float* d = edt::binary_edt<T>(l, (int)sx, (int)sy, wx, wy, bb, 1);
+      bool ok = true;
+      for (int64_t i = 0; i < vox && ok; i++) ok = d[i] == std::sqrt(want[i]);
+      delete[] d;
+      if (!ok) return false;
+    } else {
+      edt::binary_edtsq<T>(l, (int)sx, (int)sy, (int)sz, wx, wy, wz, bb, 1, got.data());
+      float* d = edt::binary_edt<T>(l, (int)sx, (int)sy, (int)sz, wx, wy, wz, bb, 1);
+      bool ok = true;
+      for (int64_t i = 0; i < vox && ok; i++) ok = d[i] == std::sqrt(want[i]);
+      delete[] d;
+      if (!ok) return false;
+    }
+    return std::memcmp(got.data(), want.data(), vox * sizeof(float)) == 0;
+  }
   if (has_graph) {
     uint8_t* g = const_cast<uint8_t*>(graph.data());
     if (ndim == 2) pyedt::_edt2dsq_voxel_graph<T, uint8_t>(l, g, sx, sy, wx, wy, bb, got.data());
@@ -58,17 +81,17 @@ int run_file(const char* path) {
   if (std::fread(&ncases, 4, 1, f) != 1) return 2;
   int bad = 0;
   for (int c = 0; c < ncases; c++) {
-    int32_t head[7];   // dtype, ndim, sx, sy, sz, bb, has_graph
+    int32_t head[7];   // dtype, ndim, sx, sy, sz, bb, mode (0: edtsq, 1: voxel graph follows, 2: binary route)
     float w[3];
     if (std::fread(head, 4, 7, f) != 7 || std::fread(w, 4, 3, f) != 3) return 2;
     const int dtype = head[0], ndim = head[1];
     const int64_t sx = head[2], sy = head[3], sz = head[4], vox = sx * sy * sz;
     static const int size_of[] = {1, 2, 4, 8, 4, 8, 1};
     std::vector<char> lab((size_t)vox * size_of[dtype]);
-    std::vector<uint8_t> graph(head[6] ? vox : 0);
+    std::vector<uint8_t> graph(head[6] == 1 ? vox : 0);
     std::vector<float> want(vox);
     if (std::fread(lab.data(), 1, lab.size(), f) != lab.size()) return 2;
-    if (head[6] && std::fread(graph.data(), 1, graph.size(), f) != graph.size()) return 2;
+    if (head[6] == 1 && std::fread(graph.data(), 1, graph.size(), f) != graph.size()) return 2;
     if (std::fread(want.data(), 4, vox, f) != (size_t)vox) return 2;
     bool ok = false;
     switch (dtype) {

@@ -76,6 +76,32 @@ def voronoi_coarse(coarse_shape, nseeds, seed=0, zrange=None, workers=-1):
     return np.asfortranarray((idx + 1).astype(np.uint32).reshape(coarse_shape[0], coarse_shape[1], z1 - z0))
 
 
+def voronoi_full(shape, nseeds, seed=0, dtype=np.uint32, workers=-1):
+    """FULL-resolution nearest-seed segmentation (smooth cell walls, no up-sampling): large label runs along every
+    axis -- ~60 seeds in 512^3 give cells ~130 voxels across, ~500 seeds ~65.  Built slab by slab (bounded memory)."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    pts = rng.random((nseeds, 3)) * np.array(shape)
+    tree = cKDTree(pts)
+    out = np.empty(shape, dtype=dtype, order="F")
+    gx, gy = np.meshgrid(np.arange(shape[0]) + 0.5, np.arange(shape[1]) + 0.5, indexing="ij")
+    zstep = max(1, (1 << 22) // max(1, shape[0] * shape[1]))
+    for z0 in range(0, shape[2], zstep):
+        z1 = min(shape[2], z0 + zstep)
+        g = np.empty((shape[0], shape[1], z1 - z0, 3))
+        g[..., 0] = gx[:, :, None]
+        g[..., 1] = gy[:, :, None]
+        g[..., 2] = (np.arange(z0, z1) + 0.5)[None, None, :]
+        idx = tree.query(g.reshape(-1, 3), workers=workers)[1]
+        out[:, :, z0:z1] = (idx + 1).reshape(shape[0], shape[1], z1 - z0)
+    return out
+
+
+# large-cell segmentations (VERDICT r2: the regime where the hull path / long windows were slow)
+LARGE_CELL = {"cfg3L": (60, (1.0, 1.0, 1.0)), "cfg3La": (60, (6.0, 6.0, 30.0)),
+              "cfg3M": (500, (1.0, 1.0, 1.0)), "cfg3Ma": (500, (6.0, 6.0, 30.0))}
+
+
 def config_volume(name: str, n: int = 512):
     """The BASELINE.json configurations at edge length `n` (Fortran order, x fastest).
 
@@ -85,6 +111,8 @@ def config_volume(name: str, n: int = 512):
       cfg3: ~2000 (scaled with volume) random multi-labels, black_border=False
       cfg4: the same kind of segmentation as configs[3] builds it (16 000 seeds at 1024^3), black_border=False
       cfg5: uint8 binary blobs, black_border=True
+      cfg3L / cfg3La / cfg3M / cfg3Ma: full-resolution Voronoi segmentations with LARGE cells (~130 / ~65 voxels
+            across at 512^3) at (1,1,1) / (6,6,30), black_border=False
     """
     if name == "cfg1":
         return np.ones((n, n, n), dtype=np.uint32, order="F"), (1.0, 1.0, 1.0), True
@@ -103,6 +131,10 @@ def config_volume(name: str, n: int = 512):
         for ax in range(3):
             lab = lab.repeat(4, axis=ax)
         return np.asfortranarray(lab[:n, :n, :n]), (1.0, 1.0, 1.0), False
+    if name in LARGE_CELL:  # full-resolution Voronoi cells: ~130 voxels (cfg3L*) / ~65 voxels (cfg3M*) across at 512^3
+        seeds, an = LARGE_CELL[name]
+        nseeds = max(4, int(round(seeds * (n / 512.0) ** 3)))
+        return voronoi_full((n, n, n), nseeds, seed=3), an, False
     if name == "cfg5":
         rng = np.random.default_rng(5)
         up = 16 if n >= 64 else 4

@@ -163,3 +163,29 @@ def test_index_form_criterion_of_the_library_implies_exact_sums(lib):
             acc = np.float32(acc + w)
         assert np.array_equal(sums, np.arange(sx + 2, dtype=np.float32) * w), (w, sx)
     assert yes > 1500
+
+
+def test_default_library_ignores_wrong_result_diagnostics():
+    """The phase-skipping diagnostics (bits 1, 2, 4, 8, 0x200, 0x40000, 0x80000: wrong results, cost measurements) exist
+    only in a -DEDT_DIAG build: the shipped library masks them out of whatever edt_hip_set_debug_mode /
+    EDT_HIP_DEBUG_MODE asks for, keeps the form-selection bits, and the mode belongs to the calling thread."""
+    import subprocess
+    import sys
+    import threading
+    from edt import _lib
+    lib = _lib.load()
+    try:
+        lib.edt_hip_set_debug_mode(0x200 | 0x80000 | 0x40000 | 15 | 0x4000 | 0x100000)
+        assert lib.edt_hip_get_debug_mode() == 0x4000 | 0x100000
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(lib.edt_hip_get_debug_mode()))
+        t.start()
+        t.join()
+        assert seen == [0]          # another thread: its own mode
+    finally:
+        lib.edt_hip_set_debug_mode(0)
+    code = ("import sys; sys.path.insert(0, %r); from edt import _lib; print(_lib.load().edt_hip_get_debug_mode())"
+            % os.path.join(ROOT, "euclidean-distance-transform-3d_amd"))
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EDT_HIP_DEBUG_MODE="0x8201"),
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip() == str(0x8000), res.stdout + res.stderr

@@ -280,10 +280,56 @@ def test_cpp_drop_in_header_on_gpu(edt_gpu, oracle_port, tmp_path):
         if graph is not None:
             blob.append(graph.tobytes(order="F"))
         blob.append(np.asfortranarray(want).astype(np.float32).tobytes(order="F"))
+    # the binary route of the facade on MULTI-VALUED images (mode 2): labels split runs along x only
+    # (src/edt.hpp:487-576, :681-755); expected values from the oracle's restatement of that route, which
+    # tests/test_oracle.py pins to the compiled reference
+    nbin = 0
+    for t in range(28):
+        dims = 2 + t % 2
+        dt = dtypes[t % 6]                                 # every non-bool label type
+        shape = tuple(int(rng.integers(1, 40)) for _ in range(dims))
+        lab = np.asfortranarray(blocky_labels(shape, nlabels=4, zero_frac=0.3, block=int(rng.integers(1, 6)),
+                                              rng=rng).astype(dt))
+        an = tuple(float(a) for a in ANISO[int(rng.integers(0, len(ANISO)))][:dims])
+        bb = bool(rng.integers(0, 2))
+        want = oracle_port.binary_edtsq(lab, an, bb)
+        ext = shape + (1,) * (3 - dims)
+        w = an + (1.0,) * (3 - dims)
+        blob.append(struct.pack("<7i3f", harness._DTYPE_CODE[np.dtype(dt)], dims, ext[0], ext[1], ext[2], int(bb), 2, *w))
+        blob.append(lab.tobytes(order="F"))
+        blob.append(np.asfortranarray(want).astype(np.float32).tobytes(order="F"))
+        nbin += 1
     path = tmp_path / "cases.bin"
-    path.write_bytes(struct.pack("<i", 60) + b"".join(blob))
+    path.write_bytes(struct.pack("<i", 60 + nbin) + b"".join(blob))
     res = subprocess.run([exe, str(path)], capture_output=True, text=True)
-    assert res.returncode == 0 and "60 of 60" in res.stdout, res.stdout + res.stderr
+    assert res.returncode == 0 and f"{60 + nbin} of {60 + nbin}" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.uint32, np.uint64, np.float32, np.float64])
+def test_binary_route_multivalued_labels(edt_gpu, oracle_port, dtype):
+    """edt_hip_binary_edtsq / EDT_FLAG_BINARY_YZ == pyedt::_binary_edt{2,3}dsq<T> (src/edt.hpp:487-576, :681-755) on
+    images holding the values {0,1,2,3}: runs split by label along x only.  Against the compiled reference where it is
+    built, else the oracle's restatement (pinned to it by tests/test_oracle.py).  Covers the wave kernels, the index
+    form and the fp32 form of pass X, odd extents, both border modes and the fused sqrt."""
+    from oracle import harness
+    chk = harness.ref() if harness.have_ref() else oracle_port
+    rng = np.random.default_rng(77)
+    differs = 0
+    for t, shape in enumerate([(37, 29, 31), (64, 64, 40), (96, 80), (33, 47), (130, 70, 36), (40, 300, 20)]):
+        lab = blocky_labels(shape, nlabels=3, zero_frac=0.3, block=int(rng.integers(1, 6)), rng=rng).astype(dtype)
+        if t % 2:
+            lab = np.asfortranarray(lab)
+        for an, bb in (((1, 1, 1), False), ((6, 6, 30), True), ((0.5, 0.7, 1.3), False)):
+            an = an[:lab.ndim]
+            want = chk.binary_edtsq(lab, an, bb)
+            got = edt_gpu.binary_edtsq(lab, anisotropy=an, black_border=bb)
+            assert same(got, want), (shape, an, bb, explain(got, want))
+            assert same(edt_gpu.binary_edt(lab, anisotropy=an, black_border=bb), np.sqrt(want))
+            differs += not same(want, edt_gpu.edtsq(lab, anisotropy=an, black_border=bb))
+    assert differs >= 6  # the route really differs from the multi-label transform on these inputs
+    # 0/1 input: both routes agree (and bool goes through the ordinary planes)
+    img = (rng.random((50, 41, 33)) < 0.7).astype(dtype)
+    assert same(edt_gpu.binary_edtsq(img, (6, 6, 30), True), edt_gpu.edtsq(img, (6, 6, 30), True))
 
 
 def test_device_resident_voxel_graph(edt_gpu):

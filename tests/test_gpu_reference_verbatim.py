@@ -36,7 +36,9 @@ def _cython_dir():
 
 
 def _run_suite(module_dir, expect_so):
-    env = dict(os.environ, PYTHONPATH=module_dir)
+    # (prepend: the driver's own PYTHONPATH entries -- its sitecustomize hook that records which .so files a python
+    # process maps -- must stay visible in the child)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([module_dir] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
     env.pop("EDT_HIP_DEBUG_MODE", None)
     probe = subprocess.run([sys.executable, "-c", "import edt; print(edt.__file__)"], env=env, capture_output=True,
                            text=True, timeout=300)
@@ -100,7 +102,7 @@ for c in load('edt_sdf_voxel_graph.npz'):
     n += 1
 print('ok', n)
 """
-    env = dict(os.environ, PYTHONPATH=moddir)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([moddir] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert res.stdout.strip().startswith("ok") and int(res.stdout.split()[-1]) > 50

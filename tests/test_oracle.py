@@ -169,3 +169,24 @@ def test_reference_fast_math_twin_agrees(oracle_ref):
     lab = np.asfortranarray(blocky_labels((40, 36, 28), 12, 0.1, 5, rng).astype(np.uint32))
     for an, bb in (((6, 6, 30), True), ((0.5, 0.7, 1.3), False)):
         assert same(oracle_ref.edtsq(lab, an, bb), fast.edtsq(lab, an, bb))
+
+
+def test_binary_route_against_compiled_reference(oracle_port, oracle_ref):
+    # pyedt::_binary_edt{2,3}dsq<T> for multi-valued non-bool T (src/edt.hpp:487-576, :681-732): labels split runs in
+    # pass 1 only; it differs from the multi-label transform as soon as two non-zero labels touch along y or z
+    rng = np.random.default_rng(21)
+    dtypes = [np.uint8, np.uint16, np.uint32, np.uint64, np.float32, np.float64, bool]
+    differs = 0
+    for t in range(84):
+        dims = 2 + t % 2
+        shape = tuple(int(rng.integers(1, 40)) for _ in range(dims))
+        lab = blocky_labels(shape, nlabels=int(rng.integers(1, 6)), zero_frac=float(rng.random() * 0.5),
+                            block=int(rng.integers(1, 7)), rng=rng).astype(dtypes[t % len(dtypes)])
+        if t % 3 == 0:
+            lab = np.asfortranarray(lab)
+        an = [(1, 1, 1), (6, 6, 30), (0.5, 0.7, 1.3), (4, 4, 40)][t % 4][:dims]
+        bb = bool(rng.integers(0, 2))
+        want = oracle_ref.binary_edtsq(lab, an, bb, parallel=1 + t % 2)
+        assert same(oracle_port.binary_edtsq(lab, an, bb), want), (t, shape, an, bb)
+        differs += not same(want, oracle_ref.edtsq(lab, an, bb))
+    assert differs > 10  # the case the facade used to get wrong is really exercised

@@ -378,6 +378,17 @@ def sharded_main(args, rank, world, dev):
     dist.barrier()
 
     ys, ye = plan.local_y()
+    # what travels: this rank's slab records for every OTHER rank (4 B x record length x its slices), max over ranks
+    sent = 0
+    if plan.records:
+        rec = [plan.ops.record_floats(plan.sx, b - a) for a, b in plan.yparts]
+        sent = 4 * (ze - zs) * sum(rec[h] for h in range(world) if h != rank)
+    else:
+        sent = 5 * sum((ze - zs) * (b - a) * plan.sx for h, (a, b) in enumerate(plan.yparts) if h != rank)
+    sent_t = torch.tensor([sent], dtype=torch.int64, device=dev)
+    dist.all_reduce(sent_t, op=dist.ReduceOp.MAX)
+    ksum = torch.tensor([sum(kernel_ms.values())], dtype=torch.float64, device=dev)
+    dist.all_reduce(ksum, op=dist.ReduceOp.MAX)
     cpu = None
     if kind == "ones":
         # correctness of the timed output: closed form of the all-ones box on this rank's y-slab
@@ -449,6 +460,15 @@ def sharded_main(args, rank, world, dev):
                        "output_verified": verified, "verified_by": how,
                        "single_gpu_same_workload": same_n1},
             "roofline": roofline,
+            # how to read a SCALE curve: per-rank kernel time (rank 0, per step, chunks summed), the slowest rank's
+            # kernel sum, what is left of the step once the kernels are subtracted (= the exposed part of the
+            # exchange + launch gaps; 0 when the exchange hides under the next chunk's kernels), and the bytes the
+            # busiest rank sends per step over xGMI (7 links x ~153 GB/s per GPU: bytes / (world - 1) per link)
+            "per_rank": {"kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                         "kernel_ms_sum_max_over_ranks": round(float(ksum.item()), 4),
+                         "exchange_ms_exposed": round(max(0.0, elapsed / args.steps * 1e3 - float(ksum.item())), 4),
+                         "bytes_exchanged": int(sent_t.item()),
+                         "link_floor_ms": round(int(sent_t.item()) / max(1, world - 1) / 153e9 * 1e3, 4) if world > 1 else 0.0},
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -549,6 +549,24 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
       touch.join();
       return run_multi(labels, dtype, sx, sy, sz, wx, wy, wz, flags, output, devs.data(), (int)devs.size());
     }
+    if (!devs.empty()) {
+      // a one-entry list, or a volume the slab-record form does not cover: the FIRST listed device does it alone
+      if (devs.size() >= 2) {
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+          fprintf(stderr, "[edt_hip] note: a %lld x %lld x %lld volume cannot be Z-sharded over %zu devices (slab records: "
+                          "sx <= 1024, sy and sz <= 2048, >= 1 z-slice and >= 32 y-rows per device); device %d runs it alone\n",
+                  (long long)sx, (long long)sy, (long long)sz, devs.size(), devs[0]);
+      }
+      int prev = 0;
+      EDT_HIP_TRY(hipGetDevice(&prev));
+      if (prev != devs[0]) {
+        EDT_HIP_TRY(hipSetDevice(devs[0]));
+        rc = run_host(labels, dtype, ndim, sx, sy, sz, wx, wy, wz, flags | EDT_FLAG_SINGLE_DEVICE, output);
+        (void)hipSetDevice(prev);
+        return rc;
+      }
+    }
   }
 
   const size_t lbytes = (size_t)voxels * dtype_size(dtype);
@@ -790,7 +808,12 @@ int edt_hip_edt3dsq_multi(const void *labels, int dtype, int64_t sx, int64_t sy,
   for (int i = 0; i < n_devices; ++i)
     if (devices[i] < 0 || devices[i] >= have) { set_error("device ordinal out of range"); return EDT_ERR_BAD_ARG; }
   const int flags = (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (take_sqrt ? EDT_FLAG_SQRT : 0);
-  if (!multi_supported(dtype, sx, sy, sz, n_devices)) {  // one device does it
+  if (n_devices >= 2 && !multi_supported(dtype, sx, sy, sz, n_devices)) {
+    set_error("this volume cannot be Z-sharded over " + std::to_string(n_devices) + " devices (slab records: sx <= 1024, sy "
+              "and sz <= 2048, at least one z-slice and 32 y-rows per device; edt_hip_multi_supported tells)");
+    return EDT_ERR_UNSUPPORTED;
+  }
+  if (n_devices == 1) {  // a list of one: that device does it
     int prev = 0;
     EDT_HIP_TRY(hipGetDevice(&prev));
     EDT_HIP_TRY(hipSetDevice(devices[0]));
@@ -801,6 +824,11 @@ int edt_hip_edt3dsq_multi(const void *labels, int dtype, int64_t sx, int64_t sy,
   Prefault touch(output, (size_t)(sx * sy * sz) * sizeof(float));
   touch.join();
   return run_multi(labels, dtype, sx, sy, sz, wx, wy, wz, flags, output, devices, n_devices);
+}
+
+int edt_hip_multi_supported(int dtype, int64_t sx, int64_t sy, int64_t sz, int n_devices) {
+  if (check_shape(dtype, 3, sx, sy, sz) != EDT_OK) return 0;
+  return (n_devices == 1 || multi_supported(dtype, sx, sy, sz, n_devices)) ? 1 : 0;
 }
 
 int edt_hip_sdf(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
@@ -827,6 +855,7 @@ int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, 
 }
 
 int edt_hip_release_cache(void) {
+  multi_release();
   int cur = 0;
   if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return EDT_OK; }
   for (int d = 0; d < kMaxDevices; ++d) {

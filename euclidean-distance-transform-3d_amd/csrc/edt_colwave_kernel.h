@@ -62,8 +62,13 @@ struct BruteArgs {
   float *compact;
   int64_t c_outer, c_row2;
   int c_al;             // its rows are whole 16-byte granules
+  // the bracket path (edt_colwave_lane.h: mono_band): tiles whose largest field value v satisfies
+  // mono_lo_bits < bits(v) <= mono_hi_bits (mono_hi_bits = 0: never; mono_force: every tile up to mono_hi_bits)
+  uint32_t mono_lo_bits, mono_hi_bits;
+  int mono_force;
 };
 int window_limit();  // edt_colwave.hip: largest window (rows) the windowed path is used for
+int mono_from();     // edt_colwave.hip: tiles with windows beyond this many rows take the bracket path (where it applies)
 
 namespace {
 
@@ -161,6 +166,43 @@ __device__ EDT_BRUTE_INLINE void brute_tile(float *tile, const uint32_t *alive, 
   // carried in an existing argument: the kernel around this call is sensitive to its signature, see hull path)
   if (epi & 0x100) brute_band<CW, BB, X32, 2>(BL, epi & 0x203, store);
   else brute_band<CW, BB, X32, 1>(BL, epi & 0x203, store);
+}
+
+// The bracket path of one lane (edt_colwave_lane.h: mono_anchor / mono_band).  The anchors' argmins cross bands
+// through one plane of LDS words (`anchors`: the break-scan plane of the windowed path, unused here) and one
+// workgroup barrier -- every thread of the workgroup takes this path together (the choice is per tile).
+template <int CW, bool BB>
+__device__ __forceinline__ void mono_tile(float *tile, const uint32_t *rsp, const uint32_t *lohi, uint32_t *anchors,
+                                          int n, int NB, int cols_left, int band, int col, float w, int epi,
+                                          float *dst0, int64_t dstride) {
+  using namespace edt_lane;
+  MonoLane ML;
+  ML.tile = tile;
+  ML.col = col;
+  ML.band = band;
+  ML.row0 = band * 32;
+  ML.n = n;
+  ML.rsw = rsp[addr_word<CW>(col, band)];
+  const uint32_t lh = lohi[addr_word<CW>(col, band)];
+  ML.lo_in = (int)(lh & 0xFFFFu) - 1;
+  ML.hi_out = (int)(lh >> 16) - 1;
+  ML.w2f = w * w;
+  ML.live = col < cols_left && band < NB;
+  if (!ML.live) ML.rsw = 0;
+  const float Fa = tile[addr_tile<CW>(col, ML.row0)];
+  const float Ba = mono_bound<CW, BB>(ML, 0, Fa);
+  float best0;
+  int A0;
+  mono_anchor<CW>(ML, Ba, Fa, best0, A0);
+  anchors[addr_word<CW>(col, band)] = (uint32_t)A0;
+  __syncthreads();
+  const int A32 = (ML.row0 + 32 < n) ? (int)anchors[addr_word<CW>(col, band + 1)] : n - 1;
+  auto *gdst = (__attribute__((address_space(1))) float *)dst0;
+  const bool colok = col < cols_left;
+  auto store = [&](int row, float v) {
+    if (row < n && colok) gdst[(int64_t)row * dstride] = v;
+  };
+  mono_band<CW, BB>(ML, best0, Ba, A0, A32, epi & 3, store);
 }
 
 // The hull path of one lane (phases 1-3 of edt_colwave_lane.h), inlined into the kernel (as a callee it would save
@@ -449,7 +491,10 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
       bscan[addr_word<CW>(L.colc, L.band)] = (uint32_t)(blo_in + 1) | ((uint32_t)bhi_out << 16);
       __syncthreads();
       const uint32_t tile_max = tmax[0], tile_brk = tmax[1];
-      if (tile_max <= ba.limit_bits && (tile_brk != 0u || ba.force)) {
+      // three forms: short windows (small fields), brackets (larger fields, exact arithmetic), hulls (the rest)
+      const bool mono = ba.mono_hi_bits != 0u && tile_max <= ba.mono_hi_bits &&
+                        (ba.mono_force || (tile_brk != 0u && tile_max > ba.mono_lo_bits));
+      if (mono || (tile_max <= ba.limit_bits && (tile_brk != 0u || ba.force))) {
         __syncthreads();  // (every thread has read tmax: the padding band it sits in may be filled now)
         // +inf around the columns: the padding bands and the rows that complete the last band
         for (int i = (int)threadIdx.x; i < 32 * TC; i += (int)blockDim.x)
@@ -474,6 +519,10 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
           }
         }
         // (bit 9, diagnostics: debug bit 0x80000 = no window at all, i.e. the fixed cost of the path; wrong results)
+        if (mono) {
+          mono_tile<CW, BB>(tile, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, dstep);
+          return;
+        }
         const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | (EDT_DIAG_BITS(dbg, 0x80000) ? 0x200 : 0) | (compact ? 0x400 : 0);
         if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
         else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
@@ -581,6 +630,15 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
     ba.limit_bits = force ? 0x7f800000u : bits;  // (forced: every tile, whatever it holds)
     ba.force = force ? 1 : 0;
     if (T < 1) ba.limit_bits = 0u;
+  }
+  // The bracket path (edt_colwave_lane.h: mono_limits has the conditions).  (debug bits: 0x800000 never, 0x400000
+  // every tile the exactness conditions allow, whatever its windows.)
+  ba.mono_lo_bits = ba.mono_hi_bits = 0u;
+  ba.mono_force = 0;
+  if (!(debug_mode() & 0x800000) && ba.stride == 1 && ba.compact == nullptr &&
+      edt_lane::mono_limits(w, (int)g.n, mono_from(), ba.mono_lo_bits, ba.mono_hi_bits)) {
+    ba.mono_force = (debug_mode() & 0x400000) ? 1 : 0;
+    if (ba.mono_hi_bits <= ba.mono_lo_bits && !ba.mono_force) ba.mono_hi_bits = 0u;
   }
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
   EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF, SC>)));

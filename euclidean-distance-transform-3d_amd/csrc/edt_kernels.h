@@ -140,6 +140,7 @@ bool row_codes_exact(float w, int64_t sx);
 namespace edt_amd {
 // ---- one process, several GPUs (host buffers): edt_multi.hip ----------------------------------------
 bool multi_supported(int dtype, int64_t sx, int64_t sy, int64_t sz, int n_devices);
+void multi_release();  // frees the per-slot pool (edt_hip_release_cache)
 int run_multi(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,
               int flags, float *output, const int *devices, int n_devices);
 }  // namespace edt_amd

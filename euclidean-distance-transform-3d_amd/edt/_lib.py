@@ -55,6 +55,7 @@ SIGNATURES = {
     "edt_hip_extract_runs_device": (_i, [_vp, _i, _i64, _vp, _i64, _vp, _vp, _sz, _vp]),
     "edt_hip_edt3dsq_multi": (_i, [_vp, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp, _vp, _i]),
     "edt_hip_set_devices": (_i, [_vp, _i]),
+    "edt_hip_multi_supported": (_i, [_i, _i64, _i64, _i64, _i]),
     "edt_hip_sdf": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp]),
     "edt_hip_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i64]),
     "edt_hip_workspace_bytes_flags": (_sz, [_i, _i, _i64, _i64, _i64, _i]),

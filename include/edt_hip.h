@@ -122,16 +122,23 @@ int edt_hip_binary_edtsq(const void *labels, int dtype, int ndim, int64_t sx, in
 
 /* ---- one process, several GPUs ---------------------------------------------------------------------
  * pyedt::_edt3dsq / _edt3d on host buffers, Z-sharded over the listed devices of this process (a host thread per
- * device; X and Y passes per Z-slab, ONE exchange of slab records as peer-to-peer copies over xGMI, Z pass per
- * Y-slab, each device copies its rows of the result straight into `output`).  Same result, bit for bit, as the
- * single-device entry points.  The same ordinal may be listed more than once (virtual devices: tests on one GPU).
- * Volumes the slab-record form does not cover run on devices[0] alone.
+ * device; X and Y passes per Z-slab in z-chunks, ONE exchange of slab records as peer-to-peer copies over xGMI --
+ * the copies of a chunk run under the kernels of the next --, Z pass per Y-slab, each device copies its rows of the
+ * result straight into `output`).  Same result, bit for bit, as the single-device entry points.  Device buffers and
+ * streams are kept between calls (edt_hip_release_cache frees them).  The same ordinal may be listed more than once
+ * (virtual devices: tests on one GPU).  Distinct ordinals must have peer access to each other: a pair without it is
+ * EDT_ERR_UNSUPPORTED naming the pair (EDT_HIP_ALLOW_STAGED_PEER=1 in the environment accepts staging through host
+ * memory).  A volume the slab-record form cannot cut n_devices ways (edt_hip_multi_supported == 0: sx > 1024, sy or
+ * sz > 2048, fewer z-slices or 32-row words of y than devices) is EDT_ERR_UNSUPPORTED too; n_devices = 1 runs on
+ * that device.
  * edt_hip_set_devices makes the ordinary host-buffer 3-D entry points (edt_hip_edt3dsq / edt_hip_edt3d, and with
- * them edt::edt<T>() and the Python / Cython front ends) take this route; n_devices = 0 restores the single-device
- * behaviour.  The environment variable EDT_HIP_DEVICES="0,1,2,..." presets the list. */
+ * them edt::edt<T>() and the Python / Cython front ends) take this route; volumes that cannot be cut that way (and
+ * every 1-D / 2-D call) run on the FIRST listed device, with one note on stderr; n_devices = 0 restores the
+ * current-device behaviour.  The environment variable EDT_HIP_DEVICES="0,1,2,..." presets the list. */
 int edt_hip_edt3dsq_multi(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
                           float wz, int black_border, int take_sqrt, float *output, const int *devices,
                           int n_devices);
+int edt_hip_multi_supported(int dtype, int64_t sx, int64_t sy, int64_t sz, int n_devices);
 int edt_hip_set_devices(const int *devices, int n_devices);
 
 /* sdf / sdfsq of the reference's Python layer (src/edt.pyx:121-158, :161-202): edt(labels) - edt(labels == 0)

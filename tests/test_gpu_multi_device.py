@@ -3,6 +3,7 @@ records, one peer-to-peer exchange).  The box has one GPU, so the device list re
 devices"): every code path of the driver runs -- partition, one-slice halo, per-destination records, the exchange as
 hipMemcpyPeerAsync, the Z pass per Y-slab, the strided copy back -- only the transfers stay on one device."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -34,8 +35,23 @@ def test_virtual_devices_match_the_oracle(edt_gpu, oracle_port, ndev, shape, dty
         want = oracle_port.edtsq(lab, an, bb)
         if sqrt:
             want = np.sqrt(want)
+        from edt import _lib
+        code = {1: _lib.U8, 2: _lib.U16, 4: _lib.U32, 8: _lib.U64}[np.dtype(dtype).itemsize]
+        if not _lib.load().edt_hip_multi_supported(code, shape[0], shape[1], shape[2], ndev):
+            # a volume that cannot be cut ndev ways is an error, not a silent single-device run
+            with pytest.raises(_lib.EdtHipError) as ei:
+                _multi(lab, an, bb, sqrt, [0] * ndev)
+            assert ei.value.code == -4
+            continue
         got = _multi(lab, an, bb, sqrt, [0] * ndev)
         assert np.array_equal(got, want, equal_nan=True), (ndev, shape, an, bb)
+        # the pool is warm now: a second transform allocates nothing and gives the same values; chunk counts 1 and 3
+        for chunks in ("1", "3"):
+            os.environ["EDT_HIP_MULTI_CHUNKS"] = chunks
+            try:
+                assert np.array_equal(_multi(lab, an, bb, sqrt, [0] * ndev), want, equal_nan=True), (ndev, shape, chunks)
+            finally:
+                os.environ.pop("EDT_HIP_MULTI_CHUNKS", None)
 
 
 def test_front_ends_take_the_route_when_devices_are_set(edt_gpu, oracle_port):

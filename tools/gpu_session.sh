@@ -65,6 +65,7 @@ PY
       EDT_HIP_DEBUG_MODE=0xC000 python tools/fuzz_gpu.py $((n / 2)) 63 2>&1 | tail -1
       EDT_HIP_DEBUG_MODE=0x2000 python tools/fuzz_gpu.py $((n / 2)) 64 2>&1 | tail -1
       EDT_HIP_DEBUG_MODE=0x100000 python tools/fuzz_gpu.py $((n / 2)) 65 2>&1 | tail -1
+      EDT_HIP_DEBUG_MODE=0x400000 python tools/fuzz_gpu.py $n 67 2>&1 | tail -1
       FUZZ_MAX_AXIS=2100 python tools/fuzz_gpu.py $((n / 2)) 66 2>&1 | tail -1 ;;
     run) "$@" ;;
     *) echo "unknown step $what" ;;

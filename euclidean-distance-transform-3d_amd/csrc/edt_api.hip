@@ -116,6 +116,7 @@ struct Plan {
   float *bufB = nullptr;
   int32_t *stack = nullptr;
   uint32_t *nz_y = nullptr, *rs_y = nullptr, *zs_y = nullptr, *nz_z = nullptr, *rs_z = nullptr;
+  unsigned char *line_ws = nullptr;  // scratch of the line pipeline when pass 1 runs over rows of more than 2048 voxels
   uint16_t *codes = nullptr;  // 16-bit distance indices of pass 1 (index form), one slab of xy_slab slices
   int64_t xy_slab = 0;        // slices per slab of the slab-wise X/Y passes (0: no index form for this shape)
   size_t bytes = 0;
@@ -185,6 +186,9 @@ static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, v
     if (p.xy_slab > 0) p.codes = c.take<uint16_t>((size_t)(p.xy_slab * sx * sy));
   }
   if (ndim == 1) (void)c.take<unsigned char>(line_workspace_bytes(sx));  // block scan + table of the 1-D pipeline
+  // rows too long for the row kernels (sx > 2048): pass 1 runs as the line pipeline over the stack of rows
+  if (ndim >= 2 && !row_pass_tiled_supported(sx) && !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic())
+    p.line_ws = c.take<unsigned char>(rows_line_workspace_bytes(sx, sy * sz));
   p.bytes = align_up(c.off, 256) + 256;
   return p;
 }
@@ -345,7 +349,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   } else {
     {
       ScopedPass t("x_pass", stream);
-      rc = launch_row_pass_serial(dtype, d_labels, cur, sx, sy * sz, wx, bb, bb ? 0 : 1, 0, stream);
+      // rows of more than 2048 voxels: one thread per VOXEL through the line pipeline (edt_line.hip); the
+      // thread-per-row kernel stays behind EDT_FLAG_FORCE_GENERIC as the cross-check it is
+      if (p.line_ws != nullptr) rc = launch_rows_line_pass(dtype, d_labels, cur, sx, sy * sz, wx, bb, bb ? 0 : 1, p.line_ws, stream);
+      else rc = launch_row_pass_serial(dtype, d_labels, cur, sx, sy * sz, wx, bb, bb ? 0 : 1, 0, stream);
       if (rc != EDT_OK) return rc;
     }
     {

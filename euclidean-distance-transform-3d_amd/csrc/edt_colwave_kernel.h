@@ -168,9 +168,13 @@ __device__ EDT_BRUTE_INLINE void brute_tile(float *tile, const uint32_t *alive, 
   else brute_band<CW, BB, X32, 1>(BL, epi & 0x203, store);
 }
 
-// The bracket path of one lane (edt_colwave_lane.h: mono_anchor / mono_band).  The anchors' argmins cross bands
+// The bracket path of one lane (edt_colwave_lane.h: mono_anchor / mono_band) -- EXPERIMENT, compiled into the kernel
+// only with -DEDT_MONO (make VARIANT=mono EXTRA=-DEDT_MONO): bit-exact (GPU parity suite + fuzz under debug bit 0x400000,
+// host emulation in the CPU tier) but not faster than the better of the two shipped forms at any cell size
+// (profiles/r03_mono_v1_*.txt), so the shipped kernels do not carry its code.  The anchors' argmins cross bands
 // through one plane of LDS words (`anchors`: the break-scan plane of the windowed path, unused here) and one
 // workgroup barrier -- every thread of the workgroup takes this path together (the choice is per tile).
+#ifdef EDT_MONO
 template <int CW, bool BB>
 __device__ __forceinline__ void mono_tile(float *tile, const uint32_t *rsp, const uint32_t *lohi, uint32_t *anchors,
                                           int n, int NB, int cols_left, int band, int col, float w, int epi,
@@ -204,6 +208,7 @@ __device__ __forceinline__ void mono_tile(float *tile, const uint32_t *rsp, cons
   };
   mono_band<CW, BB>(ML, best0, Ba, A0, A32, epi & 3, store);
 }
+#endif  // EDT_MONO
 
 // The hull path of one lane (phases 1-3 of edt_colwave_lane.h), inlined into the kernel (as a callee it would save
 // and restore 48 callee-saved registers per tile: cfg2 0.69 -> 1.04 ms, measured).  It RE-READS the lane's 32 rows
@@ -492,8 +497,12 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
       __syncthreads();
       const uint32_t tile_max = tmax[0], tile_brk = tmax[1];
       // three forms: short windows (small fields), brackets (larger fields, exact arithmetic), hulls (the rest)
+#ifdef EDT_MONO
       const bool mono = ba.mono_hi_bits != 0u && tile_max <= ba.mono_hi_bits &&
                         (ba.mono_force || (tile_brk != 0u && tile_max > ba.mono_lo_bits));
+#else
+      constexpr bool mono = false;
+#endif
       if (mono || (tile_max <= ba.limit_bits && (tile_brk != 0u || ba.force))) {
         __syncthreads();  // (every thread has read tmax: the padding band it sits in may be filled now)
         // +inf around the columns: the padding bands and the rows that complete the last band
@@ -519,10 +528,12 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
           }
         }
         // (bit 9, diagnostics: debug bit 0x80000 = no window at all, i.e. the fixed cost of the path; wrong results)
+#ifdef EDT_MONO
         if (mono) {
           mono_tile<CW, BB>(tile, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, dstep);
           return;
         }
+#endif
         const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | (EDT_DIAG_BITS(dbg, 0x80000) ? 0x200 : 0) | (compact ? 0x400 : 0);
         if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
         else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
@@ -635,11 +646,13 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   // every tile the exactness conditions allow, whatever its windows.)
   ba.mono_lo_bits = ba.mono_hi_bits = 0u;
   ba.mono_force = 0;
+#ifdef EDT_MONO
   if (!(debug_mode() & 0x800000) && ba.stride == 1 && ba.compact == nullptr &&
       edt_lane::mono_limits(w, (int)g.n, mono_from(), ba.mono_lo_bits, ba.mono_hi_bits)) {
     ba.mono_force = (debug_mode() & 0x400000) ? 1 : 0;
     if (ba.mono_hi_bits <= ba.mono_lo_bits && !ba.mono_force) ba.mono_hi_bits = 0u;
   }
+#endif
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
   EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF, SC>)));
   const int64_t tiles_x = ceil_div(g.sx, TC);

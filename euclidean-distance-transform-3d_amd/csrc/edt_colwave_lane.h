@@ -1092,6 +1092,9 @@ EDT_LANE void mono_anchor(const MonoLane &L, float Ba, float Fa, float &best, in
   best = Fa;
   int off = 0;
   float bnd = L.live ? minpos(Ba, Fa) : 0.0f;
+#if defined(EDT_MONO_SKIP) && (EDT_MONO_SKIP & 1)
+  bnd = 0.0f;  // (cost measurement: no anchor search; wrong results)
+#endif
   // (rows a - d, a + d for d <= 32 exist in the LDS image whatever a is: one band of +inf rows on either side)
   const float *P = L.tile + addr_tile<CW>(L.col, a);
   const float *Pm = L.tile + addr_tile<CW>(L.col, a - 32);  // the band below (its own column rotation)
@@ -1196,6 +1199,9 @@ EDT_LANE void mono_band(const MonoLane &L, float best0, float B0, int A0, int A3
   // (rows beyond the column do not exist: nothing is computed for them and their "argmin" is the last row)
   auto level_row = [&](int r, int lo, int hi) -> int {
     if (row0 + r >= n) return n - 1;
+#if defined(EDT_MONO_SKIP) && (EDT_MONO_SKIP & 2)
+    hi = lo;  // (cost measurement: one candidate per level row; wrong results)
+#endif
     const float Fp = own[r * TC];
     float best = Fp;
     int arg = row0 + r;
@@ -1221,7 +1227,11 @@ EDT_LANE void mono_band(const MonoLane &L, float best0, float B0, int A0, int A3
       Fp[i] = own[(8 * q + 1 + i) * TC];
       best[i] = Fp[i];
     }
+#if defined(EDT_MONO_SKIP) && (EDT_MONO_SKIP & 4)
+    mono_gap<CW>(L, p0, lo_of(Alo, Ahi), lo_of(Alo, Ahi), best);  // (cost measurement: one candidate per gap)
+#else
     mono_gap<CW>(L, p0, lo_of(Alo, Ahi), hi_of(Alo, Ahi), best);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif

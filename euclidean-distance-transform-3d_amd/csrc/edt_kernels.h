@@ -39,6 +39,10 @@ int launch_row_pass_serial(int dtype, const void *labels, float *out, int64_t sx
 size_t line_workspace_bytes(int64_t n);
 int launch_line_pass(int dtype, const void *labels, float *out, int64_t n, float w, int bb, int take_sqrt,
                      void *ws, hipStream_t stream);
+// pass 1 over rows of any length (sx > 2048): the line pipeline with a run start forced at every row's first voxel
+size_t rows_line_workspace_bytes(int64_t sx, int64_t nrows);
+int launch_rows_line_pass(int dtype, const void *labels, float *out, int64_t sx, int64_t nrows, float w, int bb,
+                          int to_finite, void *ws, hipStream_t stream);
 size_t runs_workspace_bytes(int64_t n);
 int launch_extract_runs(int dtype, const void *labels, int64_t n, int64_t *starts, int64_t capacity, int64_t *total,
                         void *ws, hipStream_t stream);

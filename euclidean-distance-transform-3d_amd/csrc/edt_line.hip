@@ -27,17 +27,22 @@ namespace {
 constexpr int kLineBlock = 1024;
 constexpr int64_t kNone = -1;
 
+// a run starts where the label changes -- and at the first voxel of every row when the array is a stack of rows
+// of `row` voxels (row = 0: one line)
 template <typename T>
-__device__ __forceinline__ bool line_starts(const T *lab, int64_t i) { return i == 0 || lab[i] != lab[i - 1]; }
+__device__ __forceinline__ bool line_starts(const T *lab, int64_t i, int64_t row = 0) {
+  return i == 0 || lab[i] != lab[i - 1] || (row > 0 && i % row == 0);
+}
 
 template <typename T>
 __global__ void __launch_bounds__(kLineBlock)
-k_line_marks(const T *__restrict__ lab, int64_t n, int64_t *__restrict__ blk_last, int64_t *__restrict__ blk_first) {
+k_line_marks(const T *__restrict__ lab, int64_t n, int64_t *__restrict__ blk_last, int64_t *__restrict__ blk_first,
+             int64_t row) {
   __shared__ int64_t s_last, s_first;
   if (threadIdx.x == 0) { s_last = 0; s_first = INT64_MAX; }  // s_last holds position + 1 (0: none)
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * kLineBlock + threadIdx.x;
-  if (i < n && line_starts(lab, i)) {
+  if (i < n && line_starts(lab, i, row)) {
     atomicMax((unsigned long long *)&s_last, (unsigned long long)(i + 1));
     atomicMin((unsigned long long *)&s_first, (unsigned long long)i);
   }
@@ -107,11 +112,12 @@ __global__ void k_line_ttab(float *__restrict__ ttab, float w, int64_t count) {
 template <typename T>
 __global__ void __launch_bounds__(kLineBlock)
 k_line_eval(const T *__restrict__ lab, float *__restrict__ out, int64_t n, const int64_t *__restrict__ blk_last,
-            const int64_t *__restrict__ blk_first, const float *__restrict__ ttab, float w, int bb, int take_sqrt) {
+            const int64_t *__restrict__ blk_first, const float *__restrict__ ttab, float w, int bb, int take_sqrt,
+            int64_t row, int to_finite) {
   __shared__ int64_t s_lo[kLineBlock], s_hi[kLineBlock];
   const int64_t i = (int64_t)blockIdx.x * kLineBlock + threadIdx.x;
   const bool in = i < n;
-  const bool st = in && line_starts(lab, i);
+  const bool st = in && line_starts(lab, i, row);
   // last start at or before i / first start after i, inside the block
   s_lo[threadIdx.x] = st ? i : kNone;
   s_hi[threadIdx.x] = st ? i : INT64_MAX;
@@ -132,10 +138,13 @@ k_line_eval(const T *__restrict__ lab, float *__restrict__ out, int64_t n, const
   float v = 0.0f;
   if (lab[i] != 0) {
     auto tk = [&](int64_t k) -> float { return ttab ? ttab[k] : (float)k * w; };
-    const float dl = (s > 0 || bb) ? tk(i - s + 1) : INFINITY;
-    const float dr = (e < n || bb) ? tk(e - i) : INFINITY;
+    // the ends of the line (of the voxel's row, for a stack of rows) are borders only with black_border
+    const int64_t r0 = row > 0 ? (i / row) * row : 0, r1 = row > 0 ? r0 + row : n;
+    const float dl = (s > r0 || bb) ? tk(i - s + 1) : INFINITY;
+    const float dr = (e < r1 || bb) ? tk(e - i) : INFINITY;
     const float d = dl < dr ? dl : dr;
     v = d * d;                       // `d[i] *= d[i]` (src/edt.hpp:116-118)
+    if (to_finite && v > 3.402823466e+38f) v = 3.402823466e+38f;  // tofinite (src/edt.hpp:39-45)
     if (take_sqrt) v = sqrtf(v);
   }
   out[i] = v;
@@ -153,7 +162,7 @@ bool multiples_exact(float w, int64_t kmax) {
 
 template <typename T>
 int launch_line_t(const void *labels, float *out, int64_t n, float w, int bb, int take_sqrt, void *ws,
-                  hipStream_t stream) {
+                  hipStream_t stream, int64_t row = 0, int to_finite = 0) {
   const T *lab = static_cast<const T *>(labels);
   const int64_t nblk = ceil_div(n, kLineBlock);
   if (nblk > 0x7FFFFFFF) { set_error("line too long"); return EDT_ERR_UNSUPPORTED; }
@@ -161,14 +170,15 @@ int launch_line_t(const void *labels, float *out, int64_t n, float w, int bb, in
   int64_t *blk_last = reinterpret_cast<int64_t *>(p);
   int64_t *blk_first = blk_last + nblk;
   float *ttab = nullptr;
-  if (!multiples_exact(w, n + 1)) {
+  const int64_t longest = row > 0 ? row : n;  // no run is longer than a row
+  if (!multiples_exact(w, longest + 1)) {
     ttab = reinterpret_cast<float *>(p + align_up((size_t)(2 * nblk) * sizeof(int64_t), 256));
-    hipLaunchKernelGGL(k_line_ttab, dim3(1), dim3(64), 0, stream, ttab, w, n + 2);
+    hipLaunchKernelGGL(k_line_ttab, dim3(1), dim3(64), 0, stream, ttab, w, longest + 2);
   }
-  hipLaunchKernelGGL(k_line_marks<T>, dim3((unsigned)nblk), dim3(kLineBlock), 0, stream, lab, n, blk_last, blk_first);
+  hipLaunchKernelGGL(k_line_marks<T>, dim3((unsigned)nblk), dim3(kLineBlock), 0, stream, lab, n, blk_last, blk_first, row);
   hipLaunchKernelGGL(k_line_scan, dim3(1), dim3(1024), 0, stream, blk_last, blk_first, nblk, n);
   hipLaunchKernelGGL(k_line_eval<T>, dim3((unsigned)nblk), dim3(kLineBlock), 0, stream, lab, out, n, blk_last,
-                     blk_first, ttab, w, bb, take_sqrt);
+                     blk_first, ttab, w, bb, take_sqrt, row, to_finite);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }
@@ -272,6 +282,29 @@ int launch_extract_runs(int dtype, const void *labels, int64_t n, int64_t *start
 size_t line_workspace_bytes(int64_t n) {
   const int64_t nblk = ceil_div(n, kLineBlock);
   return align_up((size_t)(2 * nblk) * sizeof(int64_t), 256) + align_up((size_t)(n + 2) * sizeof(float), 256) + 256;
+}
+
+// Pass 1 of a volume whose rows are too long for the wave / workgroup row kernels (sx > 2048), as ONE line of
+// nrows * sx voxels with a forced run start at every row's first voxel: block scan + table look-up, every voxel its
+// own thread (the size-agnostic kernel this replaces gave every ROW one thread).
+size_t rows_line_workspace_bytes(int64_t sx, int64_t nrows) {
+  const int64_t nblk = ceil_div(sx * nrows, kLineBlock);
+  return align_up((size_t)(2 * nblk) * sizeof(int64_t), 256) + align_up((size_t)(sx + 2) * sizeof(float), 256) + 256;
+}
+
+int launch_rows_line_pass(int dtype, const void *labels, float *out, int64_t sx, int64_t nrows, float w, int bb,
+                          int to_finite, void *ws, hipStream_t stream) {
+#define ROWS(T) return launch_line_t<T>(labels, out, sx * nrows, w, bb, 0, ws, stream, sx, to_finite)
+  switch (dtype) {
+    case EDT_U8: case EDT_BOOL: ROWS(uint8_t);
+    case EDT_U16: ROWS(uint16_t);
+    case EDT_U32: ROWS(uint32_t);
+    case EDT_U64: ROWS(uint64_t);
+    case EDT_F32: ROWS(float);
+    case EDT_F64: ROWS(double);
+    default: set_error("unknown dtype"); return EDT_ERR_BAD_ARG;
+  }
+#undef ROWS
 }
 
 int launch_line_pass(int dtype, const void *labels, float *out, int64_t n, float w, int bb, int take_sqrt,

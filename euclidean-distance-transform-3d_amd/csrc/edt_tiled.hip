@@ -41,7 +41,7 @@ namespace edt_amd {
 
 namespace {
 
-// exact (double)(d*d) for |d| < 4096
+// exact (double)(d*d) for |d| < 32768 (24-bit operands, the product fits 31 bits)
 __device__ __forceinline__ double sq_i(int d) { return (double)__mul24(d, d); }
 
 // value of parabola j (height Fj) at row p -- the reference's output expression
@@ -380,7 +380,11 @@ k_column_pass_tiled(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 // launcher
 // ---------------------------------------------------------------------------------------
 bool column_pass_tiled_supported(const AxisGeom &g) {
-  return g.nbands >= 1 && g.nbands * 8 <= 1024;  // C = 8 is the narrowest tile; rows < 4096
+  // one thread per (column, band), at most 1024 threads and 160 KiB of LDS per tile: 32 columns up to 1024 rows ...
+  // 8 columns up to 4096 rows, then 4 / 2 / 1 columns up to 8192 / 16384 / 32736 rows (narrow tiles: 16- / 8- / 4-byte
+  // row pieces, poorly coalesced -- still every band of every column has its own thread, where the size-agnostic
+  // kernel gives a whole column to one).  Row distances and their products stay below 2^31 (sq_i, edge_num).
+  return g.nbands >= 1 && g.nbands <= 1023;
 }
 
 template <int C, int EPI, bool BB>
@@ -422,6 +426,9 @@ int launch_column_pass_tiled(float *F, const uint32_t *nz, const uint32_t *rs, c
   if (NB * 32 <= 1024) return launch_tiled_c<32>(F, nz, rs, g, w, bb, epi, stream);
   if (NB * 16 <= 1024) return launch_tiled_c<16>(F, nz, rs, g, w, bb, epi, stream);
   if (NB * 8 <= 1024) return launch_tiled_c<8>(F, nz, rs, g, w, bb, epi, stream);
+  if (NB * 4 <= 1024) return launch_tiled_c<4>(F, nz, rs, g, w, bb, epi, stream);
+  if (NB * 2 <= 1024) return launch_tiled_c<2>(F, nz, rs, g, w, bb, epi, stream);
+  if (NB < 1024) return launch_tiled_c<1>(F, nz, rs, g, w, bb, epi, stream);
   set_error("axis too long for the tiled column pass");
   return EDT_ERR_UNSUPPORTED;
 }

@@ -161,7 +161,7 @@ int edt_hip_release_cache(void);
 /* bytes of scratch edt_hip_edtsq_device needs for a volume of this shape: the four bit planes of the column
  * passes (1/8 of a byte per voxel each: 0.5 GiB for 1024^3) plus one slab of 16-bit distance indices between
  * passes X and Y (2 bytes per voxel, never more than 256 MiB: larger volumes run those passes slab by slab).
- * Only a call that has to use the size-agnostic column kernels (an axis longer than 4095 voxels, or
+ * Only a call that has to use the size-agnostic column kernels (an axis longer than 32735 voxels, or
  * EDT_FLAG_FORCE_GENERIC) needs a second fp32 volume and the hull stacks as well (+ 8 bytes per voxel): ask
  * with the flags of the call. */
 size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz);

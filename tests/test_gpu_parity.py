@@ -94,8 +94,9 @@ def test_odd_extents(edt_gpu, oracle_port, shape, bb):
     assert same(got, want), explain(got, want)  # 0 ULP
 
 
-def test_long_axes_take_the_generic_path(edt_gpu, oracle_port):
-    # rows / columns far longer than any LDS tile (cf. automated_test.py:819-823)
+def test_long_rows_and_axes(edt_gpu, oracle_port):
+    # rows / columns far longer than any LDS tile (cf. automated_test.py:819-823).  Rows of more than 2048 voxels go
+    # through the line pipeline (one thread per voxel, csrc/edt_line.hip), not the thread-per-row fallback.
     rng = np.random.default_rng(5)
     for shape in ((5000, 3), (3, 5000), (46342, 1), (1, 46342)):
         lab = blocky_labels(shape, 4, 0.1, 37, rng).astype(np.float64)
@@ -104,6 +105,24 @@ def test_long_axes_take_the_generic_path(edt_gpu, oracle_port):
             got = edt_gpu.edtsq(lab, anisotropy=(1.0, 2.0), black_border=bb)
             assert same(got, want), (shape, bb, explain(got, want))
             assert not np.any(np.isnan(got))
+    # axes of 4097 .. 32735 rows: the workgroup-phased column kernel with 4 / 2 / 1 columns per tile (a thread per
+    # band of every column); beyond that the size-agnostic kernels
+    for shape in ((6, 9000), (3, 17000, 2), (2, 30000), (5, 4097, 3), (2, 33000)):
+        lab = np.asfortranarray(blocky_labels(shape, 3, 0.1, int(rng.integers(20, 3000)), rng).astype(np.uint8))
+        for an, bb in (((1.0, 1.0, 1.0)[:len(shape)], False), ((2.0, 0.5, 3.0)[:len(shape)], True)):
+            want = oracle_port.edtsq(lab, an, bb)
+            got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+            assert same(got, want), (shape, an, bb, explain(got, want))
+    # 3-D volumes with long x rows: exact and tabulated (0.7: sequentially rounded sums) voxel sizes, runs that span
+    # several 1024-voxel blocks, rows without any boundary (black_border off -> +inf / FLT_MAX before pass Y)
+    for shape, dt in (((2500, 40, 6), np.uint32), ((4100, 9, 33), np.uint8), ((2049, 3, 2), np.uint16)):
+        lab = np.asfortranarray(blocky_labels(shape, 3, 0.1, int(rng.integers(5, 900)), rng).astype(dt))
+        lab[:, 0, 0] = 1   # one row, one label: no boundary along x at all
+        for an in ((1.0, 1.0, 1.0), (0.7, 1.3, 2.0), (6.0, 6.0, 30.0)):
+            for bb in (False, True):
+                want = oracle_port.edtsq(lab, an, bb)
+                got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+                assert same(got, want), (shape, an, bb, explain(got, want))
 
 
 def test_extreme_anisotropy(edt_gpu, oracle_port):

@@ -11,7 +11,8 @@ from edt import device
 from synth import voronoi_labels
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dev = torch.device("cuda", 0)
-for nseeds in (8000, 2000, 500, 120, 30, 8):
+SEEDS = [int(v) for v in os.environ.get('WINDOW_SWEEP_SEEDS', '8000,2000,500,120,30,8').split(',')]
+for nseeds in SEEDS:
     lab_np = voronoi_labels((n, n, n), nseeds, seed=3, upsample=2, membrane=0.0)
     lab = torch.from_numpy(np.ascontiguousarray(lab_np.T).view(np.int32)).to(dev)
     out = torch.empty((n, n, n), dtype=torch.float32, device=dev)

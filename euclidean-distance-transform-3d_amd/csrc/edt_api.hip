@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -265,7 +266,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   Plan p = make_plan(dtype, ndim, sx, sy, sz, d_ws, flags);
   // (a workspace sized while the index form of pass 1 was switched off still serves: fp32 form)
   if (d_ws && ws_bytes < p.bytes && p.codes != nullptr) p = make_plan(dtype, ndim, sx, sy, sz, d_ws, flags | EDT_FLAG_NO_INDEX_FORM);
-  if (!d_ws || ws_bytes < p.bytes) {
+  // (1-D: the parallel line pipeline needs its block-scan scratch; a call without any -- the ABI of round 1 -- is
+  // served by the thread-per-row kernel instead of being refused)
+  const bool line_without_ws = ndim == 1 && (!d_ws || ws_bytes < p.bytes);
+  if (!line_without_ws && (!d_ws || ws_bytes < p.bytes)) {
     set_error("workspace too small: need " + std::to_string(p.bytes) +
               " bytes (edt_hip_workspace_bytes_flags with the flags of this call)");
     return EDT_ERR_BAD_ARG;
@@ -288,7 +292,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
 
   if (ndim == 1) {
     ScopedPass t("x_pass", stream);
-    if (force_generic_1d(flags)) return launch_row_pass_serial(dtype, d_labels, d_out, sx, 1, wx, bb, 0, want_sqrt, stream);
+    if (force_generic_1d(flags) || line_without_ws) return launch_row_pass_serial(dtype, d_labels, d_out, sx, 1, wx, bb, 0, want_sqrt, stream);
     return launch_line_pass(dtype, d_labels, d_out, sx, wx, bb, want_sqrt, d_ws, stream);
   }
 
@@ -503,10 +507,14 @@ struct Prefault {
     for (unsigned t = 0; t < n; ++t) {
       const size_t lo = (size_t)t * chunk, hi = std::min(bytes, lo + chunk);
       if (lo >= hi) break;
-      threads.emplace_back([base, lo, hi] {
-        for (size_t o = lo; o < hi; o += kPage) base[o] = 0;
-        base[hi - 1] = 0;
-      });
+      try {
+        threads.emplace_back([base, lo, hi] {
+          for (size_t o = lo; o < hi; o += kPage) base[o] = 0;
+          base[hi - 1] = 0;
+        });
+      } catch (const std::system_error &) {
+        break;  // no more threads to be had: the remaining pages are touched by the copy itself (slower, not wrong)
+      }
     }
   }
   void join() {

@@ -79,6 +79,10 @@ const char *edt_hip_version(void);
 /* ---- host-buffer entry points (numpy in / numpy out) ------------------------------
  * Pointers are HOST pointers; the call stages through device memory (H2D, kernels, D2H)
  * and is synchronous.  `output` must hold one float per voxel and is fully overwritten.
+ * `output` must NOT overlap `labels`: for results of 32 MiB and more, helper threads touch (write zeros into) the
+ * pages of `output` while the labels are still travelling to the device, so that the copy back runs at PCIe speed.
+ * For the same reason the contents of `output` are unspecified after a call that FAILED.
+ * (EDT_HIP_NO_PREFAULT=1 in the environment switches the helper threads off.)
  */
 
 /* replaces pyedt::squared_edt_1d_multi_seg<T>  (src/edt.hpp:70-119; bound at
@@ -175,7 +179,10 @@ int edt_hip_edt2dsq_batch(const void *labels, int dtype, int64_t sx, int64_t sy,
                           int black_border, int take_sqrt, float *output);
 
 /* ndim in {1,2,3}; unused extents must be 1.  flags: EDT_FLAG_*.  d_output may not alias
- * d_labels.  Implements _edt3dsq / _edt2dsq / squared_edt_1d_multi_seg (+ optional sqrt). */
+ * d_labels.  Implements _edt3dsq / _edt2dsq / squared_edt_1d_multi_seg (+ optional sqrt).
+ * ndim = 1: with edt_hip_workspace_bytes() of scratch the line runs through the parallel pipeline (a thread per
+ * voxel); with d_workspace = NULL (or too small) it is served by one thread walking the line -- correct, and slow
+ * for long lines. */
 int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy,
                          int64_t sz, float wx, float wy, float wz, int flags, float *d_output,
                          void *d_workspace, size_t workspace_bytes, void *stream);

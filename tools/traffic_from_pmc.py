@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_traffic.json from the PMC summaries of tools/profile_r02.sh: HBM bytes per launch and pass.
+"""profiles/<tag>_traffic.json from the PMC summaries of tools/gpu_session.sh pmc (tools/profile_r03.sh): HBM bytes per launch and pass.
 
 FETCH_SIZE / WRITE_SIZE are collected in separate rocprofv3 --pmc passes; unit KiB; corrected with the factors the
 calibration of this round found on copies of known size (profiles/r02_counter_calibration.txt): FETCH_SIZE x 2.0 for
@@ -10,7 +10,7 @@ import json, re, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 FETCH_FACTOR, WRITE_FACTOR, KIB = 2.0, 1.0, 1024
 out = {}
-for cfg in ("cfg2", "cfg3"):
+for cfg in ("cfg2", "cfg3", "cfg3m", "cfg3L", "cfg3La", "cfg3M", "cfg3Ma"):
     try:
         text = open(f"gpurun_out/pmc_{tag}{cfg}_summary.txt").read()
     except OSError:
@@ -42,7 +42,7 @@ for cfg in ("cfg2", "cfg3"):
     elif cols:
         res["y_pass"] = res["z_pass"] = entry(cols[0])
     out[cfg] = res
-out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_r02.sh), 512^3 uint32, counter unit KiB; "
+out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_session.sh pmc), 512^3 uint32, counter unit KiB; "
                 "FETCH_SIZE x 2.0 (4 B/lane and 16 B/lane reads), WRITE_SIZE x 1.0 -- profiles/r02_counter_calibration.txt; "
                 "tools/traffic_from_pmc.py")
 json.dump(out, open(f"gpurun_out/{tag}_traffic.json", "w"), indent=1)

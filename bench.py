@@ -60,7 +60,12 @@ def measured_traffic(kernel=None, config="cfg2"):
                 blob = json.load(f)
         except (OSError, ValueError):
             continue
-        entry = blob.get(config, blob) if isinstance(blob.get(config, None), dict) else blob
+        if isinstance(blob.get(config, None), dict):
+            entry = blob[config]
+        elif "x_pass" in blob and config == "cfg2":   # (round 1: one flat table, the headline configuration)
+            entry = blob
+        else:
+            continue                                    # this file has nothing for this configuration
         if kernel is None:
             ks = {k: v for k, v in entry.items() if isinstance(v, dict) and "total" in v}
             if ks:

@@ -20,10 +20,15 @@ extern template int launch_wave_c<1>(float *, const uint32_t *, const uint32_t *
 
 // Largest window of the windowed path (edt_colwave_lane.h: brute_band): a tile takes it when no row can be
 // improved by a row further than this away.  EDT_HIP_WINDOW_LIMIT overrides the default (experiments).
+// Round 3: since the far part of the window (d > 32) reads its rows through one address per eight steps, the
+// windowed path beats the hull path at EVERY cell size of the sweep (profiles/r03_window_sweep_far_addressing.txt:
+// 256-voxel cells 2.69 ms per 512^3 step against 2.93 ms on hulls), so the default limit is the longest axis the
+// wave kernels take; the hull path keeps the tiles that hold FLT_MAX (rows without any boundary, black_border off),
+// the all-flat tiles (its shortcut is cheaper) and voxel sizes whose c_d are not exact in fp32 far enough.
 int window_limit() {
   static const int v = [] {
     const char *e = getenv("EDT_HIP_WINDOW_LIMIT");
-    const int t = e ? atoi(e) : 192;
+    const int t = e ? atoi(e) : 1024;
     return t < 0 ? 0 : (t > 1024 ? 1024 : t);
   }();
   return v;

@@ -623,14 +623,15 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   if (ba.compact != nullptr) ba.stride = 2;  // (a compact destination has room for the even rows only)
   if (!(debug_mode() & 0x2000) && w * w >= 1.17549435e-38f && (double)w * (double)w < 1.0e30) {
     const bool force = (debug_mode() & 0x4000) != 0;
-    // The window limit: tools/window_sweep.py (smooth Voronoi cells of growing size, 512^3) puts the
-    // crossover with the hull path between windows of ~170 and ~270 rows.  fp32 candidates need c_d exact in
+    // The window limit (edt_colwave.hip: window_limit).  fp32 candidates need c_d exact in
     // fp32 up to the limit (w2 = 900: d <= 136): where exactness ends between 64 rows and the limit, the limit
     // is lowered to it (fp32 candidates are ~25 % cheaper than fp64 ones; the tiles in between go to the hulls).
     int T = force ? (int)g.n : window_limit();
     const int exact = edt_lane::brute_exact_prefix(w, T);
     bool x32 = exact >= T;
     if (!x32 && !force && exact >= 64) { T = exact; x32 = true; }
+    // (fp64 candidates walk their far rows one by one: beyond ~190 rows the hull path is the better form for them)
+    if (!x32 && !force && T > 192) T = 192;
     if (debug_mode() & 0x8000) x32 = false;  // diagnostics: fp64 candidates
     ba.x32 = x32 ? 1 : 0;
     const double cT = (double)(w * w) * (double)T * (double)T;

@@ -815,10 +815,9 @@ struct BruteSteps {
         rlo[s % R] = w[K - s];
         rhi[s % R] = w[K + NR - 1 + s];
       }
-      auto row_at = [&](int r) -> float {
-        r = r < -1 ? -1 : (r > nb32 ? nb32 : r);
-        return L.tile[addr_tile<CW>(L.col, r)];
-      };
+      // (eight consecutive steps read one band's worth of rows on either side through one address each: see the
+      // stride-1 form below; p0 and NR are multiples of 8 here too)
+      const float *slo = L.tile, *shi = L.tile;
       for (int d0 = K + 1; d0 < 4096; d0 += R) {
         bool done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -830,9 +829,16 @@ struct BruteSteps {
           const double c = w2 * (double)(d * d);  // exact, and so is its fp32 form (X32)
           const float cf = (float)c;
           if (!EDT_ANY(c < bmax64)) { done = true; break; }
+          if (e % 8 == 0) {
+            int rl = p0 - d - 7, rh = p0 + NR - 1 + d;
+            rl = rl < -32 ? -32 : rl;
+            rh = rh > nb32 + 24 ? nb32 + 24 : rh;
+            slo = L.tile + addr_tile<CW>(L.col, rl);
+            shi = L.tile + addr_tile<CW>(L.col, rh);
+          }
           const int sl = (1 + e) % R;
-          rlo[sl] = row_at(p0 - d);
-          rhi[sl] = row_at(p0 + NR - 1 + d);
+          rlo[sl] = slo[(7 - e % 8) * TC];
+          rhi[sl] = shi[(e % 8) * TC];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -880,10 +886,11 @@ struct BruteSteps {
         rlo[s % R] = w[K - s];
         rhi[s % R] = w[K + B - 1 + s];
       }
-      auto row_at = [&](int r) -> float {
-        r = r < -1 ? -1 : (r > nb32 ? nb32 : r);
-        return L.tile[addr_tile<CW>(L.col, r)];
-      };
+      // Eight consecutive steps read the rows p0-d-7 .. p0-d and p0+B-1+d .. p0+B+6+d: p0 is a multiple of 8 and
+      // d = 1 (mod 8) at the first of them, so either stretch starts at a multiple of 8 and lies inside ONE band --
+      // one address (with that band's column rotation) serves all eight rows through constant offsets.  A stretch
+      // beyond the column is moved onto +inf rows of the padding (rows -32 .. -1 / n .. nb32 + 31 all hold +inf).
+      const float *slo = L.tile, *shi = L.tile;
       for (int d0 = K + 1; d0 < 4096; d0 += R) {
         bool done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -895,11 +902,18 @@ struct BruteSteps {
           const double c1 = w2 * (double)(d * d), c2 = w2 * (double)((d + 1) * (d + 1));  // exact
           const float c1f = (float)c1, c2f = (float)c2;                                   // (X32: exact as well)
           if (!EDT_ANY(c1 < bmax64)) { done = true; break; }
+          if (e % 8 == 0) {
+            int rl = p0 - d - 7, rh = p0 + B - 1 + d;
+            rl = rl < -32 ? -32 : rl;
+            rh = rh > nb32 + 24 ? nb32 + 24 : rh;
+            slo = L.tile + addr_tile<CW>(L.col, rl);
+            shi = L.tile + addr_tile<CW>(L.col, rh);
+          }
           const int s1 = (1 + e) % R, s2 = (2 + e) % R;
-          rlo[s1] = row_at(p0 - d);
-          rhi[s1] = row_at(p0 + B - 1 + d);
-          rlo[s2] = row_at(p0 - d - 1);
-          rhi[s2] = row_at(p0 + B + d);
+          rlo[s1] = slo[(7 - e % 8) * TC];
+          rhi[s1] = shi[(e % 8) * TC];
+          rlo[s2] = slo[(6 - e % 8) * TC];
+          rhi[s2] = shi[(e % 8 + 1) * TC];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif

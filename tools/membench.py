@@ -25,7 +25,7 @@ cfg = os.environ.get("MB_CFG", "cfg2")
 lab_np, an, bb = config_volume(cfg, n)
 lab = torch.from_numpy(np.ascontiguousarray(lab_np.T).view(np.int32)).to(dev); out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
 plan = device.Plan((n, n, n), 2, dev)
-for mode in [int(m) for m in os.environ.get('MB_MODES', '0,14').split(',')]:
+for mode in [int(m, 0) for m in os.environ.get('MB_MODES', '0,14').split(',')]:
     lib.edt_hip_set_debug_mode(mode)
     device.set_profiling(True)
     acc = {}

@@ -818,17 +818,19 @@ struct BruteSteps {
       // (eight consecutive steps read one band's worth of rows on either side through one address each: see the
       // stride-1 form below; p0 and NR are multiples of 8 here too)
       const float *slo = L.tile, *shi = L.tile;
+      // c_d and its first difference, stepped by exact fp32 additions (X32: every c_d the loop can use is
+      // representable, and so is w2 * (2d + 1); past the limit only the exit test sees them, and rounding is monotone)
+      float cf = w2f * (float)((K + 1) * (K + 1)), gf = w2f * (float)(2 * (K + 1) + 1);
+      const float g2 = w2f + w2f;
       for (int d0 = K + 1; d0 < 4096; d0 += R) {
         bool done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int e = 0; e < R; ++e) {  // step d = d0 + e;  d mod R == (1 + e) mod R
+        for (int e = 0; e < R; ++e, cf += gf, gf += g2) {  // step d = d0 + e;  d mod R == (1 + e) mod R
           const int d = d0 + e;
           if (e % 4 == 0) refresh_bound();
-          const double c = w2 * (double)(d * d);  // exact, and so is its fp32 form (X32)
-          const float cf = (float)c;
-          if (!EDT_ANY(c < bmax64)) { done = true; break; }
+          if (!EDT_ANY(cf < bmaxf)) { done = true; break; }
           if (e % 8 == 0) {
             int rl = p0 - d - 7, rh = p0 + NR - 1 + d;
             rl = rl < -32 ? -32 : rl;
@@ -891,6 +893,8 @@ struct BruteSteps {
       // one address (with that band's column rotation) serves all eight rows through constant offsets.  A stretch
       // beyond the column is moved onto +inf rows of the padding (rows -32 .. -1 / n .. nb32 + 31 all hold +inf).
       const float *slo = L.tile, *shi = L.tile;
+      float cf = w2f * (float)((K + 1) * (K + 1)), gf = w2f * (float)(2 * (K + 1) + 1);
+      const float g2 = w2f + w2f;
       for (int d0 = K + 1; d0 < 4096; d0 += R) {
         bool done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -899,9 +903,11 @@ struct BruteSteps {
         for (int e = 0; e < R; e += 2) {  // steps d, d + 1 with d = d0 + e;  d mod R == (1 + e) mod R
           const int d = d0 + e;
           if (e % 4 == 0) refresh_bound();
-          const double c1 = w2 * (double)(d * d), c2 = w2 * (double)((d + 1) * (d + 1));  // exact
-          const float c1f = (float)c1, c2f = (float)c2;                                   // (X32: exact as well)
-          if (!EDT_ANY(c1 < bmax64)) { done = true; break; }
+          // c_d, c_(d+1) by exact fp32 additions (see the stride-2 form above)
+          const float c1f = cf, c2f = cf + gf;
+          cf = c2f + (gf + g2);
+          gf += g2 + g2;
+          if (!EDT_ANY(c1f < bmaxf)) { done = true; break; }
           if (e % 8 == 0) {
             int rl = p0 - d - 7, rh = p0 + B - 1 + d;
             rl = rl < -32 ? -32 : rl;
@@ -921,8 +927,7 @@ struct BruteSteps {
             // row p0+i-d entered at step d-i, row p0+i+d at step d-(B-1-i)
             const float m1 = minpos(rlo[(s1 - i + R) % R], rhi[(s1 - (B - 1 - i) + R) % R]);
             const float m2 = minpos(rlo[(s2 - i + R) % R], rhi[(s2 - (B - 1 - i) + R) % R]);
-            if (X32) best[i] = min3pos(best[i], m1 + c1f, m2 + c2f);
-            else best64[i] = fmin(best64[i], fmin((double)m1 + c1, (double)m2 + c2));
+            best[i] = min3pos(best[i], m1 + c1f, m2 + c2f);  // (this form is X32 only)
           }
         }
         if (done) break;

@@ -6,17 +6,21 @@ For N > 1 it is launched under torch.distributed.run, one rank per GPU (RCCL).
 
   * N = 1 headline workload = BASELINE.json configs[1]: 512^3 uint32 single label, anisotropy
     (6,6,30), black_border=True, labels and output resident in HBM (no PCIe in the timed region).
-    The same line carries a `secondary` list: configs[2] (cfg3: 512^3, 2000 labels, black_border=False),
-    its membrane / anisotropic twin (cfg3m) and the 1024^3 segmentation of configs[3] on ONE GPU (cfg4),
-    each with ms_per_step, per-kernel times and the 32 B/voxel whole-job fraction, cfg3 / cfg3m checked
-    bit for bit against the compiled reference on this host.
+    The same line carries a `secondary` list: configs[2] (cfg3: 512^3, 2000 labels, black_border=False), its
+    membrane / anisotropic twin (cfg3m), four large-cell segmentations (cfg3L / cfg3La / cfg3M / cfg3Ma: full-resolution
+    Voronoi cells ~130 / ~65 voxels across), the 1024^3 segmentation of configs[3] on ONE GPU (cfg4), configs[4]
+    (cfg5: voxel graph) and `snemi_like` (the reference README's 334-label extraction workload) -- each with
+    ms_per_step, per-kernel times and the 32 B/voxel whole-job fraction, and EVERY ONE checked bit for bit against
+    the compiled reference on this host (`output_verified`; EDT_BENCH_VERIFY=0 skips the checks).
   * N > 1 workload = ONE global multi-label volume with 512^3 voxels PER GPU (N=8 -> the 1024^3
     segmentation of BASELINE configs[3]), Z-sharded; the X and Y passes are slab-local, ONE all-to-all
     (RCCL send/recv group over xGMI) re-partitions Z-slabs into Y-slabs before the Z pass.  Weak scaling.
   * a "step" = one complete edtsq of the (local part of the) volume.
   * roofline: dominant kernel's ALGORITHMIC bytes (pass X reads labels + writes
     fp32, passes Y/Z read labels + read/write fp32 -> 8 / 12 / 12 B per uint32 voxel) divided
-    by its duration measured with hipEvents inside the library on the launch stream.
+    by its duration measured with hipEvents inside the library on the launch stream; beside that
+    model, `real_*`: the bytes the kernels really move (PMC of a committed profile, `traffic_source`)
+    over this run's times, against the 8 TB/s spec and the ~6.3 TB/s a streaming kernel reaches.
   * cpu_baseline: the real reference (oracle/_ref, compiled from the reference sources) on
     this host's cores: the headline volume and the cfg3 volume, 1 thread and all threads,
     1 warm-up + best of 3, CPU model stated.

@@ -548,7 +548,7 @@ def _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)   # 0.65 s of timed kernels: long enough for a busy-sampler to see
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=512, help="edge length of the per-GPU volume")
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg3m", "cfg4", "cfg5", "cfg3L", "cfg3La",
@@ -643,7 +643,7 @@ def main():
                 continue
             try:
                 run = DeviceRun(name, size, dev)
-                s, kern, _ = run.measure(max(5, args.steps // 2) if size > n else args.steps, args.warmup)
+                s, kern, _ = run.measure(max(5, min(args.steps, 200) // 2) if size > n else min(args.steps, 400), args.warmup)
                 entry = {"config": name,
                          "workload": f"{size}^3 uint32 multi-label: {what[name]}, anisotropy {tuple(run.an)}, "
                                      f"black_border={run.bb}, device-resident in/out, 1 GPU", **s}
@@ -663,7 +663,7 @@ def main():
                 secondary.append({"config": name, "error": repr(e)})
         if not only or "cfg5" in only:
             try:
-                secondary.append(voxel_graph_secondary(n, dev, max(5, args.steps // 4), args.warmup,
+                secondary.append(voxel_graph_secondary(n, dev, max(5, min(args.steps, 200) // 4), args.warmup,
                                                        lib if kind == "reference" else None))
             except Exception as e:  # pragma: no cover
                 secondary.append({"config": "cfg5", "error": repr(e)})

@@ -107,3 +107,49 @@ def test_large_result_buffer_is_prefaulted_correctly(edt_gpu, oracle_port):
     want = oracle_port.edtsq(lab, (1.0, 1.0, 2.0), False)
     for _ in range(2):
         assert np.array_equal(edt_gpu.edtsq(lab, anisotropy=(1.0, 1.0, 2.0), black_border=False), want)
+
+
+def test_line_without_workspace_is_served(edt_gpu, oracle_port):
+    """edt_hip_edtsq_device(ndim = 1, d_workspace = NULL): the round-1 ABI needed no scratch for a line; the parallel
+    pipeline does, and a call without it is served by the row kernel instead of being refused."""
+    import ctypes
+    import torch
+    from edt import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    lab = blocky_labels((20000,), nlabels=4, zero_frac=0.2, block=311, rng=rng).astype(np.uint16)
+    t = torch.from_numpy(lab.view(np.int16)).cuda()
+    out = torch.empty(lab.size, dtype=torch.float32, device="cuda")
+    for bb in (False, True):
+        rc = lib.edt_hip_edtsq_device(t.data_ptr(), _lib.U16, 1, lab.size, 1, 1, 3.0, 1.0, 1.0,
+                                      _lib.FLAG_BLACK_BORDER if bb else 0, out.data_ptr(), None, 0, None)
+        _lib.check(rc)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), oracle_port.edtsq(lab, 3.0, bb))
+    # 2-D without a workspace is still an argument error (it has no scratch-free form)
+    rc = lib.edt_hip_edtsq_device(t.data_ptr(), _lib.U16, 2, 100, 200, 1, 1.0, 1.0, 1.0, 0, out.data_ptr(), None, 0, None)
+    assert rc == -2
+
+
+def test_binary_route_through_every_kernel_family(edt_gpu, oracle_port):
+    """EDT_FLAG_BINARY_YZ (one all-foreground run per column) through the other forms of the same passes: fp32 instead
+    of 16-bit indices between X and Y, hulls only, windows on every tile, the workgroup-phased row / column kernels, and
+    the size-agnostic kernels (long axis)."""
+    from edt import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    lab = np.asfortranarray(blocky_labels((70, 90, 41), nlabels=3, zero_frac=0.35, block=6, rng=rng).astype(np.uint16))
+    want = oracle_port.binary_edtsq(lab, (2.0, 1.0, 3.0), False)
+    try:
+        for mode in (0, 0x100000, 0x2000, 0x4000, 0xC000, 32 | 64):
+            lib.edt_hip_set_debug_mode(mode)
+            got = edt_gpu.binary_edtsq(lab, anisotropy=(2.0, 1.0, 3.0), black_border=False)
+            assert np.array_equal(got, want), hex(mode)
+    finally:
+        lib.edt_hip_set_debug_mode(0)
+    long_axis = np.asfortranarray(blocky_labels((5, 33000), nlabels=3, zero_frac=0.3, block=700, rng=rng).astype(np.uint8))
+    assert np.array_equal(edt_gpu.binary_edtsq(long_axis, anisotropy=(1.0, 2.0), black_border=True),
+                          oracle_port.binary_edtsq(long_axis, (1.0, 2.0), True))
+    long_row = np.asfortranarray(blocky_labels((3000, 7, 3), nlabels=3, zero_frac=0.3, block=300, rng=rng).astype(np.uint32))
+    assert np.array_equal(edt_gpu.binary_edtsq(long_row, anisotropy=(1.0, 2.0, 0.5), black_border=False),
+                          oracle_port.binary_edtsq(long_row, (1.0, 2.0, 0.5), False))

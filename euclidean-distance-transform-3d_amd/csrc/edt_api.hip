@@ -963,7 +963,12 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
                          stream);
     if (rc != EDT_OK) return rc;
   } else {
-    rc = launch_row_pass_serial(dtype, d_labels, xout, sx, sy * sz_local, wx, bb, bb ? 0 : 1, 0, stream);
+    // rows of more than 2048 voxels: the line pipeline (a thread per voxel), its scratch borrowed from the hull
+    // stacks, which only the size-agnostic column pass uses -- later on this stream
+    if (!force_generic && rows_line_workspace_bytes(sx, sy * sz_local) <= (size_t)(sx * sy * sz_local) * sizeof(int32_t))
+      rc = launch_rows_line_pass(dtype, d_labels, xout, sx, sy * sz_local, wx, bb, bb ? 0 : 1, p.stack, stream);
+    else
+      rc = launch_row_pass_serial(dtype, d_labels, xout, sx, sy * sz_local, wx, bb, bb ? 0 : 1, 0, stream);
     if (rc != EDT_OK) return rc;
     rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz, p.rs, gy, stream);
     if (rc != EDT_OK) return rc;

@@ -65,7 +65,7 @@ def test_axes_beyond_the_wave_kernels(edt_gpu, oracle_port):
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-@pytest.mark.parametrize("shape", [(96, 80, 72), (512, 64, 40), (40, 24, 33)])
+@pytest.mark.parametrize("shape", [(96, 80, 72), (512, 64, 40), (40, 24, 33), (2200, 36, 10)])  # (the last: rows beyond the row kernels)
 def test_shard_phases_as_virtual_ranks(edt_gpu, oracle_port, world, shape):
     import torch
     from edt import _lib

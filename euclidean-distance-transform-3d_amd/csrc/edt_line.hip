@@ -7,10 +7,10 @@
 // (a side counts only if there is a neighbour run / background there, or black_border), result fl32(d*d).
 // Run starts are found per 1024-voxel block; the last start before and the first start after every block
 // come from ONE small scan over the blocks, so a run may span any number of blocks.
-//   k_line_marks : per block, position of its last / first run start
+//   k_line_marks : per block, position of its last / first run start (one ballot per wave)
 //   k_line_scan  : exclusive prefix max / suffix min over the blocks (one workgroup)
-//   k_line_eval  : per voxel, nearest run start on either side (block scan in LDS + the carried values),
-//                  table look-up, square (+ optional sqrt)
+//   k_line_eval  : per voxel, nearest run start on either side (bit scans of the block's sixteen ballot masks + the
+//                  carried values), table look-up, square (+ optional sqrt)
 // T is exact as k*w when w = m * 2^e with m*(n+1) < 2^24 (all the usual anisotropies); otherwise it is
 // tabulated once by a single thread -- the sums are sequentially rounded, there is no closed form.
 #include "edt_common.h"
@@ -25,74 +25,108 @@ namespace edt_amd {
 namespace {
 
 constexpr int kLineBlock = 1024;
-constexpr int64_t kNone = -1;
+constexpr int kNoneLo = -1;           // "no run start below" (positions are row-relative 32-bit ints: extents < 2^31)
+constexpr int kNoneHi = 0x7FFFFFFF;   // "no run start above"
 
-// a run starts where the label changes -- and at the first voxel of every row when the array is a stack of rows
-// of `row` voxels (row = 0: one line)
+// a run starts where the label changes (run extraction: one flat array)
 template <typename T>
-__device__ __forceinline__ bool line_starts(const T *lab, int64_t i, int64_t row = 0) {
-  return i == 0 || lab[i] != lab[i - 1] || (row > 0 && i % row == 0);
+__device__ __forceinline__ bool line_starts(const T *lab, int64_t i) { return i == 0 || lab[i] != lab[i - 1]; }
+
+// Where a block of the line pipeline sits.  The array is `rows` rows of `row` voxels (one line: rows = 1); every row is
+// cut into `bpr` blocks of 1024 voxels of its own (a block never straddles two rows, so no voxel needs a 64-bit
+// division to find its row: one 32-bit division of the block index per thread).  Positions INSIDE the kernels are
+// row-relative 32-bit integers (x); only the final addresses are 64-bit.
+struct LinePos {
+  int64_t r0;     // first voxel of this thread's row (global index)
+  int x;          // position of this thread's voxel in its row
+  unsigned bx;    // block of the row
+  bool in;        // the voxel exists
+};
+__device__ __forceinline__ LinePos line_pos(int64_t row, unsigned bpr) {
+  const unsigned b = blockIdx.x, r = b / bpr;
+  LinePos p;
+  p.bx = b - r * bpr;
+  p.x = (int)(p.bx * kLineBlock + threadIdx.x);
+  p.r0 = (int64_t)r * row;
+  p.in = (int64_t)p.x < row;
+  return p;
 }
+
+// The run starts of a 1024-voxel block as sixteen 64-bit masks (one ballot per wave) in LDS, plus ONE 16-bit word
+// saying which waves have any: the nearest start below / above a voxel is then a handful of bit operations -- own
+// mask, else the nearest wave with a start (one bit scan of the 16-bit word) and a bit scan of that wave's mask, else
+// the block's carried value.  No loops, no 64-bit positions.  (Round 2 ran two ten-step Hillis-Steele scans over int64
+// positions in LDS per block; the first ballot version walked the masks in per-lane loops and paid ~450 instructions per
+// wave, most of them scalar: profiles/r03_long_shapes_*.txt.)
+constexpr int kLineWaves = kLineBlock / 64;
+
+__device__ __forceinline__ int hi_bit64(unsigned long long m) { return 63 - __builtin_clzll(m); }
+__device__ __forceinline__ int lo_bit64(unsigned long long m) { return __builtin_ctzll(m); }
 
 template <typename T>
 __global__ void __launch_bounds__(kLineBlock)
-k_line_marks(const T *__restrict__ lab, int64_t n, int64_t *__restrict__ blk_last, int64_t *__restrict__ blk_first,
-             int64_t row) {
-  __shared__ int64_t s_last, s_first;
-  if (threadIdx.x == 0) { s_last = 0; s_first = INT64_MAX; }  // s_last holds position + 1 (0: none)
+k_line_marks(const T *__restrict__ lab, int *__restrict__ blk_last, int *__restrict__ blk_first, int64_t row,
+             unsigned bpr) {
+  __shared__ unsigned long long s_mask[kLineWaves];
+  const LinePos p = line_pos(row, bpr);
+  const int64_t i = p.r0 + p.x;
+  const unsigned long long m = __ballot(p.in && (p.x == 0 || lab[i] != lab[i - 1]));
+  if ((threadIdx.x & 63) == 0) s_mask[threadIdx.x >> 6] = m;
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * kLineBlock + threadIdx.x;
-  if (i < n && line_starts(lab, i, row)) {
-    atomicMax((unsigned long long *)&s_last, (unsigned long long)(i + 1));
-    atomicMin((unsigned long long *)&s_first, (unsigned long long)i);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    blk_last[blockIdx.x] = s_last - 1;
-    blk_first[blockIdx.x] = s_first;
+  if (threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x;
+    const unsigned long long mw = lane < kLineWaves ? s_mask[lane] : 0ull;
+    const unsigned has = (unsigned)__ballot(mw != 0ull);
+    if (lane == 0) {
+      const int base = (int)(p.bx * kLineBlock);
+      int last = kNoneLo, first = kNoneHi;
+      if (has) {
+        const int wl = 31 - __builtin_clz(has), wf = __builtin_ctz(has);
+        last = base + wl * 64 + hi_bit64(s_mask[wl]);
+        first = base + wf * 64 + lo_bit64(s_mask[wf]);
+      }
+      blk_last[blockIdx.x] = last;
+      blk_first[blockIdx.x] = first;
+    }
   }
 }
 
-// in place: blk_last[b] <- last run start in blocks < b (or -1); blk_first[b] <- first run start in blocks > b (or n)
-__global__ void __launch_bounds__(1024) k_line_scan(int64_t *blk_last, int64_t *blk_first, int64_t nblk, int64_t n) {
-  __shared__ int64_t buf[1024];
-  // prefix max, chunk by chunk
-  int64_t carry = kNone;
+// One line only: in place, blk_last[b] <- last run start in blocks < b (or -1); blk_first[b] <- first run start in
+// blocks > b (or n).
+__global__ void __launch_bounds__(1024) k_line_scan(int *blk_last, int *blk_first, int64_t nblk, int n) {
+  __shared__ int buf[1024];
+  int carry = kNoneLo;
   for (int64_t base = 0; base < nblk; base += 1024) {
     const int64_t b = base + threadIdx.x;
-    int64_t v = b < nblk ? blk_last[b] : kNone;
-    buf[threadIdx.x] = v;
+    buf[threadIdx.x] = b < nblk ? blk_last[b] : kNoneLo;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-      const int64_t t = threadIdx.x >= (unsigned)d ? buf[threadIdx.x - d] : kNone;
+      const int t = threadIdx.x >= (unsigned)d ? buf[threadIdx.x - d] : kNoneLo;
       __syncthreads();
       if (t > buf[threadIdx.x]) buf[threadIdx.x] = t;
       __syncthreads();
     }
-    const int64_t incl = buf[threadIdx.x];
-    const int64_t excl = threadIdx.x > 0 ? buf[threadIdx.x - 1] : kNone;
-    const int64_t total = buf[1023];
+    const int excl = threadIdx.x > 0 ? buf[threadIdx.x - 1] : kNoneLo;
+    const int total = buf[1023];
     __syncthreads();
     if (b < nblk) blk_last[b] = excl > carry ? excl : carry;
     carry = total > carry ? total : carry;
-    (void)incl;
   }
-  // suffix min, chunk by chunk from the end
-  int64_t carry2 = n;
+  int carry2 = n;
   for (int64_t top = nblk; top > 0; top -= 1024) {
     const int64_t b = top - 1 - threadIdx.x;  // thread 0 takes the last block of the chunk
-    int64_t v = b >= 0 ? blk_first[b] : INT64_MAX;
-    if (v == INT64_MAX) v = n;
+    int v = b >= 0 ? blk_first[b] : kNoneHi;
+    if (v == kNoneHi) v = n;
     buf[threadIdx.x] = v;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-      const int64_t t = threadIdx.x >= (unsigned)d ? buf[threadIdx.x - d] : n;
+      const int t = threadIdx.x >= (unsigned)d ? buf[threadIdx.x - d] : n;
       __syncthreads();
       if (t < buf[threadIdx.x]) buf[threadIdx.x] = t;
       __syncthreads();
     }
-    const int64_t excl = threadIdx.x > 0 ? buf[threadIdx.x - 1] : n;
-    const int64_t total = buf[1023];
+    const int excl = threadIdx.x > 0 ? buf[threadIdx.x - 1] : n;
+    const int total = buf[1023];
     __syncthreads();
     if (b >= 0) blk_first[b] = excl < carry2 ? excl : carry2;
     carry2 = total < carry2 ? total : carry2;
@@ -111,37 +145,72 @@ __global__ void k_line_ttab(float *__restrict__ ttab, float w, int64_t count) {
 
 template <typename T>
 __global__ void __launch_bounds__(kLineBlock)
-k_line_eval(const T *__restrict__ lab, float *__restrict__ out, int64_t n, const int64_t *__restrict__ blk_last,
-            const int64_t *__restrict__ blk_first, const float *__restrict__ ttab, float w, int bb, int take_sqrt,
-            int64_t row, int to_finite) {
-  __shared__ int64_t s_lo[kLineBlock], s_hi[kLineBlock];
-  const int64_t i = (int64_t)blockIdx.x * kLineBlock + threadIdx.x;
-  const bool in = i < n;
-  const bool st = in && line_starts(lab, i, row);
-  // last start at or before i / first start after i, inside the block
-  s_lo[threadIdx.x] = st ? i : kNone;
-  s_hi[threadIdx.x] = st ? i : INT64_MAX;
-  __syncthreads();
-  for (int d = 1; d < kLineBlock; d <<= 1) {
-    const int64_t a = threadIdx.x >= (unsigned)d ? s_lo[threadIdx.x - d] : kNone;
-    const int64_t b = threadIdx.x + d < kLineBlock ? s_hi[threadIdx.x + d] : INT64_MAX;
-    __syncthreads();
-    if (a > s_lo[threadIdx.x]) s_lo[threadIdx.x] = a;
-    if (b < s_hi[threadIdx.x]) s_hi[threadIdx.x] = b;
-    __syncthreads();
+k_line_eval(const T *__restrict__ lab, float *__restrict__ out, const int *__restrict__ blk_last,
+            const int *__restrict__ blk_first, const float *__restrict__ ttab, float w, int bb, int take_sqrt,
+            int64_t row, unsigned bpr, int to_finite, int bpr_local) {
+  __shared__ unsigned long long s_mask[kLineWaves];
+  __shared__ int s_before, s_after;
+  const LinePos p = line_pos(row, bpr);
+  const int64_t i = p.r0 + p.x;
+  const bool in = p.in;
+  const T here = in ? lab[i] : T(0);
+  const unsigned long long mine = __ballot(in && (p.x == 0 || here != lab[i - 1]));
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+  if (lane == 0) s_mask[wv] = mine;
+  // The nearest start before / after the whole block is the same for every voxel of it: looked up ONCE per block (by
+  // the first wave, its loads in flight next to everybody's label loads) and shared through LDS.
+  if (wv == 0) {
+    int sb = kNoneLo, sa = kNoneHi;
+    if (bpr_local) {
+      // a stack of rows: the marks are per block (no scan over all blocks); a row has a handful of blocks and its first
+      // one starts with a run.  lanes 0..31: the blocks before this one, nearest first; lanes 32..63: the blocks after
+      for (unsigned k0 = 0; k0 < bpr; k0 += 32) {
+        const unsigned k = k0 + (lane & 31) + 1;
+        int v = (lane < 32) ? kNoneLo : kNoneHi;
+        if (lane < 32) { if (k <= p.bx) v = blk_last[blockIdx.x - k]; }
+        else if (p.bx + k < bpr) v = blk_first[blockIdx.x + k];
+        const unsigned long long has = __ballot(lane < 32 ? v != kNoneLo : v != kNoneHi);
+        const unsigned lo = (unsigned)(has & 0xFFFFFFFFull), hi = (unsigned)(has >> 32);
+        if (sb == kNoneLo && lo) sb = __shfl(v, __builtin_ctz(lo));
+        if (sa == kNoneHi && hi) sa = __shfl(v, 32 + __builtin_ctz(hi));
+        if ((sb != kNoneLo || k0 + 32 >= p.bx) && (sa != kNoneHi || p.bx + k0 + 33 >= bpr)) break;
+      }
+      if (sa == kNoneHi) sa = (int)row;  // the next row's first voxel (or the end of the array)
+    } else {
+      sb = blk_last[blockIdx.x];   // (scanned: last start before / first start after the block; >= 0 resp. <= n)
+      sa = blk_first[blockIdx.x];
+    }
+    if (lane == 0) { s_before = sb; s_after = sa; }
   }
+  __syncthreads();
+  // which waves of the block hold a start (every wave computes the word for itself: 16 LDS reads, one ballot)
+  const unsigned wmask = (unsigned)__ballot(lane < kLineWaves && s_mask[lane < kLineWaves ? lane : 0] != 0ull);
   if (!in) return;
-  int64_t s = s_lo[threadIdx.x];
-  if (s == kNone) s = blk_last[blockIdx.x];  // (>= 0: voxel 0 starts a run)
-  int64_t e = threadIdx.x + 1 < kLineBlock ? s_hi[threadIdx.x + 1] : INT64_MAX;
-  if (e == INT64_MAX) e = blk_first[blockIdx.x];
+  const int base = (int)(p.bx * kLineBlock);
+  // last start at or before x
+  int sx_;
+  {
+    const unsigned long long below = mine & (~0ull >> (63 - lane));  // bits 0 .. lane
+    const unsigned wb = wmask & ((1u << wv) - 1u);                    // waves before this one that hold a start
+    if (below) sx_ = base + wv * 64 + hi_bit64(below);
+    else if (wb) { const int kw = 31 - __builtin_clz(wb); sx_ = base + kw * 64 + hi_bit64(s_mask[kw]); }
+    else sx_ = s_before;
+  }
+  // first start after x
+  int ex_;
+  {
+    const unsigned long long above = lane < 63 ? (mine & (~0ull << (lane + 1))) : 0ull;  // bits lane+1 .. 63
+    const unsigned wa = wv < kLineWaves - 1 ? (wmask & (~0u << (wv + 1))) : 0u;
+    if (above) ex_ = base + wv * 64 + lo_bit64(above);
+    else if (wa) { const int kw = __builtin_ctz(wa); ex_ = base + kw * 64 + lo_bit64(s_mask[kw]); }
+    else ex_ = s_after;
+  }
   float v = 0.0f;
-  if (lab[i] != 0) {
-    auto tk = [&](int64_t k) -> float { return ttab ? ttab[k] : (float)k * w; };
-    // the ends of the line (of the voxel's row, for a stack of rows) are borders only with black_border
-    const int64_t r0 = row > 0 ? (i / row) * row : 0, r1 = row > 0 ? r0 + row : n;
-    const float dl = (s > r0 || bb) ? tk(i - s + 1) : INFINITY;
-    const float dr = (e < r1 || bb) ? tk(e - i) : INFINITY;
+  if (here != 0) {
+    auto tk = [&](int k) -> float { return ttab ? ttab[k] : (float)k * w; };
+    // the ends of the row (of the line) are borders only with black_border
+    const float dl = (sx_ > 0 || bb) ? tk(p.x - sx_ + 1) : INFINITY;
+    const float dr = ((int64_t)ex_ < row || bb) ? tk(ex_ - p.x) : INFINITY;
     const float d = dl < dr ? dl : dr;
     v = d * d;                       // `d[i] *= d[i]` (src/edt.hpp:116-118)
     if (to_finite && v > 3.402823466e+38f) v = 3.402823466e+38f;  // tofinite (src/edt.hpp:39-45)
@@ -164,21 +233,27 @@ template <typename T>
 int launch_line_t(const void *labels, float *out, int64_t n, float w, int bb, int take_sqrt, void *ws,
                   hipStream_t stream, int64_t row = 0, int to_finite = 0) {
   const T *lab = static_cast<const T *>(labels);
-  const int64_t nblk = ceil_div(n, kLineBlock);
+  if (row <= 0) row = n;                       // one line = one row
+  const int64_t rows = n / row;
+  const int64_t bpr = ceil_div(row, kLineBlock);
+  const int64_t nblk = rows * bpr;
   if (nblk > 0x7FFFFFFF) { set_error("line too long"); return EDT_ERR_UNSUPPORTED; }
   char *p = static_cast<char *>(ws);
-  int64_t *blk_last = reinterpret_cast<int64_t *>(p);
-  int64_t *blk_first = blk_last + nblk;
+  int *blk_last = reinterpret_cast<int *>(p);   // (row-relative positions: 32 bits; the carve below keeps 8 bytes per entry)
+  int *blk_first = blk_last + nblk;
   float *ttab = nullptr;
-  const int64_t longest = row > 0 ? row : n;  // no run is longer than a row
-  if (!multiples_exact(w, longest + 1)) {
+  if (!multiples_exact(w, row + 1)) {          // (no run is longer than a row)
     ttab = reinterpret_cast<float *>(p + align_up((size_t)(2 * nblk) * sizeof(int64_t), 256));
-    hipLaunchKernelGGL(k_line_ttab, dim3(1), dim3(64), 0, stream, ttab, w, longest + 2);
+    hipLaunchKernelGGL(k_line_ttab, dim3(1), dim3(64), 0, stream, ttab, w, row + 2);
   }
-  hipLaunchKernelGGL(k_line_marks<T>, dim3((unsigned)nblk), dim3(kLineBlock), 0, stream, lab, n, blk_last, blk_first, row);
-  hipLaunchKernelGGL(k_line_scan, dim3(1), dim3(1024), 0, stream, blk_last, blk_first, nblk, n);
-  hipLaunchKernelGGL(k_line_eval<T>, dim3((unsigned)nblk), dim3(kLineBlock), 0, stream, lab, out, n, blk_last,
-                     blk_first, ttab, w, bb, take_sqrt, row, to_finite);
+  hipLaunchKernelGGL(k_line_marks<T>, dim3((unsigned)nblk), dim3(kLineBlock), 0, stream, lab, blk_last, blk_first, row,
+                     (unsigned)bpr);
+  // one line: the marks are turned into "last start before / first start after the block" by a scan over the blocks;
+  // a stack of rows needs none (every row's first voxel starts a run: k_line_eval looks at the row's own few blocks)
+  const int local = rows > 1 ? 1 : 0;
+  if (!local) hipLaunchKernelGGL(k_line_scan, dim3(1), dim3(1024), 0, stream, blk_last, blk_first, nblk, (int)n);
+  hipLaunchKernelGGL(k_line_eval<T>, dim3((unsigned)nblk), dim3(kLineBlock), 0, stream, lab, out, blk_last,
+                     blk_first, ttab, w, bb, take_sqrt, row, (unsigned)bpr, to_finite, local);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }
@@ -288,7 +363,7 @@ size_t line_workspace_bytes(int64_t n) {
 // nrows * sx voxels with a forced run start at every row's first voxel: block scan + table look-up, every voxel its
 // own thread (the size-agnostic kernel this replaces gave every ROW one thread).
 size_t rows_line_workspace_bytes(int64_t sx, int64_t nrows) {
-  const int64_t nblk = ceil_div(sx * nrows, kLineBlock);
+  const int64_t nblk = nrows * ceil_div(sx, kLineBlock);
   return align_up((size_t)(2 * nblk) * sizeof(int64_t), 256) + align_up((size_t)(sx + 2) * sizeof(float), 256) + 256;
 }
 

@@ -201,6 +201,10 @@ static bool column_inplace_supported(const AxisGeom &g) {
 }
 static int launch_column_inplace(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                                  float w, int bb, int epi, hipStream_t stream) {
+  // axes of at most 32 rows with many columns: a thread per column (edt_short.hip); the LDS-tiled kernels would
+  // launch a single-wave workgroup per 32 columns.  (debug bit 0x1000000 keeps them on the wave kernel.)
+  if (column_pass_short_supported(g) && g.sx * g.nouter >= 4096 && !(g_debug_mode & (64 | 0x1000000)))
+    return launch_column_pass_short(F, nz, rs, g, w, bb, epi, stream);
   if (column_pass_wave_supported(g) && !(g_debug_mode & 64))
     return launch_column_pass_wave(F, nz, rs, g, w, bb, epi, stream);
   return launch_column_pass_tiled(F, nz, rs, g, w, bb, epi, stream);

@@ -34,9 +34,9 @@ void set_error(const std::string &msg);
 //   0x4000        every tile takes the windowed path             0x8000    fp64 candidates on the windowed path
 //   0x20000       voxel graph: up-sampled formulation            0x100000  fp32 form of pass X (no 16-bit indices)
 //   0x200000      voxel graph: separate gather pass              0x400000  every tile takes the bracket path (where exact)
-//   0x800000      no tile takes the bracket path
+//   0x800000      no tile takes the bracket path                 0x1000000 short axes (<= 32 rows) stay on the wave kernel
 constexpr int kDiagFormBits = 16 | 32 | 64 | 256 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |
-                              0x100000 | 0x200000 | 0x400000 | 0x800000;
+                              0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000;
 #ifdef EDT_DIAG
 #define EDT_DIAG_BITS(dbg, bits) ((dbg) & (bits))
 #else

@@ -83,6 +83,10 @@ int launch_bits_from_flags(const uint8_t *flags, uint32_t *nz, uint32_t *rs, con
 int launch_pack_record_bits(const uint32_t *nz_y, const uint32_t *zs_y, const BandScatter &sc,
                             BandScatter *d_table, int64_t sx, int64_t nby, int64_t szl,
                             hipStream_t stream);
+// ---- short axes (at most 32 rows): a thread per column, rows in registers: edt_short.hip ----
+bool column_pass_short_supported(const AxisGeom &g);
+int launch_column_pass_short(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w, int bb,
+                             int epi, hipStream_t stream);
 // ---- LDS-tiled column pass: edt_tiled.hip ---------------------------------------------------
 bool column_pass_tiled_supported(const AxisGeom &g);
 int launch_column_pass_tiled(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,

@@ -187,3 +187,33 @@ def test_device_entry_point_is_graph_capturable(edt_gpu, oracle_port):
         graph.replay()
         torch.cuda.synchronize()
         assert same(out.cpu().numpy().T, want)
+
+
+def test_short_axes_thread_per_column(edt_gpu, oracle_port):
+    """Axes of at most 32 rows with many columns take edt_short.hip (a thread per column, rows in registers, brute
+    force over the column) instead of single-wave workgroups of the LDS-tiled kernel; both against the oracle, and
+    against each other (debug bit 0x1000000 keeps the wave kernel)."""
+    from edt import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(31)
+    shapes = [(300, 200, 8), (257, 130, 17), (130, 5, 400), (66, 32, 70), (512, 512, 3), (100, 100, 1), (90, 31, 33),
+              (4100, 7, 9)]
+    for t, shape in enumerate(shapes):
+        dt = [np.uint8, np.uint16, np.uint32, np.uint64, np.float32][t % 5]
+        lab = np.asfortranarray(blocky_labels(shape, nlabels=4, zero_frac=0.2, block=int(rng.integers(1, 7)), rng=rng).astype(dt))
+        if t % 3 == 0:
+            lab[:, :, 0] = 1   # whole slices of one label: runs that span the short axis, no boundary in some rows
+        for an, bb in (((1.0, 1.0, 1.0), False), ((6.0, 6.0, 30.0), True), ((0.7, 1.3, 2.1), False)):
+            want = oracle_port.edtsq(lab, an, bb)
+            got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+            assert same(got, want), (shape, dt, an, bb)
+            assert same(edt_gpu.edt(lab, anisotropy=an, black_border=bb), np.sqrt(want)), (shape, "sqrt")
+            lib.edt_hip_set_debug_mode(0x1000000)
+            try:
+                assert same(edt_gpu.edtsq(lab, anisotropy=an, black_border=bb), want), (shape, "wave kernel")
+            finally:
+                lib.edt_hip_set_debug_mode(0)
+    # the binary route and a 2-D image with a short y axis
+    img = np.asfortranarray(blocky_labels((5000, 20), nlabels=3, zero_frac=0.3, block=3, rng=rng).astype(np.uint8))
+    assert same(edt_gpu.edtsq(img, anisotropy=(2.0, 3.0), black_border=True), oracle_port.edtsq(img, (2.0, 3.0), True))
+    assert same(edt_gpu.binary_edtsq(img, anisotropy=(2.0, 3.0), black_border=False), oracle_port.binary_edtsq(img, (2.0, 3.0), False))

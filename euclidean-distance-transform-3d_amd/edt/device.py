@@ -68,8 +68,9 @@ class Plan:
         return self._generic_ws
 
     def run(self, labels: torch.Tensor, weights_xyz, black_border=False, sqrt=False,
-            out: torch.Tensor | None = None, force_generic=False, batch2d=False) -> torch.Tensor:
-        """Enqueue the transform of ``labels`` (device, contiguous, ``voxels`` elements)."""
+            out: torch.Tensor | None = None, force_generic=False, batch2d=False, binary=False) -> torch.Tensor:
+        """Enqueue the transform of ``labels`` (device, contiguous, ``voxels`` elements).  binary: the reference's
+        binary route for multi-valued labels (EDT_FLAG_BINARY_YZ: labels split runs along x only)."""
         if not labels.is_cuda or not labels.is_contiguous():
             raise ValueError("labels must be a contiguous device tensor")
         if labels.numel() != self.voxels:
@@ -83,7 +84,7 @@ class Plan:
         w = tuple(float(np.float32(v)) for v in weights_xyz) + (1.0,) * (3 - self.ndim)
         flags = ((_lib.FLAG_BLACK_BORDER if black_border else 0) | (_lib.FLAG_SQRT if sqrt else 0)
                  | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
-                 | (_lib.FLAG_BATCH_2D if batch2d else 0) | self.base_flags)
+                 | (_lib.FLAG_BATCH_2D if batch2d else 0) | (_lib.FLAG_BINARY_YZ if binary else 0) | self.base_flags)
         ws = self._workspace_for(flags)
         rc = self.lib.edt_hip_edtsq_device(
             ctypes.c_void_p(labels.data_ptr()), self.code, self.ndim, *self.ext, w[0], w[1], w[2],
@@ -106,7 +107,7 @@ def _plan_for(ext, code, device) -> Plan:
     return _plans[key]
 
 
-def _transform(labels: torch.Tensor, anisotropy, black_border, sqrt, force_generic=False):
+def _transform(labels: torch.Tensor, anisotropy, black_border, sqrt, force_generic=False, binary=False):
     if labels.numel() == 0:
         return torch.zeros(labels.shape, dtype=torch.float32, device=labels.device)
     if labels.dim() < 1 or labels.dim() > 3:
@@ -119,7 +120,15 @@ def _transform(labels: torch.Tensor, anisotropy, black_border, sqrt, force_gener
     ext = tuple(labels.shape[::-1])
     w = an[::-1]
     plan = _plan_for(ext, dtype_code(labels.dtype), labels.device)
-    return plan.run(labels, w, black_border, sqrt, force_generic=force_generic)
+    return plan.run(labels, w, black_border, sqrt, force_generic=force_generic, binary=binary)
+
+
+def binary_edtsq(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
+    """``edt::binary_edtsq`` on a 2-D / 3-D device tensor of ANY label type (reference: src/edt.hpp:487-576, :681-755):
+    labels split runs along x only; along y and z every non-zero voxel is one foreground."""
+    if labels.dim() not in (2, 3):
+        raise TypeError("binary_edtsq: 2-D or 3-D tensors")
+    return _transform(labels, anisotropy, black_border, sqrt=False, binary=True)
 
 
 def edtsq(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:

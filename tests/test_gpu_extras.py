@@ -147,6 +147,12 @@ def test_binary_route_through_every_kernel_family(edt_gpu, oracle_port):
             assert np.array_equal(got, want), hex(mode)
     finally:
         lib.edt_hip_set_debug_mode(0)
+    # device-resident form (C-ordered tensor: anisotropy in (z, y, x) order)
+    import torch
+    from edt import device
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int16)).cuda()
+    got = device.binary_edtsq(t, anisotropy=(3.0, 1.0, 2.0), black_border=False).cpu().numpy().T
+    assert np.array_equal(got, want)
     long_axis = np.asfortranarray(blocky_labels((5, 33000), nlabels=3, zero_frac=0.3, block=700, rng=rng).astype(np.uint8))
     assert np.array_equal(edt_gpu.binary_edtsq(long_axis, anisotropy=(1.0, 2.0), black_border=True),
                           oracle_port.binary_edtsq(long_axis, (1.0, 2.0), True))

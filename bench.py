@@ -385,6 +385,19 @@ def sharded_main(args, rank, world, dev):
     device.set_profiling(False)
     kernel_ms = {k: float(np.sum(v)) / 3 for k, v in acc.items()}  # chunks of a step add up
     dist.barrier()
+    # exposed exchange: events on the compute stream around the waits for the records (edt/distributed.py), in steps of
+    # their own (the per-kernel events above serialise the chunks' streams)
+    exposed = []
+    if plan.records:
+        plan.measure_exchange = True
+        for _ in range(5):
+            step()
+            torch.cuda.synchronize()
+            exposed.append(plan.exposed_ms())
+        plan.measure_exchange = False
+    exposed_t = torch.tensor([float(np.mean(exposed[1:])) if len(exposed) > 1 else -1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(exposed_t, op=dist.ReduceOp.MAX)
+    dist.barrier()
 
     ys, ye = plan.local_y()
     # what travels: this rank's slab records for every OTHER rank (4 B x record length x its slices), max over ranks
@@ -470,19 +483,33 @@ def sharded_main(args, rank, world, dev):
                        "single_gpu_same_workload": same_n1},
             "roofline": roofline,
             # how to read a SCALE curve: per-rank kernel time (rank 0, per step, chunks summed), the slowest rank's
-            # kernel sum, what is left of the step once the kernels are subtracted (= the exposed part of the
-            # exchange + launch gaps; 0 when the exchange hides under the next chunk's kernels), and the bytes the
-            # busiest rank sends per step over xGMI (7 links x ~153 GB/s per GPU: bytes / (world - 1) per link)
+            # kernel sum, the exposed part of the exchange (measured with events around the waits; ~0 when it hides
+            # under the next chunk's kernels), and the bytes the busiest rank sends per step over xGMI
+            # (7 links x ~153 GB/s per GPU: bytes / (world - 1) per link)
             "per_rank": {"kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                         "kernel_ms_note": "hipEvents per kernel, chunks summed; chunks run on two streams, so overlapping "
+                                           "kernels are each timed at their stretched duration and the sum may exceed the step",
                          "kernel_ms_sum_max_over_ranks": round(float(ksum.item()), 4),
-                         "exchange_ms_exposed": round(max(0.0, elapsed / args.steps * 1e3 - float(ksum.item())), 4),
+                         "exchange_ms_exposed": (round(float(exposed_t.item()), 4) if float(exposed_t.item()) >= 0 else None),
+                         "exchange_ms_exposed_note": "events on the compute stream around the waits for the slab records: how long "
+                                                     "the slowest rank sat between its last XY kernel and the last record's arrival",
                          "bytes_exchanged": int(sent_t.item()),
                          "link_floor_ms": round(int(sent_t.item()) / max(1, world - 1) / 153e9 * 1e3, 4) if world > 1 else 0.0},
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
+    dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio (buffered when stdout is a pipe): push it out first, so that the
+        # JSON line is the LAST thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 def _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev):

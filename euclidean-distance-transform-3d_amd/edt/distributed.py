@@ -301,8 +301,16 @@ class ShardedEDT:
         if side is not None:
             for st in side:
                 main.wait_stream(st)
+        # (measure_exchange: two events on the compute stream bracket the waits for the exchanges -- the time this rank's
+        # kernels are done and the Z pass cannot start yet = the EXPOSED part of the exchange; read with exposed_ms())
+        timed = getattr(self, "measure_exchange", False) and labels.is_cuda
+        if timed:
+            self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
         for req in pending:
             req.wait()
+        if timed:
+            self._ev[1].record()
         self.ops.z_records(dst, self.sx, ye - ys, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0))
         # the result is the float part of every record: a (sz, syl, sx) view with z-stride = record
         return dst[:, :(ye - ys) * self.sx].view(self.sz, ye - ys, self.sx)
@@ -338,6 +346,12 @@ class ShardedEDT:
         else:
             peers = [h for h in range(self.world) if h != self.rank]
             pending.append(self._p2p([(blocks[h], h) for h in peers], [(recv[h], h) for h in peers]))
+
+    def exposed_ms(self):
+        """Exposed exchange time of the last run() with ``measure_exchange`` set (after a device synchronisation):
+        how long the compute stream sat between its last XY kernel and the arrival of the last record."""
+        ev = getattr(self, "_ev", None)
+        return float(ev[0].elapsed_time(ev[1])) if ev else None
 
     # -- the pipeline -----------------------------------------------------------------------
     def run(self, labels, weights_xyz, black_border=False, sqrt=False, gather_back=False):

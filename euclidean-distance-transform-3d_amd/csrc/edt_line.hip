@@ -12,9 +12,11 @@
 //   k_line_eval  : per voxel, nearest run start on either side (bit scans of the block's sixteen ballot masks + the
 //                  carried values), table look-up, square (+ optional sqrt)
 // T is exact as k*w when w = m * 2^e with m*(n+1) < 2^24 (all the usual anisotropies); otherwise it is
-// tabulated once by a single thread -- the sums are sequentially rounded, there is no closed form.
+// tabulated -- the sums are sequentially rounded -- in parallel: every chunk of the table starts from a value reached by
+// jumping through the binades (edt_seqsum.h).
 #include "edt_common.h"
 #include "edt_kernels.h"
+#include "edt_seqsum.h"
 
 #include <cmath>
 
@@ -133,13 +135,18 @@ __global__ void __launch_bounds__(1024) k_line_scan(int *blk_last, int *blk_firs
   }
 }
 
+// The table T[0 .. count) of the sequential fp32 sums of w, built in PARALLEL: a thread jumps to the first entry of its
+// chunk through the binades (edt_seqsum.h: bit-identical to walking there) and fills the chunk with real additions.
+// (Rounds 1-2: one thread, count dependent additions -- seconds for a 2^31-voxel line at a voxel size like 0.1.)
+constexpr int64_t kTabChunk = 1024;
 __global__ void k_line_ttab(float *__restrict__ ttab, float w, int64_t count) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  float acc = 0.0f;
-  ttab[0] = 0.0f;
-  for (int64_t k = 1; k < count; ++k) {
-    acc = acc + w;
-    ttab[k] = acc;
+  const int64_t k0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * kTabChunk;
+  if (k0 >= count) return;
+  const int64_t k1 = k0 + kTabChunk < count ? k0 + kTabChunk : count;
+  float t = edt_seq_sum_at(w, k0);
+  for (int64_t k = k0; k < k1; ++k) {
+    ttab[k] = t;
+    t = t + w;
   }
 }
 
@@ -244,7 +251,8 @@ int launch_line_t(const void *labels, float *out, int64_t n, float w, int bb, in
   float *ttab = nullptr;
   if (!multiples_exact(w, row + 1)) {          // (no run is longer than a row)
     ttab = reinterpret_cast<float *>(p + align_up((size_t)(2 * nblk) * sizeof(int64_t), 256));
-    hipLaunchKernelGGL(k_line_ttab, dim3(1), dim3(64), 0, stream, ttab, w, row + 2);
+    const int64_t tthreads = ceil_div(row + 2, kTabChunk);
+    hipLaunchKernelGGL(k_line_ttab, dim3((unsigned)ceil_div(tthreads, 64)), dim3(64), 0, stream, ttab, w, row + 2);
   }
   hipLaunchKernelGGL(k_line_marks<T>, dim3((unsigned)nblk), dim3(kLineBlock), 0, stream, lab, blk_last, blk_first, row,
                      (unsigned)bpr);

@@ -159,3 +159,17 @@ def test_binary_route_through_every_kernel_family(edt_gpu, oracle_port):
     long_row = np.asfortranarray(blocky_labels((3000, 7, 3), nlabels=3, zero_frac=0.3, block=300, rng=rng).astype(np.uint32))
     assert np.array_equal(edt_gpu.binary_edtsq(long_row, anisotropy=(1.0, 2.0, 0.5), black_border=False),
                           oracle_port.binary_edtsq(long_row, (1.0, 2.0, 0.5), False))
+
+
+def test_very_long_line_with_tabulated_sums(edt_gpu, oracle_port):
+    """A 2^24-voxel run at voxel sizes whose multiples are NOT exact: the table of sequential fp32 sums is built in
+    parallel (every 1024-entry chunk starts from a value reached by jumping through the binades, csrc/edt_seqsum.h) and
+    must equal the reference's running sums far beyond 2^23, where 0.7 has long since started to round to 1.0 per step."""
+    n = 1 << 24
+    lab = np.ones(n, dtype=np.uint8)
+    lab[n // 3] = 0                     # two runs of ~5.6 and ~11.2 million voxels
+    for w in (0.7, 0.1):
+        for bb in (True, False):
+            want = oracle_port.edtsq(lab, w, bb)
+            got = edt_gpu.edtsq(lab, anisotropy=w, black_border=bb)
+            assert np.array_equal(got, want), (w, bb, np.argwhere(got != want)[:3])

@@ -287,6 +287,13 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   // the reference's binary route for multi-valued labels: labels split runs in pass 1 only (edt_generic.hip:
   // k_planes_one_run).  Boolean input gives the same values either way and keeps the ordinary planes.
   const bool binary_yz = (flags & EDT_FLAG_BINARY_YZ) != 0 && dtype != EDT_BOOL;
+  // lower bounds of the non-zero values passes Y and Z read (AxisGeom::fmin): pass X leaves fl32(T[k]^2) >= fl32(wx^2),
+  // pass Y's results are at least the smaller of that and fl32(wy^2) (every candidate is its row's own value or carries
+  // a c_d >= w2y; the border terms are >= w2y).  Not for the fused sqrt of a 2-D call (pass Z does not exist then).
+  const float fmin_y = wx * wx;
+  const float fmin_z = fminf(wx * wx, wy * wy);
+  p.gy.fmin = fmin_y;
+  p.gz.fmin = fmin_z;
 
   // the pass log is process-wide and only touched (under its mutex) while profiling is switched on
   if (g_log.enabled.load(std::memory_order_relaxed)) {

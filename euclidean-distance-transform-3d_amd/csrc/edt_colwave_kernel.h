@@ -54,7 +54,8 @@ namespace edt_amd {
 // arguments of the windowed path of the column kernel
 struct BruteArgs {
   uint32_t limit_bits;  // a tile takes the path when the bit pattern of its largest field value is <= this; 0 = never
-  int x32;              // candidates are fp32 sums (c_d exactly representable up to the limit)
+  int x32;              // 1: candidates are fp32 sums, c_d exactly representable up to the limit; 2: fp32 fma candidates of
+                        //    a rounded c_d, equal to the reference's values because its fp64 sums are exact (brute_f32e_prefix)
   int force;            // diagnostics: every tile takes the path
   int stride;           // 1: every row is evaluated; 2: only the even rows are (and written), see BruteSteps
   // stride 2 only, or nullptr: the even rows leave for a compact array instead of their places in F --
@@ -164,8 +165,9 @@ __device__ EDT_BRUTE_INLINE void brute_tile(float *tile, const uint32_t *alive, 
   };
   // (bit 8 of epi: only the even rows are evaluated and written -- the doubled grids of the voxel-graph transform;
   // carried in an existing argument: the kernel around this call is sensitive to its signature, see hull path)
-  if (epi & 0x100) brute_band<CW, BB, X32, 2>(BL, epi & 0x203, store);
-  else brute_band<CW, BB, X32, 1>(BL, epi & 0x203, store);
+  // (bit 11 of epi: the fp32 candidates are fma's of a ROUNDED c_d -- brute_f32e_prefix -- the exit tests allow for it)
+  if (epi & 0x100) brute_band<CW, BB, X32, 2>(BL, epi & 0xA03, store);
+  else brute_band<CW, BB, X32, 1>(BL, epi & 0xA03, store);
 }
 
 // The bracket path of one lane (edt_colwave_lane.h: mono_anchor / mono_band) -- EXPERIMENT, compiled into the kernel
@@ -534,7 +536,8 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
           return;
         }
 #endif
-        const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | (EDT_DIAG_BITS(dbg, 0x80000) ? 0x200 : 0) | (compact ? 0x400 : 0);
+        const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | (EDT_DIAG_BITS(dbg, 0x80000) ? 0x200 : 0) | (compact ? 0x400 : 0) |
+                          (ba.x32 == 2 ? 0x800 : 0);
         if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
         else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
         return;
@@ -628,12 +631,19 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
     // is lowered to it (fp32 candidates are ~25 % cheaper than fp64 ones; the tiles in between go to the hulls).
     int T = force ? (int)g.n : window_limit();
     const int exact = edt_lane::brute_exact_prefix(w, T);
-    bool x32 = exact >= T;
-    if (!x32 && !force && exact >= 64) { T = exact; x32 = true; }
+    int mode = exact >= T ? 1 : 0;
+    // Voxel sizes whose c_d are not all exact: fp32 fma candidates where the caller vouches for a lower bound of the
+    // field (g.fmin) and the fp64 sums of the reference are exact on tiles up to c_Tf (brute_f32e_prefix) -- not for a
+    // forced tile, whose values are not bounded by c_T.  Failing that, the exact prefix where it is worth a window.
+    if (mode == 0 && !force) {
+      const int Tf = (g.fmin > 0.0f && !(debug_mode() & 0x2000000)) ? edt_lane::brute_f32e_prefix(w, g.fmin, T) : 0;
+      if (Tf >= 64 && Tf > exact) { T = Tf; mode = 2; }
+      else if (exact >= 64) { T = exact; mode = 1; }
+    }
     // (fp64 candidates walk their far rows one by one: beyond ~190 rows the hull path is the better form for them)
-    if (!x32 && !force && T > 192) T = 192;
-    if (debug_mode() & 0x8000) x32 = false;  // diagnostics: fp64 candidates
-    ba.x32 = x32 ? 1 : 0;
+    if (mode == 0 && !force && T > 192) T = 192;
+    if (debug_mode() & 0x8000) mode = 0;  // diagnostics: fp64 candidates
+    ba.x32 = mode;
     const double cT = (double)(w * w) * (double)T * (double)T;
     float lim = cT < 3.0e38 ? (float)cT : 3.0e38f;
     if ((double)lim > cT) lim = nextafterf(lim, 0.0f);

@@ -749,6 +749,8 @@ struct BruteSteps {
   int nb32;
   float w2f;   // per-block copies of L.w2f / L.w2 (see brute_band: keeps the c_d next to their use)
   double w2;
+  uint32_t cbias;  // X32 only: 0 = c_d exact in fp32; 1 = c_d rounded (fma candidates, brute_f32e_prefix): the exit tests
+                   // then use the float just below fl32(c_d), which is <= the true c_d
 
   // The exit bound follows the minima: a candidate at distance d is at least c_d, so once c_d >= every current
   // minimum of the wave's blocks nothing further away can lower any of them (ties change nothing).  Refreshed every
@@ -778,8 +780,11 @@ struct BruteSteps {
   EDT_LANE_MEMBER void run() {
     if constexpr (D < K) {
       if constexpr (D > 1 && (D - 1) % 4 == 0) refresh_bound();
-      // c_d = w2 * d^2: in X32 mode exactly representable, so the fp32 product is it
-      const float c1f = w2f * (float)(D * D), c2f = w2f * (float)((D + 1) * (D + 1));
+      // X32: a candidate is fl32(w2 * d^2 + F) -- ONE rounding of the exact sum (fma with an exact product).  Where c_d is
+      // exactly representable that is the plain fp32 sum; where it is not, it is still the reference's value wherever the
+      // fp64 sum the reference forms is exact (brute_f32e_prefix).  The exit test compares (a lower bound of) c_d.
+      const float d1f = (float)(D * D), d2f = (float)((D + 1) * (D + 1));
+      const float c1f = u2f(f2u(w2f * d1f) - cbias);
       const double c1 = w2 * (double)(D * D), c2 = w2 * (double)((D + 1) * (D + 1));
       if (X32 ? !EDT_ANY(c1f < bmaxf) : !EDT_ANY(c1 < bmax64)) return;
       // the rows that enter the window in these two steps
@@ -796,7 +801,7 @@ struct BruteSteps {
         const float m1 = minpos(w[K + S * i - D], w[K + S * i + D]);
         const float m2 = minpos(w[K + S * i - D - 1], w[K + S * i + D + 1]);
         // (sums of non-negative terms: integer minima, no canonicalisation of the operands)
-        if (X32) best[i] = min3pos(best[i], m1 + c1f, m2 + c2f);
+        if (X32) best[i] = min3pos(best[i], fmaf(w2f, d1f, m1), fmaf(w2f, d2f, m2));
         else best64[i] = fmin(best64[i], fmin((double)m1 + c1, (double)m2 + c2));
       }
       run<D + 2>();
@@ -818,19 +823,18 @@ struct BruteSteps {
       // (eight consecutive steps read one band's worth of rows on either side through one address each: see the
       // stride-1 form below; p0 and NR are multiples of 8 here too)
       const float *slo = L.tile, *shi = L.tile;
-      // c_d and its first difference, stepped by exact fp32 additions (X32: every c_d the loop can use is
-      // representable, and so is w2 * (2d + 1); past the limit only the exit test sees them, and rounding is monotone)
-      float cf = w2f * (float)((K + 1) * (K + 1)), gf = w2f * (float)(2 * (K + 1) + 1);
-      const float g2 = w2f + w2f;
+      // d^2 and its first difference as floats, stepped by exact additions (integers below 2^24); candidates are
+      // fl32(w2 * d^2 + F) by fma, the exit test sees (a lower bound of) fl32(w2 * d^2)
+      float ddf = (float)((K + 1) * (K + 1)), gdd = (float)(2 * (K + 1) + 1);
       for (int d0 = K + 1; d0 < 4096; d0 += R) {
         bool done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int e = 0; e < R; ++e, cf += gf, gf += g2) {  // step d = d0 + e;  d mod R == (1 + e) mod R
+        for (int e = 0; e < R; ++e, ddf += gdd, gdd += 2.0f) {  // step d = d0 + e;  d mod R == (1 + e) mod R
           const int d = d0 + e;
           if (e % 4 == 0) refresh_bound();
-          if (!EDT_ANY(cf < bmaxf)) { done = true; break; }
+          if (!EDT_ANY(u2f(f2u(w2f * ddf) - cbias) < bmaxf)) { done = true; break; }
           if (e % 8 == 0) {
             int rl = p0 - d - 7, rh = p0 + NR - 1 + d;
             rl = rl < -32 ? -32 : rl;
@@ -846,7 +850,7 @@ struct BruteSteps {
 #endif
           for (int i = 0; i < B; ++i) {
             const float m = minpos(rlo[(sl - 2 * i + 2 * R) % R], rhi[(sl - (NR - 1) + 2 * i + 2 * R) % R]);
-            best[i] = minpos(best[i], m + cf);
+            best[i] = minpos(best[i], fmaf(w2f, ddf, m));
           }
         }
         if (done) break;
@@ -893,8 +897,7 @@ struct BruteSteps {
       // one address (with that band's column rotation) serves all eight rows through constant offsets.  A stretch
       // beyond the column is moved onto +inf rows of the padding (rows -32 .. -1 / n .. nb32 + 31 all hold +inf).
       const float *slo = L.tile, *shi = L.tile;
-      float cf = w2f * (float)((K + 1) * (K + 1)), gf = w2f * (float)(2 * (K + 1) + 1);
-      const float g2 = w2f + w2f;
+      float ddf = (float)((K + 1) * (K + 1)), gdd = (float)(2 * (K + 1) + 1);
       for (int d0 = K + 1; d0 < 4096; d0 += R) {
         bool done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -903,11 +906,11 @@ struct BruteSteps {
         for (int e = 0; e < R; e += 2) {  // steps d, d + 1 with d = d0 + e;  d mod R == (1 + e) mod R
           const int d = d0 + e;
           if (e % 4 == 0) refresh_bound();
-          // c_d, c_(d+1) by exact fp32 additions (see the stride-2 form above)
-          const float c1f = cf, c2f = cf + gf;
-          cf = c2f + (gf + g2);
-          gf += g2 + g2;
-          if (!EDT_ANY(c1f < bmaxf)) { done = true; break; }
+          // d^2, (d+1)^2 by exact additions (see the stride-2 form above)
+          const float d1f = ddf, d2f = ddf + gdd;
+          ddf = d2f + (gdd + 2.0f);
+          gdd += 4.0f;
+          if (!EDT_ANY(u2f(f2u(w2f * d1f) - cbias) < bmaxf)) { done = true; break; }
           if (e % 8 == 0) {
             int rl = p0 - d - 7, rh = p0 + B - 1 + d;
             rl = rl < -32 ? -32 : rl;
@@ -927,7 +930,7 @@ struct BruteSteps {
             // row p0+i-d entered at step d-i, row p0+i+d at step d-(B-1-i)
             const float m1 = minpos(rlo[(s1 - i + R) % R], rhi[(s1 - (B - 1 - i) + R) % R]);
             const float m2 = minpos(rlo[(s2 - i + R) % R], rhi[(s2 - (B - 1 - i) + R) % R]);
-            best[i] = min3pos(best[i], m1 + c1f, m2 + c2f);  // (this form is X32 only)
+            best[i] = min3pos(best[i], fmaf(w2f, d1f, m1), fmaf(w2f, d2f, m2));  // (this form is X32 only)
           }
         }
         if (done) break;
@@ -1028,7 +1031,8 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
       double w2 = L.w2;
       EDT_OPAQUE(w2f);
       EDT_OPAQUE(w2);
-      BruteSteps<CW, X32, S> steps{L, w, best, best64, PL0, PL1, PH0, PH1, k0, bmaxf, bmax64, nb32, w2f, w2};
+      BruteSteps<CW, X32, S> steps{L, w, best, best64, PL0, PL1, PH0, PH1, k0, bmaxf, bmax64, nb32, w2f, w2,
+                                    (epi & 0x800) ? 1u : 0u};
       steps.template run<1>();
     }
     // ---- epilogue (src/edt.hpp:47-53, :599-601) and the rows leave ----
@@ -1276,6 +1280,33 @@ inline int brute_exact_prefix(float w, int want) {
   return d;
 }
 inline bool brute_exact32(float w, int want) { return brute_exact_prefix(w, want) >= want; }
+
+// fp32 candidates for voxel sizes whose c_d = w2 * d^2 are NOT exactly representable in fp32.  The reference forms
+// fl32( fl64( w2 * d^2 + F ) ): the product is exact in fp64 (24 x 24 bits at most), the sum is rounded to fp64, the
+// result narrowed.  An fp32 fma gives fl32( w2 * d^2 + F ) -- one rounding of the exact sum -- which is the same value
+// whenever the fp64 sum is EXACT, i.e. whenever all set bits of w2 * d^2 and of F fit one 53-bit window.  The lowest set
+// bit of w2 * d^2 is at least that of w2; the lowest set bit of a non-zero field value F >= fmin is at least
+// 2^(ilogb(fmin) - 23); on a tile of the windowed path F <= c_T and d <= T, so every sum is below 2 * c_T.  Returns the
+// largest T <= want for which 2 * w2 * T^2 < 2^(low + 53), low = the smaller of the two lowest-bit exponents
+// (0: never -- no lower bound on the field is known, or the voxel sizes are too far apart).
+// fmin: a lower bound of the non-zero values the pass reads (pass Y: fl32(wx^2); pass Z: the smaller of that and fl32(wy^2)).
+inline int brute_f32e_prefix(float w, float fmin, int want) {
+  const float w2f = w * w;
+  if (!(w2f >= 1.17549435e-38f) || !(fmin >= 1.17549435e-38f) || !((double)w2f < 1.0e30) || !(fmin < 3.0e38f)) return 0;
+  uint32_t bits;
+  memcpy(&bits, &w2f, 4);
+  const uint32_t man = (bits & 0x7FFFFFu) | 0x800000u;          // 24-bit significand of w2 (normal)
+  const int ew = (int)((bits >> 23) & 0xFF) - 127 - 23;           // exponent of its last bit
+  int tz = 0;
+  while (!((man >> tz) & 1u)) ++tz;
+  const int low_w = ew + tz;                                     // lowest SET bit of w2
+  const int low_f = ilogbf(fmin) - 23;                           // lowest possible set bit of a field value >= fmin
+  const int low = low_w < low_f ? low_w : low_f;
+  const double cap = ldexp(1.0, low + 53);
+  int T = want > 4095 ? 4095 : want;                             // (d^2 as an exact float: d < 4096)
+  while (T > 0 && !(2.0 * (double)w2f * (double)T * (double)T < cap)) --T;
+  return T;
+}
 
 // Which tiles may take the bracket path (mono_band), as bit patterns of the tile's largest field value v:
 // lo_bits < bits(v) <= hi_bits.  A tile whose largest value is at most c_T never looks further than T + 32 rows (the

@@ -35,8 +35,9 @@ void set_error(const std::string &msg);
 //   0x20000       voxel graph: up-sampled formulation            0x100000  fp32 form of pass X (no 16-bit indices)
 //   0x200000      voxel graph: separate gather pass              0x400000  every tile takes the bracket path (where exact)
 //   0x800000      no tile takes the bracket path                 0x1000000 short axes (<= 32 rows) stay on the wave kernel
+//   0x2000000     inexact voxel sizes: fp64 candidates even where fp32 fma candidates are exact
 constexpr int kDiagFormBits = 16 | 32 | 64 | 256 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |
-                              0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000;
+                              0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000 | 0x2000000;
 #ifdef EDT_DIAG
 #define EDT_DIAG_BITS(dbg, bits) ((dbg) & (bits))
 #else
@@ -96,6 +97,10 @@ struct AxisGeom {
   int64_t nouter;        // number of outer indices
   int64_t outer_stride;  // element stride between outer indices
   int64_t nbands;        // ceil(n / 32): bit-words per column
+  // a lower bound of the NON-ZERO values the pass reads, where the caller knows one (pass Y: fl32(wx^2); pass Z: the
+  // smaller of that and fl32(wy^2)); 0 = unknown.  Lets the windowed path use fp32 fma candidates for voxel sizes whose
+  // c_d are not exact in fp32 (edt_colwave_lane.h: brute_f32e_prefix).
+  float fmin = 0.0f;
 };
 
 // Destination map of a column pass that scatters its rows into per-destination "slab records"

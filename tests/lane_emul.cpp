@@ -30,6 +30,15 @@ using namespace edt_lane;
 
 static long g_mono_tiles = 0;  // tiles that took the bracket path (tests make sure the path is really exercised)
 extern "C" long lane_emul_mono_tiles() { return g_mono_tiles; }
+// mode 7: fp32 fma candidates for voxel sizes whose c_d are not exact (brute_f32e_prefix), the launcher's conditions:
+// the caller vouches for a lower bound of the non-zero field values (AxisGeom::fmin), a tile takes the window when its
+// largest value is at most c_T.  g_f32e_tiles counts the tiles that did.
+static float g_fmin = 0.0f;
+static int g_f32e_limit = 1024;
+static long g_f32e_tiles = 0;
+extern "C" long lane_emul_f32e_tiles() { return g_f32e_tiles; }
+extern "C" void lane_emul_set_fmin(float fmin, int limit) { g_fmin = fmin; g_f32e_limit = limit; }
+extern "C" int lane_emul_f32e_prefix(float w, float fmin, int want) { return brute_f32e_prefix(w, fmin, want); }
 
 namespace {
 
@@ -183,13 +192,22 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
     bool x32 = brute_exact32(w, want);
     if (mode == 2) x32 = false;
     bool take = true;
-    if (mode == 3) {
+    int f32e_T = 0;
+    if (mode == 7) {
+      const int lim = n < g_f32e_limit ? n : g_f32e_limit;
+      f32e_T = brute_f32e_prefix(w, g_fmin, lim);
+      x32 = true;
+      if (f32e_T < 1) take = false;
+    }
+    if (mode == 3 || mode == 7) {
       float fmaxv = 0.0f;
       for (auto &P : lanes)
         if (P.L.colc < cols_left && P.L.band < NB)
-          for (int r = 0; r < 32; ++r) fmaxv = std::max(fmaxv, P.f[r]);
-      const double cT = (double)(w * w) * 96.0 * 96.0;
-      take = (double)fmaxv <= cT;
+          for (int r = 0; r < 32 && P.L.row0 + r < n; ++r) fmaxv = std::max(fmaxv, P.f[r]);
+      const double T = mode == 3 ? 96.0 : (double)f32e_T;
+      const double cT = (double)(w * w) * T * T;
+      take = take && (double)fmaxv <= cT;
+      if (mode == 7 && take) { ++g_f32e_tiles; epi |= 0x800; }
     }
     if (take) {
       // the links that are not flat (the kernel: alive plane)

@@ -29,8 +29,10 @@ def emul():
     src = os.path.join(ROOT, "tests", "lane_emul.cpp")
     hdr = os.path.join(CSRC, "edt_colwave_lane.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        tmp = f"{so}.{os.getpid()}.tmp"  # (xdist workers may all find it stale: each builds its own, the rename is atomic)
         subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared",
-                        "-fPIC", f"-I{CSRC}", src, "-o", so], check=True)
+                        "-fPIC", f"-I{CSRC}", src, "-o", tmp], check=True)
+        os.replace(tmp, so)
     lib = ctypes.CDLL(so)
     lib.lane_emul_column_pass.restype = ctypes.c_int
     lib.lane_emul_column_pass_mode.restype = ctypes.c_int
@@ -100,6 +102,56 @@ def test_column_pass_matches_oracle(emul, oracle_port, n, sx, kind, mode):
             assert np.array_equal(got_sqrt[ev], np.sqrt(want)[ev]), (n, sx, kind, wx, wy, bb, "sqrt")
             if mode.endswith("_even"):
                 assert np.array_equal(got[1::2], f1[1::2])
+
+
+# voxel sizes whose c_d = w2 * d^2 are not exactly representable in fp32 (the windowed path then used fp64 candidates):
+# fp32 fma candidates on the tiles the launcher's conditions allow (edt_colwave_lane.h: brute_f32e_prefix)
+F32E_ANISO = ((3.58, 40.0), (3.58, 3.58), (1.1, 1.1), (0.1, 0.3), (0.7, 1.3), (4.0, 40.0), (30.0, 6.0), (1.0, 1.0e-3),
+              (1.0e-3, 1.0), (7.25, 0.5), (1.3, 7.25), (123.456, 0.031))
+
+
+@pytest.mark.parametrize("n,sx,kind", [c for c in CASES if c[2] != "ones" or c[0] <= 600])
+def test_fma_candidates_match_oracle(emul, oracle_port, n, sx, kind):
+    emul.lane_emul_f32e_tiles.restype = ctypes.c_long
+    rng = np.random.default_rng(n * 77 + sx)
+    lab = make_labels(n, sx, kind, rng)
+    for (wx, wy) in F32E_ANISO:
+        for bb in (True, False):
+            f1 = x_pass(oracle_port, lab, wx, bb)
+            want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
+            # pass Y reads the results of pass X: every non-zero value is at least fl32(wx^2)
+            emul.lane_emul_set_fmin(ctypes.c_float(float(np.float32(wx) * np.float32(wx))), ctypes.c_int(1024))
+            got = column_pass(emul, lab, f1, wy, bb, 0 if bb else 1, 7)
+            assert np.array_equal(got, want), (n, sx, kind, wx, wy, bb)
+            # a second pass over the first one's results (what pass Z reads): at least the smaller of the two squares
+            fmin2 = min(float(np.float32(wx) * np.float32(wx)), float(np.float32(wy) * np.float32(wy)))
+            emul.lane_emul_set_fmin(ctypes.c_float(fmin2), ctypes.c_int(1024))
+            for wz in (wy, wx, 2.17):
+                got2 = column_pass(emul, lab, want, wz, bb, 0 if bb else 1, 7)
+                want2 = column_pass(emul, lab, want, wz, bb, 0 if bb else 1, 0)
+                assert np.array_equal(got2, want2), (n, sx, kind, wx, wy, wz, bb, "second pass")
+
+
+def test_fma_candidates_are_exercised(emul, oracle_port):
+    """the conditions really admit tiles for the voxel sizes the change is for, and refuse sizes too far apart"""
+    emul.lane_emul_f32e_tiles.restype = ctypes.c_long
+    emul.lane_emul_f32e_prefix.restype = ctypes.c_int
+    pre = lambda w, fmin, want: emul.lane_emul_f32e_prefix(ctypes.c_float(w), ctypes.c_float(fmin), ctypes.c_int(want))
+    f32 = lambda v: float(np.float32(v) * np.float32(v))
+    assert pre(40.0, f32(3.58), 1024) == 1024
+    assert pre(1.1, f32(1.1), 1024) == 1024
+    assert pre(30.0, 36.0, 1024) == 1024
+    assert pre(1.0, 0.0, 1024) == 0            # no lower bound known
+    assert pre(1.0, 1e-30, 1024) == 0          # sizes too far apart: the fp64 sums round
+    assert pre(1.0e6, 1.0e-3, 1024) == 0
+    rng = np.random.default_rng(5)
+    lab = make_labels(512, 64, "blocky", rng)
+    before = emul.lane_emul_f32e_tiles()
+    f1 = x_pass(oracle_port, lab, 3.58, True)
+    emul.lane_emul_set_fmin(ctypes.c_float(f32(3.58)), ctypes.c_int(1024))
+    got = column_pass(emul, lab, f1, 40.0, True, 0, 7)
+    assert emul.lane_emul_f32e_tiles() > before
+    assert np.array_equal(got, oracle_port.raw2d(lab, 2, 64, 512, (3.58, 40.0), True).reshape(512, 64))
 
 
 def codes_exact(w, sx):

@@ -965,7 +965,8 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
   const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0;
-  const AxisGeom gy = make_geom_y(sx, sy, sz_local);
+  AxisGeom gy = make_geom_y(sx, sy, sz_local);
+  gy.fmin = wx * wx;  // (pass Y reads the results of pass X: AxisGeom::fmin)
   const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
   const bool tiled_y = !force_generic && column_inplace_supported(gy);
   float *xout = tiled_y ? d_partial : p.bufB;  // the tiled y pass runs in place
@@ -1066,7 +1067,8 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
     return EDT_ERR_BAD_ARG;
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  const AxisGeom gy = make_geom_y(sx, sy, sz_local);
+  AxisGeom gy = make_geom_y(sx, sy, sz_local);
+  gy.fmin = wx * wx;  // (pass Y reads the results of pass X: AxisGeom::fmin)
   // destination map: every 32-row band of y lies inside one part
   BandScatter sc;
   bool aligned = (sx % 4) == 0;

@@ -195,7 +195,7 @@ int edt_hip_set_profiling(int enabled);
 /* Diagnostics / test hook.  The mode belongs to the CALLING THREAD (EDT_HIP_DEBUG_MODE in the environment presets
  * every thread's).  The shipped library honours only bits that choose between result-preserving forms of the same
  * computation -- e.g. 0x2000: no tile of the column pass takes the windowed path, 0x4000: every tile does, 0x8000:
- * fp64 candidates there, 0x100000: fp32 instead of 16-bit indices between passes X and Y, 0x20000: up-sampled
+ * fp64 candidates there (0x2000000: only where fp32 fma candidates would serve), 0x100000: fp32 instead of 16-bit indices between passes X and Y, 0x20000: up-sampled
  * voxel-graph formulation, 32 / 64: workgroup-phased row / column kernels (csrc/edt_common.h lists them); results
  * are bit-identical under every one of them, which is what the GPU test tier uses them for.  Bits that switch
  * phases off (wrong results, for cost measurements) exist only in a build with -DEDT_DIAG and are ignored here.

@@ -173,3 +173,35 @@ def test_very_long_line_with_tabulated_sums(edt_gpu, oracle_port):
             want = oracle_port.edtsq(lab, w, bb)
             got = edt_gpu.edtsq(lab, anisotropy=w, black_border=bb)
             assert np.array_equal(got, want), (w, bb, np.argwhere(got != want)[:3])
+
+
+_CELLS = {}
+
+
+def _cells(nseeds, shape):
+    if (nseeds, shape) not in _CELLS:
+        _CELLS[(nseeds, shape)] = voronoi_labels(shape, nseeds, seed=nseeds, upsample=1 if nseeds < 100 else 2,
+                                                 membrane=0.0 if nseeds < 100 else 0.01)
+    return _CELLS[(nseeds, shape)]
+
+
+@pytest.mark.parametrize("anisotropy", [(3.58, 3.58, 40.0), (1.1, 1.1, 1.1), (0.1, 0.3, 0.2), (0.7, 1.3, 2.1), (30.0, 6.0, 6.0),
+                                        (1.0e-3, 1.0, 1.0), (7.25, 0.5, 1.3)])
+def test_inexact_voxel_sizes_both_candidate_forms(edt_gpu, oracle_port, anisotropy):
+    """Voxel sizes whose c_d = w2 * d^2 are not exactly representable in fp32: the windowed path forms its candidates as
+    fp32 fma's where the reference's fp64 sums are exact (edt_colwave_lane.h: brute_f32e_prefix) and as fp64 sums
+    otherwise (debug bit 0x2000000 keeps the latter everywhere) -- both against the oracle, on cells of ~20 and ~45 voxels
+    (windows of a few and of tens of rows) with and without the border."""
+    from edt import _lib
+    lib = _lib.load()
+    for nseeds, shape in ((300, (160, 144, 130)), (24, (130, 160, 150))):
+        lab = _cells(nseeds, shape)
+        for bb in (False, True):
+            want = oracle_port.edtsq(lab, anisotropy, bb)
+            try:
+                for mode in (0, 0x2000000, 0x100000):
+                    lib.edt_hip_set_debug_mode(mode)
+                    got = edt_gpu.edtsq(lab, anisotropy=anisotropy, black_border=bb)
+                    assert np.array_equal(got, want), (anisotropy, bb, hex(mode), int((got != want).sum()))
+            finally:
+                lib.edt_hip_set_debug_mode(0)

@@ -128,3 +128,43 @@ def test_two_threads_two_streams_stay_bit_exact(edt_gpu, oracle_port):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_volume_beyond_2_32_voxels(edt_gpu):
+    """A volume of more than 2^32 voxels (1280 x 2048 x 1664 = 4.36e9: 4.4 GB of uint8 labels, 17.4 GB of results) --
+    what a 288 GB device is for; every element offset past 2^32 has to be 64-bit arithmetic in every kernel.  Labels: boxes
+    of 160 x 256 x 208 voxels whose face neighbours all carry another label, black border: the squared distance of a voxel
+    is the smallest of its three squared distances to the faces of its box (exact small integers times the voxel sizes),
+    formed on the device by broadcasting.  Built and checked on the device; skipped where 60 GB are not free."""
+    import torch
+    from edt import _lib, device
+
+    if torch.cuda.mem_get_info()[0] < 60 * (1 << 30):
+        pytest.skip("needs 60 GB of free device memory")
+    sx, sy, sz = 1280, 2048, 1664
+    box = (160, 256, 208)
+    w = (1.0, 2.0, 3.0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    idx = [torch.arange(s, device=dev) for s in (sx, sy, sz)]
+    cell = [(i // b).to(torch.uint8) for i, b in zip(idx, box)]
+    lab = ((cell[2][:, None, None] + cell[1][None, :, None] + cell[0][None, None, :]) % 3 + 1).contiguous()  # [z][y][x]
+    assert lab.dtype == torch.uint8 and lab.numel() > 1 << 32
+    face = [(torch.minimum(i % b + 1, b - i % b).to(torch.float32) * wa) ** 2 for i, b, wa in zip(idx, box, w)]
+    plan = device.Plan((sx, sy, sz), _lib.U8, dev)
+    out = plan.run(lab, w, black_border=True)
+    torch.cuda.synchronize()
+    del lab
+    # compared slab by slab (no second 17 GB tensor)
+    bad = 0
+    for z0 in range(0, sz, 64):
+        want = torch.minimum(torch.minimum(face[2][z0:z0 + 64, None, None], face[1][None, :, None]), face[0][None, None, :])
+        bad += int((out[z0:z0 + 64] != want).sum())
+    assert bad == 0
+    # ... and the fused square root on the same plan, last slab only (the far end of every offset)
+    out = plan.run(((cell[2][:, None, None] + cell[1][None, :, None] + cell[0][None, None, :]) % 3 + 1).contiguous(), w,
+                   black_border=True, sqrt=True, out=out)
+    torch.cuda.synchronize()
+    want = torch.minimum(torch.minimum(face[2][-64:, None, None], face[1][None, :, None]), face[0][None, None, :]).sqrt()
+    assert torch.equal(out[-64:], want)
+    del out, plan
+    torch.cuda.empty_cache()

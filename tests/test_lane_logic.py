@@ -154,6 +154,48 @@ def test_fma_candidates_are_exercised(emul, oracle_port):
     assert np.array_equal(got, oracle_port.raw2d(lab, 2, 64, 512, (3.58, 40.0), True).reshape(512, 64))
 
 
+def test_fma_candidate_criterion_implies_exact_fp64_sums(emul):
+    """brute_f32e_prefix(w, fmin, want) = T promises: for every d <= T and every fp32 field value F with fmin <= F <= c_T
+    the reference's fp64 sum w2 * d^2 + F is EXACT (then fl32 of it is what one fp32 fma gives).  Checked in rational
+    arithmetic on adversarial values: F with its last significand bit set at the smallest and largest exponents allowed,
+    d at the end of the window."""
+    from fractions import Fraction
+    emul.lane_emul_f32e_prefix.restype = ctypes.c_int
+    rng = np.random.default_rng(11)
+    checked = 0
+    for t in range(3000):
+        if t % 3 == 0:
+            w = np.float32(rng.uniform(0.05, 60.0))
+        elif t % 3 == 1:
+            w = np.float32(rng.integers(1, 4000) * 2.0 ** int(rng.integers(-12, 4)))
+        else:
+            w = np.float32(10.0 ** rng.uniform(-3, 3))
+        wx = np.float32(w * np.float32(2.0 ** rng.uniform(-6, 6)))
+        fmin = np.float32(wx * wx)
+        want = int(rng.integers(64, 2049))
+        T = emul.lane_emul_f32e_prefix(ctypes.c_float(float(w)), ctypes.c_float(float(fmin)), ctypes.c_int(want))
+        assert 0 <= T <= want
+        if T == 0:
+            continue
+        w2 = np.float32(w * w)          # fp32 product, widened by the reference (src/edt.hpp:181, :258)
+        cT = float(w2) * T * T
+        for d in (T, T - 1, max(1, T // 2), 1):
+            cd = float(w2) * float(d * d)               # the reference's fp64 product
+            assert Fraction(cd) == Fraction(float(w2)) * d * d  # (exact: 24 x 24 bits)
+            # field values: fmin itself, fmin's binade with the last bit set, the largest fp32 <= c_T with the last bit set
+            top = np.nextafter(np.float32(min(cT, 3.0e38)), np.float32(0)) if np.float32(cT) > cT else np.float32(cT)
+            cands = [fmin, np.nextafter(fmin, np.float32(np.inf)), top, np.nextafter(top, np.float32(0)),
+                     np.float32(rng.uniform(float(fmin), max(float(fmin), float(top))))]
+            for F in cands:
+                F = np.float32(F)
+                if not (fmin <= F) or float(F) > cT:
+                    continue
+                s64 = cd + float(F)                      # fp64 sum, as the reference forms it
+                assert Fraction(s64) == Fraction(cd) + Fraction(float(F)), (float(w), float(fmin), T, d, float(F))
+                checked += 1
+    assert checked > 5000
+
+
 def codes_exact(w, sx):
     """mirror of edt_rowwave.hip: row_codes_exact -- k * w is exact in fp32 for every k <= sx + 1"""
     w = float(np.float32(w))

@@ -290,8 +290,8 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   // lower bounds of the non-zero values passes Y and Z read (AxisGeom::fmin): pass X leaves fl32(T[k]^2) >= fl32(wx^2),
   // pass Y's results are at least the smaller of that and fl32(wy^2) (every candidate is its row's own value or carries
   // a c_d >= w2y; the border terms are >= w2y).  Not for the fused sqrt of a 2-D call (pass Z does not exist then).
-  const float fmin_y = wx * wx;
-  const float fmin_z = fminf(wx * wx, wy * wy);
+  const float fmin_y = edt_hip_field_floor(wx, wx);
+  const float fmin_z = edt_hip_field_floor(wx, wy);
   p.gy.fmin = fmin_y;
   p.gz.fmin = fmin_z;
 
@@ -966,7 +966,7 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
   const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0;
   AxisGeom gy = make_geom_y(sx, sy, sz_local);
-  gy.fmin = wx * wx;  // (pass Y reads the results of pass X: AxisGeom::fmin)
+  gy.fmin = edt_hip_field_floor(wx, wx);  // (pass Y reads the results of pass X: AxisGeom::fmin)
   const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
   const bool tiled_y = !force_generic && column_inplace_supported(gy);
   float *xout = tiled_y ? d_partial : p.bufB;  // the tiled y pass runs in place
@@ -994,6 +994,13 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
 int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx, int64_t sy_local,
                            int64_t sz, float wz, int flags, void *d_workspace,
                            size_t workspace_bytes, void *stream_) {
+  return edt_hip_shard_z_device_ex(d_partial, d_zflags, sx, sy_local, sz, wz, 0.0f, flags, d_workspace, workspace_bytes,
+                                   stream_);
+}
+
+int edt_hip_shard_z_device_ex(float *d_partial, const uint8_t *d_zflags, int64_t sx, int64_t sy_local,
+                              int64_t sz, float wz, float field_floor, int flags, void *d_workspace,
+                              size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
   if (rc != EDT_OK) return rc;
@@ -1006,7 +1013,8 @@ int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
   const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
-  const AxisGeom gz = make_geom_z(sx, sy_local, sz);
+  AxisGeom gz = make_geom_z(sx, sy_local, sz);
+  gz.fmin = field_floor > 0.0f ? field_floor : 0.0f;  // (AxisGeom::fmin; NaN and negatives: unknown)
   rc = launch_bits_from_flags(d_zflags, p.nz, p.rs, gz, stream);
   if (rc != EDT_OK) return rc;
   if (!(flags & EDT_FLAG_FORCE_GENERIC) && column_inplace_supported(gz))
@@ -1016,6 +1024,14 @@ int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx
   EDT_HIP_TRY(hipMemcpyAsync(d_partial, p.bufB, (size_t)(sx * sy_local * sz) * sizeof(float),
                              hipMemcpyDeviceToDevice, stream));
   return EDT_OK;
+}
+
+// min(fl32(wx*wx), fl32(wy*wy)): what every non-zero value of a field is at least after passes X and Y (run_device has
+// the argument); 0 where a voxel size is not a positive finite number
+float edt_hip_field_floor(float wx, float wy) {
+  const float a = wx * wx, b = wy * wy;
+  if (!(a > 0.0f) || !(b > 0.0f) || !(a < INFINITY) || !(b < INFINITY)) return 0.0f;
+  return a < b ? a : b;
 }
 
 int edt_hip_shard_records_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
@@ -1068,7 +1084,7 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
   AxisGeom gy = make_geom_y(sx, sy, sz_local);
-  gy.fmin = wx * wx;  // (pass Y reads the results of pass X: AxisGeom::fmin)
+  gy.fmin = edt_hip_field_floor(wx, wx);  // (pass Y reads the results of pass X: AxisGeom::fmin)
   // destination map: every 32-row band of y lies inside one part
   BandScatter sc;
   bool aligned = (sx % 4) == 0;
@@ -1107,6 +1123,13 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
 
 int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz,
                                    int flags, void *d_workspace, size_t workspace_bytes, void *stream_) {
+  return edt_hip_shard_z_records_device_ex(d_records, sx, sy_local, sz, wz, 0.0f, flags, d_workspace, workspace_bytes,
+                                           stream_);
+}
+
+int edt_hip_shard_z_records_device_ex(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz,
+                                      float field_floor, int flags, void *d_workspace, size_t workspace_bytes,
+                                      void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
   if (rc != EDT_OK) return rc;
@@ -1133,6 +1156,7 @@ int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_loca
   AxisGeom gz;  // z-columns of the record buffer: consecutive z are one record apart
   gz.sx = sx; gz.n = sz; gz.stride = rec; gz.nouter = sy_local; gz.outer_stride = sx;
   gz.nbands = ceil_div(sz, kBandRows);
+  gz.fmin = field_floor > 0.0f ? field_floor : 0.0f;
   ScopedPass t("z_pass", stream);
   return launch_column_pass_wave(d_records, p.nz_z, p.rs_z, gz, wz, bb, epi, stream);
 }

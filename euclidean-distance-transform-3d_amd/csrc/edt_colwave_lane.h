@@ -1163,7 +1163,6 @@ EDT_LANE void mono_anchor(const MonoLane &L, float Ba, float Fa, float &best, in
 // and its row.  Per-lane trip counts: the loop is an ordinary divergent one.
 template <int CW>
 EDT_LANE void mono_row(const MonoLane &L, int p, int lo, int hi, float &best, int &arg) {
-  constexpr int TC = TileGeom<CW>::kCols;
   // c = w2 * (p - j)^2 and its difference to the next candidate, stepped exactly: g = c_(j+1) - c_j = w2 * (1 - 2*(p - j))
   const float dj = (float)(p - lo);
   float c = L.w2f * (dj * dj);
@@ -1183,7 +1182,6 @@ EDT_LANE void mono_row(const MonoLane &L, int p, int lo, int hi, float &best, in
 // Seven rows p0+1 .. p0+7 (best[0..6]) against the candidates lo .. hi, no argmin.
 template <int CW>
 EDT_LANE void mono_gap(const MonoLane &L, int p0, int lo, int hi, float *best) {
-  constexpr int TC = TileGeom<CW>::kCols;
   float d[8];  // d[i] = (p0 + 1 + i) - j as a float (|d| < 2^12), stepped by -1 per candidate
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll

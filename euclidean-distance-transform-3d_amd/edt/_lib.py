@@ -75,6 +75,9 @@ SIGNATURES = {
     "edt_hip_shard_records_workspace_bytes": (_sz, [_i, _i64, _i64, _i64]),
     "edt_hip_shard_xy_records_device": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _f, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "edt_hip_shard_z_records_device": (_i, [_vp, _i64, _i64, _i64, _f, _i, _vp, _sz, _vp]),
+    "edt_hip_shard_z_device_ex": (_i, [_vp, _vp, _i64, _i64, _i64, _f, _f, _i, _vp, _sz, _vp]),
+    "edt_hip_shard_z_records_device_ex": (_i, [_vp, _i64, _i64, _i64, _f, _f, _i, _vp, _sz, _vp]),
+    "edt_hip_field_floor": (_f, [_f, _f]),
     "edt_hip_subtract_device": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "edt_hip_voxel_graph_workspace_bytes": (_sz, [_i, _i64, _i64, _i64]),
     "edt_hip_edtsq_voxel_graph_device": (_i, [_vp, _i, _vp, _i, _i64, _i64, _i64, _f, _f, _f, _i, _vp, _vp, _sz, _vp]),

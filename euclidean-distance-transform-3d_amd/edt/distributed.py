@@ -62,6 +62,11 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
+        self.field_floor = 0.0  # lower bound of the non-zero values the Z phase reads (edt_hip.h: field_floor); 0 = unknown
+
+    def set_voxel_sizes(self, wx, wy):
+        """The caller of both phases knows what the XY phase leaves: every non-zero value >= min(fl32(wx^2), fl32(wy^2))."""
+        self.field_floor = float(self.lib.edt_hip_field_floor(wx, wy))
 
     def _workspace(self, nbytes, device, slot=0):
         """Scratch of one stream of work (`slot`): calls that may overlap use different slots."""
@@ -111,15 +116,15 @@ class HipOps:
         """Z pass in place over the gathered (sz, record_floats) buffer."""
         sz = records.shape[0]
         ws = self._workspace(self.lib.edt_hip_shard_records_workspace_bytes(_lib.U8, sx, syl, sz), records.device)
-        _lib.check(self.lib.edt_hip_shard_z_records_device(
-            ctypes.c_void_p(records.data_ptr()), sx, syl, sz, wz, flags, ctypes.c_void_p(ws.data_ptr()),
+        _lib.check(self.lib.edt_hip_shard_z_records_device_ex(
+            ctypes.c_void_p(records.data_ptr()), sx, syl, sz, wz, self.field_floor, flags, ctypes.c_void_p(ws.data_ptr()),
             ws.numel(), self._stream()))
 
     def z(self, partial, zflags, wz, flags):
         sz, syl, sx = partial.shape
         ws = self._workspace(self.lib.edt_hip_shard_workspace_bytes(_lib.U8, sx, syl, sz), partial.device)
-        _lib.check(self.lib.edt_hip_shard_z_device(
-            ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(zflags.data_ptr()), sx, syl, sz, wz,
+        _lib.check(self.lib.edt_hip_shard_z_device_ex(
+            ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(zflags.data_ptr()), sx, syl, sz, wz, self.field_floor,
             flags, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
         return partial
 
@@ -363,6 +368,8 @@ class ShardedEDT:
             raise ValueError(f"rank {self.rank}: expected a contiguous ({ze - zs}, {self.sy}, {self.sx}) slab")
         w = tuple(float(np.float32(v)) for v in weights_xyz)
         flags = (_lib.FLAG_BLACK_BORDER if black_border else 0)
+        if hasattr(self.ops, "set_voxel_sizes"):  # (the GPU phases: the Z phase may use what the XY phase guarantees)
+            self.ops.set_voxel_sizes(w[0], w[1])
         halo = self._halo(labels)
         if self.records:
             out = self._run_records(labels, w, flags, sqrt, halo)

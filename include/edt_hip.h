@@ -222,6 +222,16 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
 int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx,
                            int64_t sy_local, int64_t sz, float wz, int flags,
                            void *d_workspace, size_t workspace_bytes, void *stream);
+/* The same with `field_floor`: a lower bound of the NON-ZERO values of the partial field, which the caller of both
+ * phases knows -- after edt_hip_shard_xy_* every non-zero value is at least min(fl32(wx*wx), fl32(wy*wy))
+ * (edt_hip_field_floor).  It lets the Z pass form its candidates in fp32 for voxel sizes whose multiples are not exact
+ * in fp32; results are the same bits either way.  0 (or anything not positive) = unknown, which is
+ * what the entry points without the argument pass.  A floor ABOVE a non-zero value of the field is a contract
+ * violation (results may differ from the reference's in the last bit). */
+float edt_hip_field_floor(float wx, float wy);
+int edt_hip_shard_z_device_ex(float *d_partial, const uint8_t *d_zflags, int64_t sx,
+                              int64_t sy_local, int64_t sz, float wz, float field_floor, int flags,
+                              void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* Slab records: the fast form of the same two phases (sx <= 1024, sy and sz <= 2048; query with
  * edt_hip_shard_records_supported, otherwise use the pair above).  The y axis is cut into `nparts`
@@ -248,6 +258,9 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
 int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_local, int64_t sz,
                                    float wz, int flags, void *d_workspace, size_t workspace_bytes,
                                    void *stream);
+int edt_hip_shard_z_records_device_ex(float *d_records, int64_t sx, int64_t sy_local, int64_t sz,
+                                      float wz, float field_floor, int flags, void *d_workspace,
+                                      size_t workspace_bytes, void *stream);
 
 /* ---- fused helpers on device-resident data ------------------------------------------ */
 /* out[i] = a[i] - b[i]  (src/edt.pyx:156-158, sdf = edt(x) - edt(x == 0)) */

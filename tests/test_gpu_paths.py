@@ -79,8 +79,11 @@ def test_shard_phases_as_virtual_ranks(edt_gpu, oracle_port, world, shape):
     lab = voronoi_labels(shape, nseeds=40, seed=world, upsample=4, membrane=0.04)
     t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev)  # (sz, sy, sx), x fastest
     zparts, yparts = balanced_partition(sz, world), balanced_partition(sy, world)
-    for an, bb, sqrt in (((6.0, 6.0, 30.0), True, False), ((1.0, 1.5, 0.5), False, True)):
+    # (the third: voxel sizes whose multiples are not exact in fp32, the Z phase told what the XY phase guarantees --
+    # edt_hip_shard_z_device_ex's field_floor, fp32 fma candidates)
+    for an, bb, sqrt in (((6.0, 6.0, 30.0), True, False), ((1.0, 1.5, 0.5), False, True), ((1.1, 0.7, 1.3), False, False)):
         flags = _lib.FLAG_BLACK_BORDER if bb else 0
+        ops.set_voxel_sizes(an[0], an[1])
         partial, zflags = [], []
         for r, (zs, ze) in enumerate(zparts):
             halo = t[zs - 1].contiguous() if r > 0 else None  # the previous rank's last slice
@@ -108,7 +111,7 @@ def _record_case(shape, oracle_port):
     """labels + oracle answers of one shape, computed once for all virtual world sizes"""
     if shape not in _RECORD_CASES:
         lab = voronoi_labels(shape, nseeds=40, seed=sum(shape), upsample=4, membrane=0.04)
-        runs = [((6.0, 6.0, 30.0), True, False), ((1.0, 1.5, 0.5), False, True)]
+        runs = [((6.0, 6.0, 30.0), True, False), ((1.0, 1.5, 0.5), False, True), ((1.1, 0.7, 1.3), True, False)]
         wants = []
         for an, bb, sqrt in runs:
             w = oracle_port.edtsq(lab, an, bb)
@@ -143,6 +146,7 @@ def test_shard_records_as_virtual_ranks(edt_gpu, oracle_port, world, chunks, sha
     rec = [ops.record_floats(sx, b - a) for a, b in yparts]
     for (an, bb, sqrt), want in zip(runs, wants):
         flags = _lib.FLAG_BLACK_BORDER if bb else 0
+        ops.set_voxel_sizes(an[0], an[1])  # (the Z phase may use fp32 fma candidates: edt_hip.h, field_floor)
         dst = [torch.full((sz, rec[h]), float("nan"), dtype=torch.float32, device=dev) for h in range(world)]
         for r, (zs, ze) in enumerate(zparts):
             halo = t[zs - 1] if r > 0 else None  # the previous rank's last slice

@@ -578,7 +578,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)   # 0.65 s of timed kernels: long enough for a busy-sampler to see
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=512, help="edge length of the per-GPU volume")
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg3m", "cfg4", "cfg5", "cfg3L", "cfg3La",
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg3f", "cfg3m", "cfg4", "cfg5", "cfg3L", "cfg3La",
                                                         "cfg3M", "cfg3Ma"])
     ap.add_argument("--secondary", default="", help="comma-separated subset of the secondary configurations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -659,10 +659,11 @@ def main():
         del head
         torch.cuda.empty_cache()
         what = {"cfg3": "2000 labels (up-sampled x4: cells ~34 voxels)", "cfg3m": "2000 labels + 5 % zero membranes",
+                "cfg3f": "the 2000 labels of cfg3 at voxel sizes whose multiples are not exact in fp32",
                 "cfg3L": "~60 full-resolution Voronoi cells (~130 voxels across)", "cfg3La": "~60 full-resolution cells",
                 "cfg3M": "~500 full-resolution Voronoi cells (~65 voxels across)", "cfg3Ma": "~500 full-resolution cells",
                 "cfg4": "the 1024^3 segmentation of configs[3] (16 000 seeds) on ONE GPU"}
-        todo = [("cfg3", n), ("cfg3m", n), ("cfg3L", n), ("cfg3La", n), ("cfg3M", n), ("cfg3Ma", n), ("cfg4", 2 * n)]
+        todo = [("cfg3", n), ("cfg3f", n), ("cfg3m", n), ("cfg3L", n), ("cfg3La", n), ("cfg3M", n), ("cfg3Ma", n), ("cfg4", 2 * n)]
         only = [c for c in args.secondary.split(",") if c]
         verify = os.environ.get("EDT_BENCH_VERIFY", "1") != "0"
         for name, size in todo:

@@ -109,6 +109,7 @@ def config_volume(name: str, n: int = 512):
       cfg1: all-ones uint32, (1,1,1), black_border=True
       cfg2: all-ones uint32 single label, (6,6,30), black_border=True      <- headline metric
       cfg3: ~2000 (scaled with volume) random multi-labels, black_border=False
+      cfg3f: the same labels at anisotropy (3.58, 3.58, 40)
       cfg4: the same kind of segmentation as configs[3] builds it (16 000 seeds at 1024^3), black_border=False
       cfg5: uint8 binary blobs, black_border=True
       cfg3L / cfg3La / cfg3M / cfg3Ma: full-resolution Voronoi segmentations with LARGE cells (~130 / ~65 voxels
@@ -121,6 +122,9 @@ def config_volume(name: str, n: int = 512):
     if name == "cfg3":
         nseeds = max(8, int(round(2000 * (n / 512.0) ** 3)))
         return voronoi_labels((n, n, n), nseeds, seed=0, upsample=4), (1.0, 1.0, 1.0), False
+    if name == "cfg3f":  # same labels, voxel sizes whose multiples are not exact in fp32 (a typical EM resolution in nm)
+        nseeds = max(8, int(round(2000 * (n / 512.0) ** 3)))
+        return voronoi_labels((n, n, n), nseeds, seed=0, upsample=4), (3.58, 3.58, 40.0), False
     if name == "cfg3m":  # same with thin zero membranes
         nseeds = max(8, int(round(2000 * (n / 512.0) ** 3)))
         return voronoi_labels((n, n, n), nseeds, seed=0, upsample=4, membrane=0.05), (6.0, 6.0, 30.0), False

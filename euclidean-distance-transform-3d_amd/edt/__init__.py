@@ -31,7 +31,23 @@ __all__ = [
     "edt", "edtsq", "sdf", "sdfsq",
     "edt1d", "edt1dsq", "edt2d", "edt2dsq", "edt3d", "edt3dsq",
     "each", "edt_stack", "edtsq_stack", "binary_edt", "binary_edtsq", "set_devices", "EdtHipError",
+    "runs", "draw", "transfer", "erase", "reshape", "nvl",
 ]
+
+
+def nvl(val, default_val):
+    """`val`, or `default_val` when it is None (module-level helper of the reference, src/edt.pyx:115-118)."""
+    return default_val if val is None else val
+
+
+def reshape(arr, shape, order=None):
+    """A view of a contiguous array under another shape, in the array's own memory order unless `order` ('C' / 'F') says
+    otherwise -- no copy where the layout allows one (module-level helper of the reference, src/edt.pyx:851-877; an
+    array that is contiguous in neither order is reshaped the numpy way)."""
+    arr = np.asarray(arr)
+    if order is None:
+        order = "F" if arr.flags.f_contiguous else ("C" if arr.flags.c_contiguous else None)
+    return arr.reshape(shape) if order is None else arr.reshape(shape, order=order)
 
 _DTYPE_CODE = {
     np.dtype(np.uint8): _lib.U8, np.dtype(np.int8): _lib.U8,

@@ -97,3 +97,17 @@ def test_device_each_equals_the_reference_definition(dtype, in_place):
         got_keys.append(k)
         assert np.array_equal(img.cpu().numpy(), (lab == k) * mdt)
     assert sorted(got_keys) == sorted(keys)
+
+
+def test_module_level_helpers_reshape_and_nvl():
+    """`edt.reshape` / `edt.nvl` (src/edt.pyx:115-118, :851-877): views of contiguous arrays under another shape in their own
+    memory order; the default for a missing argument."""
+    import edt
+    assert edt.nvl(None, 3) == 3 and edt.nvl(0, 3) == 0
+    a = np.arange(24, dtype=np.int32)
+    f = edt.reshape(np.asfortranarray(a.reshape(4, 6)), (2, 12))
+    assert f.flags.f_contiguous and np.array_equal(f, np.asfortranarray(a.reshape(4, 6)).reshape((2, 12), order="F"))
+    c = edt.reshape(a.reshape(4, 6), (2, 3, 4))
+    assert c.flags.c_contiguous and np.shares_memory(c, a) and np.array_equal(c, a.reshape(2, 3, 4))
+    assert np.shares_memory(edt.reshape(a, (6, 4), order="F"), a)                 # 1-D: contiguous both ways, still a view
+    assert np.array_equal(edt.reshape(a.reshape(4, 6)[:, ::2], (6, 2)), a.reshape(4, 6)[:, ::2].reshape(6, 2))

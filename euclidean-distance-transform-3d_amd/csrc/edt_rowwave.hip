@@ -73,11 +73,12 @@ __device__ __forceinline__ T buf_load(rsrc_t r, uint32_t voff, uint32_t soff) {
 // neither fewer VALU instructions nor 16-byte loads move it any further).
 // XCD-aware schedule (see the kernels): worth it when every XCD gets at least one y-band and z is
 // long enough to have neighbours in flight; returns 1 and rounds the grid to 8 workgroup columns.
-static int row_xcd_schedule(int64_t nby, int64_t sz, int64_t *blocks) {
+static int row_xcd_schedule(int64_t nby, int64_t sz, int64_t *blocks, int groups_per_block = kRowWaves,
+                            int64_t max_per_xcd = 256) {
   if (nby < 8 || sz < 2 || debug_mode() & 256) return 0;
   const int64_t per_xcd = ceil_div(nby, 8) * sz;  // groups of the busiest XCD
-  int64_t bx = ceil_div(per_xcd, kRowWaves);
-  if (bx > 256) bx = 256;
+  int64_t bx = ceil_div(per_xcd, groups_per_block);
+  if (bx > max_per_xcd) bx = max_per_xcd;
   *blocks = bx * 8;
   return 1;
 }
@@ -86,15 +87,24 @@ static int row_xcd_schedule(int64_t nby, int64_t sz, int64_t *blocks) {
 // background, 0xFFFF where neither side has a boundary): half the bytes of the fp32 value, and the first column pass
 // rebuilds F = fl32(fl32(k*w)^2) while it fills its tile (edt_colwave_kernel.h, XF).  Only used when k*w is exact for
 // every k of the row (row_codes_exact): the sequential sums T[k] of the reference then ARE k*w.
-template <typename T, int NC, bool HAS_Z, bool FULL, bool C16>
-__global__ void __launch_bounds__(kRowWaves * 64)
+// H = 2: rows of 1025..2048 voxels as two halves of NC chunks each, one wave per half, a workgroup = the two waves of
+// one group of rows.  All a half needs from the other is one position per row -- the last run start of the left half
+// (where the right half's first run begins) and the first run start of the right half (where the left half's last
+// run ends) -- exchanged through two LDS words per row parity and ONE workgroup barrier per row; both waves walk the
+// same groups and the same rows, so they meet at every barrier.
+template <typename T, int NC, bool HAS_Z, bool FULL, bool C16, int H = 1>
+__global__ void __launch_bounds__((H == 2 ? 2 : kRowWaves) * 64)
 k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t *__restrict__ nz_y,
                 uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, float w,
                 int bb, int to_finite, int nby, int ngroups, int xcd_sched, const T *__restrict__ halo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *Ttab = reinterpret_cast<float *>(smem);  // [sx + 3]: T[0..sx+1], then +inf
+  int *xchg = reinterpret_cast<int *>(smem) + ((sx + 3 + 3) & ~3);  // H == 2: [row parity][half] boundary positions
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
+  constexpr int GW = H == 2 ? 1 : kRowWaves;  // groups of rows a workgroup works on at a time
+  const int gslot = H == 2 ? 0 : wave;        // which of them this wave takes
+  const int xb = H == 2 ? wave * (NC * 64) : 0;  // first voxel of this wave's part of the row
 
   // The reference's sequential fp32 sums of the voxel size (src/edt.hpp:97, :113).
   if (!C16 && threadIdx.x == 0) {
@@ -125,9 +135,10 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
   // walks z in order: slices z-1 and z of one band are then neighbouring waves of one XCD.
   const bool by_xcd = xcd_sched != 0;
   const int xcd = (int)(blockIdx.x & 7), nyk = by_xcd ? (nby - xcd + 7) >> 3 : 0;
-  const int first = by_xcd ? (int)(blockIdx.x >> 3) * kRowWaves + wave : (int)blockIdx.x * kRowWaves + wave;
-  const int step = by_xcd ? (int)(gridDim.x >> 3) * kRowWaves : (int)gridDim.x * kRowWaves;
+  const int first = by_xcd ? (int)(blockIdx.x >> 3) * GW + gslot : (int)blockIdx.x * GW + gslot;
+  const int step = by_xcd ? (int)(gridDim.x >> 3) * GW : (int)gridDim.x * GW;
   const int count = by_xcd ? nyk * sz : ngroups;
+  int par = 0;  // H == 2: which pair of exchange words the next row uses
   for (int i = first; i < count; i += step) {
     const int z = by_xcd ? i / nyk : i / nby;
     const int yb = by_xcd ? xcd + 8 * (i - z * nyk) : i - z * nby;
@@ -147,7 +158,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
     uint32_t nzw[NC], ysw[NC], zsw[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const int x = c * 64 + lane;
+      const int x = xb + c * 64 + lane;
       // every load is unconditional, clamped to a voxel that exists; lanes past the end of the row
       // read the last voxel as their own AND as their left neighbour, so they never mark a start
       xs[c] = (uint32_t)((FULL || x < sx) ? x : sx - 1) * (uint32_t)sizeof(T);
@@ -194,7 +205,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
         const uint32_t poff = (uint32_t)((r - 1) * sx) * OB;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          const int x = c * 64 + lane;
+          const int x = xb + c * 64 + lane;
           if (FULL || x < sx) {
             if (C16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pend[c], rs_out, (uint32_t)x * 2u, poff, EDT_ROW_STORE_AUX);
             else __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, EDT_ROW_STORE_AUX);
@@ -215,27 +226,56 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
         }
       }
       // ---- run starts / ends carried across chunks (scalar unit) ----------------------------
+      int pre_in = pre0, suf_in = suf0;  // what the row looks like to the left / right of this wave's part
+      if constexpr (H == 2) {
+        // this half's boundary position for the other half: the left half's LAST run start, the right half's FIRST one
+        // (kNone: no start in this half -- the other half then sees what lies beyond: pre0 / suf0)
+        constexpr int kNone = INT32_MIN;
+        int mine = kNone;
+        if (any_start) {
+          if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              if (M[c]) mine = xb + c * 64 + 63 - __builtin_clzll(M[c]);
+          } else {
+#pragma unroll
+            for (int c = NC - 1; c >= 0; --c)
+              if (M[c]) mine = xb + c * 64 + __builtin_ctzll(M[c]);
+          }
+        }
+        // (two slots, alternating from row to row ACROSS groups: the barrier of the next row separates this row's reads
+        // from the writes of the row after it)
+        int *slot = xchg + 2 * par;
+        par ^= 1;
+        if (lane == 0) slot[wave] = mine;
+        __syncthreads();
+        const int theirs = __builtin_amdgcn_readfirstlane(slot[wave ^ 1]);
+        if (theirs != kNone) {
+          if (wave == 0) suf_in = theirs;
+          else pre_in = theirs;
+        }
+      }
       int pre[NC], suf[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) { pre[c] = pre0; suf[c] = suf0; }
+      for (int c = 0; c < NC; ++c) { pre[c] = pre_in; suf[c] = suf_in; }
       if (any_start) {
-        int last = pre0;
+        int last = pre_in;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           pre[c] = last;
-          if (M[c]) last = c * 64 + 63 - __builtin_clzll(M[c]);
+          if (M[c]) last = xb + c * 64 + 63 - __builtin_clzll(M[c]);
         }
-        int nxt = suf0;
+        int nxt = suf_in;
 #pragma unroll
         for (int c = NC - 1; c >= 0; --c) {
           suf[c] = nxt;
-          if (M[c]) nxt = c * 64 + __builtin_ctzll(M[c]);
+          if (M[c]) nxt = xb + c * 64 + __builtin_ctzll(M[c]);
         }
       }
       // ---- distances ---------------------------------------------------------------------------
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int x = c * 64 + lane;
+        const int x = xb + c * 64 + lane;
         int il, ir;
         if (M[c] == 0) {
           // no run starts inside this chunk (wave-uniform test): every voxel belongs to the run
@@ -245,8 +285,8 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
         } else {
           const unsigned long long m1 = M[c] & le_mask;
           const unsigned long long m2 = M[c] & gt_mask;
-          const int s = m1 ? c * 64 + 63 - __builtin_clzll(m1) : pre[c];   // first voxel of the run
-          const int e1 = m2 ? c * 64 + __builtin_ctzll(m2) : suf[c];        // one past its last voxel
+          const int s = m1 ? xb + c * 64 + 63 - __builtin_clzll(m1) : pre[c];   // first voxel of the run
+          const int e1 = m2 ? xb + c * 64 + __builtin_ctzll(m2) : suf[c];        // one past its last voxel
           il = x - s + 1;
           ir = e1 - x;
         }
@@ -272,7 +312,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
       const uint32_t poff = (uint32_t)((nrows - 1) * sx) * OB;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int x = c * 64 + lane;
+        const int x = xb + c * 64 + lane;
         if (FULL || x < sx) {
           if (C16) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pend[c], rs_out, (uint32_t)x * 2u, poff, EDT_ROW_STORE_AUX);
           else __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pend[c], rs_out, (uint32_t)x * 4u, poff, EDT_ROW_STORE_AUX);
@@ -285,7 +325,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
     const int64_t wbase = ((int64_t)z * nby + yb) * sx;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const int x = c * 64 + lane;
+      const int x = xb + c * 64 + lane;
       if (FULL || x < sx) {
         // row 0 of the volume starts a run along y, slice 0 starts every run along z
         const uint32_t ys = (__brev(ysw[c]) >> sh) | (y0 == 0 ? 1u : 0u);
@@ -312,27 +352,32 @@ bool row_codes_exact(float w, int64_t sx) {
 }
 
 bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
-  return sx >= 1 && sx <= 1024 && sy * sz < (int64_t)1 << 30 && sx * sy * sz < ((int64_t)1 << 40);
+  // (rows of 1025..2048 voxels: two waves per row, the H = 2 form of the kernel; debug bit 0x4000000 leaves them to the
+  // workgroup-phased kernel of edt_rows.hip)
+  const int64_t widest = (debug_mode() & 0x4000000) ? 1024 : 2048;
+  return sx >= 1 && sx <= widest && sy * sz < (int64_t)1 << 30 && sx * sy * sz < ((int64_t)1 << 40);
 }
 
-template <typename T, int NC>
+template <typename T, int NC, int H = 1>
 static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                               uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
                               int to_finite, hipStream_t stream, const void *halo, bool codes) {
   const int64_t nby = ceil_div(sy, kBandRows);
   const int64_t ngroups = nby * sz;
   if (ngroups <= 0) return EDT_OK;
-  const size_t lds = (size_t)(sx + 3) * sizeof(float);
-  int64_t blocks = ceil_div(ngroups, kRowWaves);
-  const int64_t resident = 256 * 8;  // persistent grid: the T table is built once per workgroup
+  constexpr int GW = H == 2 ? 1 : kRowWaves;        // groups a workgroup works on at a time
+  constexpr int WAVES = H == 2 ? 2 : kRowWaves;     // its waves
+  const size_t lds = (size_t)(((sx + 3 + 3) & ~(int64_t)3) + 4) * sizeof(float);  // T table + the H = 2 exchange words
+  int64_t blocks = ceil_div(ngroups, GW);
+  const int64_t resident = 256 * 8 * (kRowWaves / WAVES);  // persistent grid: the T table is built once per workgroup
   if (blocks > resident) blocks = resident;
-  const int xcd_sched = row_xcd_schedule(nby, sz, &blocks);
+  const int xcd_sched = row_xcd_schedule(nby, sz, &blocks, GW, resident / 8);
 #define LAUNCH(Z, F, C)                                                                                   \
-  hipLaunchKernelGGL((k_row_pass_wave<T, NC, Z, F, C>), dim3((unsigned)blocks), dim3(kRowWaves * 64), lds, stream,  \
+  hipLaunchKernelGGL((k_row_pass_wave<T, NC, Z, F, C, H>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream,  \
                      (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb, to_finite, \
                      (int)nby, (int)ngroups, xcd_sched, (const T *)halo)
 #define LAUNCH_C(Z, F) do { if (codes) LAUNCH(Z, F, true); else LAUNCH(Z, F, false); } while (0)
-  const bool full = sx == 64 * NC;
+  const bool full = sx == 64 * NC * H;
   if (zs_y != nullptr) { if (full) LAUNCH_C(true, true); else LAUNCH_C(true, false); }
   else { if (full) LAUNCH_C(false, true); else LAUNCH_C(false, false); }
 #undef LAUNCH_C
@@ -351,8 +396,15 @@ static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uin
   if (nc <= 2) GO(2);
   if (nc <= 4) GO(4);
   if (nc <= 8) GO(8);
-  GO(16);
+  if (nc <= 16) GO(16);
 #undef GO
+  // rows of 1025..2048 voxels: two waves per row (H = 2), halves of 10, 12, 14 or 16 chunks
+#define GO2(N) return launch_row_wave_tn<T, N, 2>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes)
+  if (nc <= 20) GO2(10);
+  if (nc <= 24) GO2(12);
+  if (nc <= 28) GO2(14);
+  GO2(16);
+#undef GO2
 }
 
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,

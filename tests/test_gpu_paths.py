@@ -221,3 +221,40 @@ def test_short_axes_thread_per_column(edt_gpu, oracle_port):
     img = np.asfortranarray(blocky_labels((5000, 20), nlabels=3, zero_frac=0.3, block=3, rng=rng).astype(np.uint8))
     assert same(edt_gpu.edtsq(img, anisotropy=(2.0, 3.0), black_border=True), oracle_port.edtsq(img, (2.0, 3.0), True))
     assert same(edt_gpu.binary_edtsq(img, anisotropy=(2.0, 3.0), black_border=False), oracle_port.binary_edtsq(img, (2.0, 3.0), False))
+
+
+@pytest.mark.parametrize("sx", [1025, 1088, 1280, 1281, 1535, 1536, 1537, 1600, 1792, 1800, 2047, 2048])
+def test_rows_of_1025_to_2048_voxels_two_waves_per_row(edt_gpu, oracle_port, sx):
+    """Rows of 1025..2048 voxels: pass X as two waves per row (edt_rowwave.hip, H = 2) that exchange one position per
+    row through LDS -- the last run start of the left half, the first of the right half.  Label patterns that stress the
+    exchange: runs that cross the middle of the row, rows whose starts all lie in ONE half, rows without any start, a
+    start exactly at the first voxel of the right half, single-voxel runs; odd numbers of rows in the last y-band (the
+    exchange words alternate from row to row across groups).  Against the oracle, with the 16-bit index form and with
+    fp32 between X and Y, and against the workgroup-phased kernel (debug bit 0x4000000)."""
+    from edt import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(sx)
+    nc = -(-sx // 64)
+    half = 64 * (10 if nc <= 20 else 12 if nc <= 24 else 14 if nc <= 28 else 16)  # (edt_rowwave.hip: launch_row_wave_t)
+    sy, sz = (37, 3) if sx % 2 else (70, 2)
+    dt = [np.uint8, np.uint16, np.uint32, np.uint64, np.float32][sx % 5]
+    lab = blocky_labels((sx, sy, sz), nlabels=3, zero_frac=0.15, block=int(rng.integers(200, 500)), rng=rng)
+    lab[:, 0, :] = 1                              # rows without any run start
+    lab[:half, 1, :] = 1; lab[half:, 1, :] = 2    # one start, exactly at the first voxel of the right half
+    lab[:half - 1, 2, :] = 1; lab[half - 1:, 2, :] = 2  # ... at the last voxel of the left half
+    lab[:, 3, :] = 1; lab[5, 3, :] = 0            # starts in the left half only
+    lab[:, 4, :] = 2; lab[sx - 3, 4, :] = 1       # ... in the right half only
+    lab[:, 5, :] = rng.integers(0, 3, size=(sx, sz))  # single-voxel runs everywhere
+    lab[:, 6, :] = 0                              # background rows
+    lab = np.asfortranarray(lab.astype(dt))
+    for an, bb in (((1.0, 1.0, 1.0), False), ((6.0, 6.0, 30.0), True), ((0.7, 1.3, 2.1), False), ((1.0, 2.0, 1.0), True)):
+        want = oracle_port.edtsq(lab, an, bb)
+        for mode in (0, 0x100000, 0x4000000):
+            lib.edt_hip_set_debug_mode(mode)
+            try:
+                got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+            finally:
+                lib.edt_hip_set_debug_mode(0)
+            assert same(got, want), (sx, dt, an, bb, hex(mode), int((got != want).sum()))
+    img = np.asfortranarray(lab[:, :, 0])         # 2-D (no z bits)
+    assert same(edt_gpu.edtsq(img, anisotropy=(1.0, 1.0), black_border=False), oracle_port.edtsq(img, (1.0, 1.0), False))

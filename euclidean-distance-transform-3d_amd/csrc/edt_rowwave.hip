@@ -1,5 +1,6 @@
 // edt_rowwave.hip -- pass 1 (x axis) for gfx950, register-resident: one wavefront per group of
-// 32 consecutive rows of one z-slice, rows up to 512 voxels (8 chunks of 64 lanes).
+// 32 consecutive rows of one z-slice for rows of up to 1024 voxels (16 chunks of 64 lanes), two wavefronts
+// (one per half of the row, k_row_pass_wave<..., H = 2>) for rows of 1025..2048 voxels.
 //
 // Pass 1 is a label-aware 1-D distance along contiguous rows.  The reference walks each row
 // twice with fp32 recurrences (src/edt.hpp:83-118); the result has the closed form

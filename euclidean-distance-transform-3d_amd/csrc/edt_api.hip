@@ -581,7 +581,7 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
         static std::atomic<bool> said{false};
         if (!said.exchange(true))
           fprintf(stderr, "[edt_hip] note: a %lld x %lld x %lld volume cannot be Z-sharded over %zu devices (slab records: "
-                          "sx <= 1024, sy and sz <= 2048, >= 1 z-slice and >= 32 y-rows per device); device %d runs it alone\n",
+                          "sx, sy and sz <= 2048, >= 1 z-slice and >= 32 y-rows per device); device %d runs it alone\n",
                   (long long)sx, (long long)sy, (long long)sz, devs.size(), devs[0]);
       }
       int prev = 0;
@@ -835,7 +835,7 @@ int edt_hip_edt3dsq_multi(const void *labels, int dtype, int64_t sx, int64_t sy,
     if (devices[i] < 0 || devices[i] >= have) { set_error("device ordinal out of range"); return EDT_ERR_BAD_ARG; }
   const int flags = (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (take_sqrt ? EDT_FLAG_SQRT : 0);
   if (n_devices >= 2 && !multi_supported(dtype, sx, sy, sz, n_devices)) {
-    set_error("this volume cannot be Z-sharded over " + std::to_string(n_devices) + " devices (slab records: sx <= 1024, sy "
+    set_error("this volume cannot be Z-sharded over " + std::to_string(n_devices) + " devices (slab records: sx, sy "
               "and sz <= 2048, at least one z-slice and 32 y-rows per device; edt_hip_multi_supported tells)");
     return EDT_ERR_UNSUPPORTED;
   }
@@ -1037,8 +1037,8 @@ float edt_hip_field_floor(float wx, float wy) {
 int edt_hip_shard_records_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
   if (dtype_size(dtype) == 0 || sx < 1 || sy < 1 || sz < 1) return 0;
   if (g_debug_mode & (32 | 64)) return 0;  // diagnostics: forced fallback kernels
-  // pass 1 by the register-resident row kernel, both column passes by the wave kernel
-  return (sx <= 1024 && sy <= 2048 && sz <= 2048) ? 1 : 0;
+  // pass 1 by the register-resident row kernel (two waves per row beyond 1024 voxels), both column passes by the wave kernel
+  return (row_pass_wave_supported(dtype, sx, sy, sz) && sy <= 2048 && sz <= 2048) ? 1 : 0;
 }
 
 size_t edt_hip_shard_record_floats(int64_t sx, int64_t y_rows) {
@@ -1062,7 +1062,7 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
   if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
   if (!d_labels || !y_splits || !d_blocks || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
   if (!edt_hip_shard_records_supported(dtype, sx, sy, sz_local)) {
-    set_error("slab records need sx <= 1024 and sy <= 2048 (use edt_hip_shard_xy_device)");
+    set_error("slab records need sx <= 2048 and sy <= 2048 (use edt_hip_shard_xy_device)");
     return EDT_ERR_UNSUPPORTED;
   }
   if (y_splits[0] != 0 || y_splits[nparts] != sy) { set_error("y_splits must run from 0 to sy"); return EDT_ERR_BAD_ARG; }
@@ -1136,7 +1136,7 @@ int edt_hip_shard_z_records_device_ex(float *d_records, int64_t sx, int64_t sy_l
   if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
   if (!d_records) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   if (!edt_hip_shard_records_supported(EDT_U8, sx, sy_local, sz)) {
-    set_error("slab records need sx <= 1024 and sz <= 2048 (use edt_hip_shard_z_device)");
+    set_error("slab records need sx <= 2048 and sz <= 2048 (use edt_hip_shard_z_device)");
     return EDT_ERR_UNSUPPORTED;
   }
   RecordPlan p = make_record_plan(sx, sy_local, sz, d_workspace);

@@ -19,7 +19,7 @@
 // (EDT_HIP_ALLOW_STAGED_PEER=1 accepts the runtime's staging through host memory instead).
 //
 // The same device ordinal may appear several times in the list ("virtual devices"): that is how the whole driver is
-// tested on a one-GPU box.  Volumes the slab-record form does not cover (sx > 1024, sy or sz > 2048, fewer y words or
+// tested on a one-GPU box.  Volumes the slab-record form does not cover (sx, sy or sz > 2048, fewer y words or
 // z slices than devices): edt_hip_edt3dsq_multi reports EDT_ERR_UNSUPPORTED (query: edt_hip_multi_supported); the
 // edt_hip_set_devices route runs them on the first listed device and says so once on stderr.
 #include <condition_variable>

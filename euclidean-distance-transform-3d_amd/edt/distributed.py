@@ -20,7 +20,7 @@ The numerical work is done by `ops` (default: the HIP kernels through the C ABI)
 partition / exchange logic here is backend agnostic, which is how the CPU test-suite drives
 it over gloo with a CPU implementation of the two phases.
 
-Fast form ("slab records", include/edt_hip.h): when the extents allow it (sx <= 1024, sy, sz <= 2048, at least
+Fast form ("slab records", include/edt_hip.h): when the extents allow it (sx, sy, sz <= 2048, at least
 one 32-row word of y per rank) the y axis is cut at multiples of 32 rows and the XY phase writes,
 for every destination rank, one contiguous record per xy-slice -- that rank's rows after the
 X and Y passes followed by their foreground / z-run-start BITS (4.25 bytes per voxel).  A

@@ -132,7 +132,7 @@ int edt_hip_binary_edtsq(const void *labels, int dtype, int ndim, int64_t sx, in
  * streams are kept between calls (edt_hip_release_cache frees them).  The same ordinal may be listed more than once
  * (virtual devices: tests on one GPU).  Distinct ordinals must have peer access to each other: a pair without it is
  * EDT_ERR_UNSUPPORTED naming the pair (EDT_HIP_ALLOW_STAGED_PEER=1 in the environment accepts staging through host
- * memory).  A volume the slab-record form cannot cut n_devices ways (edt_hip_multi_supported == 0: sx > 1024, sy or
+ * memory).  A volume the slab-record form cannot cut n_devices ways (edt_hip_multi_supported == 0: sx, sy or
  * sz > 2048, fewer z-slices or 32-row words of y than devices) is EDT_ERR_UNSUPPORTED too; n_devices = 1 runs on
  * that device.
  * edt_hip_set_devices makes the ordinary host-buffer 3-D entry points (edt_hip_edt3dsq / edt_hip_edt3d, and with
@@ -233,7 +233,7 @@ int edt_hip_shard_z_device_ex(float *d_partial, const uint8_t *d_zflags, int64_t
                               int64_t sy_local, int64_t sz, float wz, float field_floor, int flags,
                               void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* Slab records: the fast form of the same two phases (sx <= 1024, sy and sz <= 2048; query with
+/* Slab records: the fast form of the same two phases (sx, sy and sz <= 2048; query with
  * edt_hip_shard_records_supported, otherwise use the pair above).  The y axis is cut into `nparts`
  * destination ranges at multiples of 32 rows (y_splits[0] = 0 ... y_splits[nparts] = sy, HOST array).
  * For destination h and every xy-slice of the slab the XY phase writes ONE contiguous record of

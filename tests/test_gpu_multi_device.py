@@ -28,7 +28,7 @@ def _multi(lab, an, bb, sqrt, devices):
 
 @pytest.mark.parametrize("ndev", [1, 2, 3, 8])
 @pytest.mark.parametrize("shape,dtype", [((96, 280, 24), np.uint32), ((130, 97, 41), np.uint8), ((512, 96, 20), np.uint16),
-                                         ((40, 1000, 9), np.uint64)])
+                                         ((40, 1000, 9), np.uint64), ((1536, 100, 8), np.uint8)])
 def test_virtual_devices_match_the_oracle(edt_gpu, oracle_port, ndev, shape, dtype):
     lab = voronoi_labels(shape, nseeds=40, seed=sum(shape), upsample=4, membrane=0.04).astype(dtype)
     for an, bb, sqrt in (((6.0, 6.0, 30.0), True, False), ((1.0, 1.5, 0.5), False, True)):

@@ -121,7 +121,8 @@ def _record_case(shape, oracle_port):
 
 
 @pytest.mark.parametrize("world,chunks", [(1, 1), (2, 2), (3, 1), (8, 3)])
-@pytest.mark.parametrize("shape", [(96, 280, 24), (512, 96, 20), (1024, 64, 6), (36, 1000, 9), (41, 200, 12), (24, 1500, 5), (16, 96, 1100)])
+@pytest.mark.parametrize("shape", [(96, 280, 24), (512, 96, 20), (1024, 64, 6), (36, 1000, 9), (41, 200, 12), (24, 1500, 5), (16, 96, 1100),
+                                   (2048, 96, 7), (1280, 70, 9)])
 def test_shard_records_as_virtual_ranks(edt_gpu, oracle_port, world, chunks, shape):
     """The slab-record form of the two phases (edt_hip_shard_xy_records_device /
     edt_hip_shard_z_records_device): every virtual rank writes its per-destination records chunk by

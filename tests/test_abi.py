@@ -189,3 +189,18 @@ def test_default_library_ignores_wrong_result_diagnostics():
     res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EDT_HIP_DEBUG_MODE="0x8201"),
                          capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and res.stdout.strip() == str(0x8000), res.stdout + res.stderr
+
+
+def test_field_floor_helper(lib):
+    """edt_hip_field_floor(wx, wy) = min(fl32(wx*wx), fl32(wy*wy)): what the XY phase guarantees about every non-zero
+    value it leaves (the `field_floor` argument of the sharded Z phase); 0 = unknown for sizes that are not positive and
+    finite, and the shard entry points that take it refuse nothing for it (argument validation needs no GPU)."""
+    f32 = np.float32
+    for wx, wy in ((1.0, 1.0), (3.58, 40.0), (40.0, 3.58), (0.1, 0.3), (1e-3, 7.25)):
+        want = min(float(f32(wx) * f32(wx)), float(f32(wy) * f32(wy)))
+        assert lib.edt_hip_field_floor(wx, wy) == want
+    for wx, wy in ((0.0, 1.0), (1.0, float("inf")), (float("nan"), 1.0), (1e30, 1.0), (1e-30, 1.0)):
+        assert lib.edt_hip_field_floor(wx, wy) == 0.0
+    # null pointers are still argument errors with the _ex forms
+    assert lib.edt_hip_shard_z_device_ex(None, None, 8, 8, 8, 1.0, 1.0, 0, None, 0, None) == -2
+    assert lib.edt_hip_shard_z_records_device_ex(None, 8, 8, 8, 1.0, 1.0, 0, None, 0, None) == -2

@@ -246,6 +246,18 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
           BL.live = col < cols_left && band < NB;
           BL.w2 = (double)(w * w); BL.w2f = w * w;
           auto store = [&](int row, float v) { res[(size_t)row * TC + col] = v; };
+#ifdef EDT_CONTIG
+          // the experiment's form: one call per block, the block's position handed in (lane = column x block)
+          for (int k0 = 0; k0 < 32; k0 += 8 * stride) {
+            if (stride == 2) {
+              if (x32) brute_block<CW, BB, true, 2>(BL, k0, epi, store);
+              else brute_block<CW, BB, false, 2>(BL, k0, epi, store);
+            } else {
+              if (x32) brute_block<CW, BB, true, 1>(BL, k0, epi, store);
+              else brute_block<CW, BB, false, 1>(BL, k0, epi, store);
+            }
+          }
+#else
           if (stride == 2) {
             if (x32) brute_band<CW, BB, true, 2>(BL, epi, store);
             else brute_band<CW, BB, false, 2>(BL, epi, store);
@@ -253,6 +265,7 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
             if (x32) brute_band<CW, BB, true, 1>(BL, epi, store);
             else brute_band<CW, BB, false, 1>(BL, epi, store);
           }
+#endif
         }
       for (int row = 0; row < n; row += stride)
         for (int c = 0; c < TC && c < cols_left; ++c) F[x0 + (int64_t)row * rstride + c] = res[(size_t)row * TC + c];

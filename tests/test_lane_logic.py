@@ -104,6 +104,46 @@ def test_column_pass_matches_oracle(emul, oracle_port, n, sx, kind, mode):
                 assert np.array_equal(got[1::2], f1[1::2])
 
 
+@pytest.fixture(scope="module")
+def emul_contig():
+    """the same emulation built with -DEDT_CONTIG: the windowed path as one call per block with the block's position an
+    argument (brute_block; the experiment of DESIGN.md 7.1, not the shipped form)"""
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "liblane_emul_contig.so")
+    src = os.path.join(ROOT, "tests", "lane_emul.cpp")
+    hdr = os.path.join(CSRC, "edt_colwave_lane.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        tmp = f"{so}.{os.getpid()}.tmp"
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-DEDT_CONTIG",
+                        "-fPIC", f"-I{CSRC}", src, "-o", tmp], check=True)
+        os.replace(tmp, so)
+    lib = ctypes.CDLL(so)
+    lib.lane_emul_column_pass_mode.restype = ctypes.c_int
+    return lib
+
+
+@pytest.mark.parametrize("mode", ["window", "window64", "window_even", "auto"])
+@pytest.mark.parametrize("n,sx,kind", [c for c in CASES if c[0] in (1025, 513, 300, 257, 130, 64, 33, 17) and (c[2] != "ones" or c[0] <= 300)])
+def test_block_form_of_the_windowed_path(emul_contig, oracle_port, n, sx, kind, mode):
+    """brute_block (EDT_CONTIG): every block of every band through the per-block entry, against the oracle"""
+    rng = np.random.default_rng(n * 31 + sx)
+    lab = make_labels(n, sx, kind, rng)
+    for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (0.7, 1.3)):
+        for bb in (True, False):
+            f1 = x_pass(oracle_port, lab, wx, bb)
+            want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
+            got = column_pass(emul_contig, lab, f1, wy, bb, 0 if bb else 1, MODES[mode])
+            ev = slice(None, None, 2) if mode.endswith("_even") else slice(None)
+            assert np.array_equal(got[ev], want[ev]), (n, sx, kind, wx, wy, bb)
+            if mode.endswith("_even"):
+                assert np.array_equal(got[1::2], f1[1::2])
+    # fp32 fma candidates (mode 7) through the same entry
+    emul_contig.lane_emul_set_fmin(ctypes.c_float(float(np.float32(3.58) * np.float32(3.58))), ctypes.c_int(1024))
+    f1 = x_pass(oracle_port, lab, 3.58, True)
+    got = column_pass(emul_contig, lab, f1, 40.0, True, 0, 7)
+    assert np.array_equal(got, oracle_port.raw2d(lab, 2, sx, n, (3.58, 40.0), True).reshape(n, sx))
+
+
 # voxel sizes whose c_d = w2 * d^2 are not exactly representable in fp32 (the windowed path then used fp64 candidates):
 # fp32 fma candidates on the tiles the launcher's conditions allow (edt_colwave_lane.h: brute_f32e_prefix)
 F32E_ANISO = ((3.58, 40.0), (3.58, 3.58), (1.1, 1.1), (0.1, 0.3), (0.7, 1.3), (4.0, 40.0), (30.0, 6.0), (1.0, 1.0e-3),

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "euclidean-distance-transform-3d_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+FLAGS += os.environ.get("EDT_SPILL_EXTRA", "").split()  # e.g. EDT_SPILL_EXTRA=-DEDT_CONTIG: a variant build
 
 
 def scan(cw, workdir):

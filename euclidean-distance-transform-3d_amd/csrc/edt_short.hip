@@ -18,7 +18,11 @@ namespace edt_amd {
 
 namespace {
 
-template <int N, bool BB>
+// X32: c_d = w2 * d^2 is exactly representable in fp32 for every d < N (voxel sizes like 1, 6, 30, 40, 0.5; checked on
+// the host, brute_exact_prefix): fl32(fl64(c_d + F)) is then the plain fp32 sum (double rounding is innocuous for a sum
+// when the wide format has >= 2p + 2 bits), so a candidate is one v_add_f32 and one integer minimum (non-negative
+// floats and +inf order like their bit patterns) instead of an fp64 fma, an fp64 minimum and a conversion.
+template <int N, bool BB, bool X32>
 __global__ void __launch_bounds__(256)
 k_column_pass_short(float *__restrict__ F, const uint32_t *__restrict__ nzbits, const uint32_t *__restrict__ rsbits,
                     AxisGeom g, float w, int epi) {
@@ -38,13 +42,28 @@ k_column_pass_short(float *__restrict__ F, const uint32_t *__restrict__ nzbits, 
 #pragma unroll
   for (int p = 0; p < N; ++p) {
     if (p < n && ((nz >> p) & 1u)) {
-      double best = (double)f[p];
+      float res;
+      if constexpr (X32) {
+        uint32_t best = __float_as_uint(f[p]);
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        if (j != p) {
-          const double d = (double)(p - j);
-          best = fmin(best, __builtin_fma(w2 * d, d, (double)f[j]));   // (+inf rows beyond the axis never win)
+        for (int j = 0; j < N; ++j) {
+          if (j != p) {
+            const float cd = w2f * (float)((p - j) * (p - j));              // exact (the host checked)
+            const uint32_t c = __float_as_uint(f[j] + cd);                  // (+inf rows beyond the axis never win)
+            best = c < best ? c : best;
+          }
         }
+        res = __uint_as_float(best);
+      } else {
+        double best = (double)f[p];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          if (j != p) {
+            const double d = (double)(p - j);
+            best = fmin(best, __builtin_fma(w2 * d, d, (double)f[j]));   // (+inf rows beyond the axis never win)
+          }
+        }
+        res = (float)best;
       }
       // borders of p's run: last run start at or below p, first run start above it
       const uint32_t lowm = rs & (0xFFFFFFFFu >> (31 - p));
@@ -52,7 +71,6 @@ k_column_pass_short(float *__restrict__ F, const uint32_t *__restrict__ nzbits, 
       const uint32_t him = p < 31 ? (rs & (0xFFFFFFFEu << p)) : 0u;
       int e = him ? __builtin_ctz(him) - 1 : n - 1;
       if (e > n - 1) e = n - 1;
-      float res = (float)best;
       float dm = INFINITY;
       if (BB || s > 0) dm = (float)(p - s + 1);
       if (BB || e < n - 1) dm = fminf(dm, (float)(e + 1 - p));
@@ -62,6 +80,16 @@ k_column_pass_short(float *__restrict__ F, const uint32_t *__restrict__ nzbits, 
   }
 }
 
+// c_d = fl32(w * w) * d^2 exactly representable in fp32 (and finite) for every d <= dmax
+bool short_exact_c(float w, int dmax) {
+  const double w2 = (double)(w * w);
+  for (int d = 1; d <= dmax; ++d) {
+    const double c = w2 * (double)(d * d);
+    if ((double)(float)c != c || !(c < 3.0e38)) return false;
+  }
+  return true;
+}
+
 template <int N>
 int launch_short_n(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w, int bb, int epi,
                    hipStream_t stream) {
@@ -69,8 +97,13 @@ int launch_short_n(float *F, const uint32_t *nz, const uint32_t *rs, const AxisG
   if (cols <= 0) return EDT_OK;
   const int64_t blocks = ceil_div(cols, 256);
   if (blocks > 0x7FFFFFFF) { set_error("too many columns"); return EDT_ERR_UNSUPPORTED; }
-  if (bb) hipLaunchKernelGGL((k_column_pass_short<N, true>), dim3((unsigned)blocks), dim3(256), 0, stream, F, nz, rs, g, w, epi & 3);
-  else hipLaunchKernelGGL((k_column_pass_short<N, false>), dim3((unsigned)blocks), dim3(256), 0, stream, F, nz, rs, g, w, epi & 3);
+  // fp32 candidates where every c_d the column can meet is exact in fp32 (debug bit 0x8000: fp64 candidates, as on the
+  // windowed path)
+  const bool x32 = !(debug_mode() & 0x8000) && w * w >= 1.17549435e-38f && short_exact_c(w, N - 1);
+#define SHORT_GO(B, X) hipLaunchKernelGGL((k_column_pass_short<N, B, X>), dim3((unsigned)blocks), dim3(256), 0, stream, F, nz, rs, g, w, epi & 3)
+  if (bb) { if (x32) SHORT_GO(true, true); else SHORT_GO(true, false); }
+  else { if (x32) SHORT_GO(false, true); else SHORT_GO(false, false); }
+#undef SHORT_GO
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }

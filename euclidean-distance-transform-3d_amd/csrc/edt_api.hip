@@ -315,7 +315,8 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   const int swaps = (tiled_y ? 0 : 1) + ((zpass && !tiled_z) ? 1 : 0);
   float *cur = (swaps % 2 == 0) ? d_out : p.bufB;
   float *other = (cur == d_out) ? p.bufB : d_out;
-  const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
+  // (pass 1 on the row kernels: the wave kernel up to 4096 voxels per row, the workgroup-phased one up to 2048)
+  const bool tiled_x = !force_generic && (row_pass_tiled_supported(sx) || row_pass_wave_supported(dtype, sx, sy, sz));
   // Index form of pass 1 (see plan_code_slab): pass 1 stores 16-bit distance indices, the first column pass turns
   // them into F while it fills its tile -- 2 B less written and 2 B less read per voxel.  Bit-identical only where
   // every multiple k * wx of the row is exact in fp32 (row_codes_exact); other voxel sizes keep the fp32 form.
@@ -967,7 +968,7 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
   const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0;
   AxisGeom gy = make_geom_y(sx, sy, sz_local);
   gy.fmin = edt_hip_field_floor(wx, wx);  // (pass Y reads the results of pass X: AxisGeom::fmin)
-  const bool tiled_x = !force_generic && row_pass_tiled_supported(sx);
+  const bool tiled_x = !force_generic && (row_pass_tiled_supported(sx) || row_pass_wave_supported(dtype, sx, sy, sz_local));
   const bool tiled_y = !force_generic && column_inplace_supported(gy);
   float *xout = tiled_y ? d_partial : p.bufB;  // the tiled y pass runs in place
   if (tiled_x) {
@@ -1038,7 +1039,7 @@ int edt_hip_shard_records_supported(int dtype, int64_t sx, int64_t sy, int64_t s
   if (dtype_size(dtype) == 0 || sx < 1 || sy < 1 || sz < 1) return 0;
   if (g_debug_mode & (32 | 64)) return 0;  // diagnostics: forced fallback kernels
   // pass 1 by the register-resident row kernel (two waves per row beyond 1024 voxels), both column passes by the wave kernel
-  return (row_pass_wave_supported(dtype, sx, sy, sz) && sy <= 2048 && sz <= 2048) ? 1 : 0;
+  return (sx <= 2048 && row_pass_wave_supported(dtype, sx, sy, sz) && sy <= 2048 && sz <= 2048) ? 1 : 0;
 }
 
 size_t edt_hip_shard_record_floats(int64_t sx, int64_t y_rows) {

@@ -1,6 +1,6 @@
 // edt_rowwave.hip -- pass 1 (x axis) for gfx950, register-resident: one wavefront per group of
-// 32 consecutive rows of one z-slice for rows of up to 1024 voxels (16 chunks of 64 lanes), two wavefronts
-// (one per half of the row, k_row_pass_wave<..., H = 2>) for rows of 1025..2048 voxels.
+// 32 consecutive rows of one z-slice for rows of up to 1024 voxels (16 chunks of 64 lanes), two / four wavefronts
+// (one per part of the row, k_row_pass_wave<..., H = 2 / 4>) for rows of 1025..2048 / 2049..4096 voxels.
 //
 // Pass 1 is a label-aware 1-D distance along contiguous rows.  The reference walks each row
 // twice with fp32 recurrences (src/edt.hpp:83-118); the result has the closed form
@@ -88,24 +88,24 @@ static int row_xcd_schedule(int64_t nby, int64_t sz, int64_t *blocks, int groups
 // background, 0xFFFF where neither side has a boundary): half the bytes of the fp32 value, and the first column pass
 // rebuilds F = fl32(fl32(k*w)^2) while it fills its tile (edt_colwave_kernel.h, XF).  Only used when k*w is exact for
 // every k of the row (row_codes_exact): the sequential sums T[k] of the reference then ARE k*w.
-// H = 2: rows of 1025..2048 voxels as two halves of NC chunks each, one wave per half, a workgroup = the two waves of
-// one group of rows.  All a half needs from the other is one position per row -- the last run start of the left half
-// (where the right half's first run begins) and the first run start of the right half (where the left half's last
-// run ends) -- exchanged through two LDS words per row parity and ONE workgroup barrier per row; both waves walk the
-// same groups and the same rows, so they meet at every barrier.
+// H = 2 / 4: rows of 1025..2048 / 2049..4096 voxels as H parts of NC chunks each, one wave per part, a workgroup = the
+// H waves of one group of rows.  All a part needs from the others is one position per side and row -- the last run start
+// to its left (where its first run begins) and the first run start to its right (where its last run ends) -- so every
+// wave publishes the last and the first start of its own part in LDS, ONE workgroup barrier per row, and takes the
+// nearest ones on either side; all waves walk the same groups and the same rows, so they meet at every barrier.
 template <typename T, int NC, bool HAS_Z, bool FULL, bool C16, int H = 1>
-__global__ void __launch_bounds__((H == 2 ? 2 : kRowWaves) * 64)
+__global__ void __launch_bounds__((H >= 2 ? H : kRowWaves) * 64)
 k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t *__restrict__ nz_y,
                 uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, float w,
                 int bb, int to_finite, int nby, int ngroups, int xcd_sched, const T *__restrict__ halo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *Ttab = reinterpret_cast<float *>(smem);  // [sx + 3]: T[0..sx+1], then +inf
-  int *xchg = reinterpret_cast<int *>(smem) + ((sx + 3 + 3) & ~3);  // H == 2: [row parity][half] boundary positions
+  int *xchg = reinterpret_cast<int *>(smem) + ((sx + 3 + 3) & ~3);  // H >= 2: [row parity][part][last, first] boundary positions
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
-  constexpr int GW = H == 2 ? 1 : kRowWaves;  // groups of rows a workgroup works on at a time
-  const int gslot = H == 2 ? 0 : wave;        // which of them this wave takes
-  const int xb = H == 2 ? wave * (NC * 64) : 0;  // first voxel of this wave's part of the row
+  constexpr int GW = H >= 2 ? 1 : kRowWaves;  // groups of rows a workgroup works on at a time
+  const int gslot = H >= 2 ? 0 : wave;        // which of them this wave takes
+  const int xb = H >= 2 ? wave * (NC * 64) : 0;  // first voxel of this wave's part of the row
 
   // The reference's sequential fp32 sums of the voxel size (src/edt.hpp:97, :113).
   if (!C16 && threadIdx.x == 0) {
@@ -139,7 +139,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
   const int first = by_xcd ? (int)(blockIdx.x >> 3) * GW + gslot : (int)blockIdx.x * GW + gslot;
   const int step = by_xcd ? (int)(gridDim.x >> 3) * GW : (int)gridDim.x * GW;
   const int count = by_xcd ? nyk * sz : ngroups;
-  int par = 0;  // H == 2: which pair of exchange words the next row uses
+  int par = 0;  // H >= 2: which set of exchange words the next row uses
   for (int i = first; i < count; i += step) {
     const int z = by_xcd ? i / nyk : i / nby;
     const int yb = by_xcd ? xcd + 8 * (i - z * nyk) : i - z * nby;
@@ -228,32 +228,36 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
       }
       // ---- run starts / ends carried across chunks (scalar unit) ----------------------------
       int pre_in = pre0, suf_in = suf0;  // what the row looks like to the left / right of this wave's part
-      if constexpr (H == 2) {
-        // this half's boundary position for the other half: the left half's LAST run start, the right half's FIRST one
-        // (kNone: no start in this half -- the other half then sees what lies beyond: pre0 / suf0)
+      if constexpr (H >= 2) {
+        // this part's boundary positions for the other parts: its LAST run start (where the first run of the part to
+        // its right begins) and its FIRST one (where the last run of the part to its left ends); kNone: no start in
+        // this part -- the others then look further, and past the row's ends see pre0 / suf0
         constexpr int kNone = INT32_MIN;
-        int mine = kNone;
+        int my_last = kNone, my_first = kNone;
         if (any_start) {
-          if (wave == 0) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-              if (M[c]) mine = xb + c * 64 + 63 - __builtin_clzll(M[c]);
-          } else {
+          for (int c = 0; c < NC; ++c)
+            if (M[c]) my_last = xb + c * 64 + 63 - __builtin_clzll(M[c]);
 #pragma unroll
-            for (int c = NC - 1; c >= 0; --c)
-              if (M[c]) mine = xb + c * 64 + __builtin_ctzll(M[c]);
-          }
+          for (int c = NC - 1; c >= 0; --c)
+            if (M[c]) my_first = xb + c * 64 + __builtin_ctzll(M[c]);
         }
-        // (two slots, alternating from row to row ACROSS groups: the barrier of the next row separates this row's reads
-        // from the writes of the row after it)
-        int *slot = xchg + 2 * par;
+        // (two sets of words, alternating from row to row ACROSS groups: the barrier of the next row separates this
+        // row's reads from the writes of the row after it)
+        int *slot = xchg + 2 * H * par;
         par ^= 1;
-        if (lane == 0) slot[wave] = mine;
+        if (lane == 0) { slot[2 * wave] = my_last; slot[2 * wave + 1] = my_first; }
         __syncthreads();
-        const int theirs = __builtin_amdgcn_readfirstlane(slot[wave ^ 1]);
-        if (theirs != kNone) {
-          if (wave == 0) suf_in = theirs;
-          else pre_in = theirs;
+        const int mine_or_theirs = slot[lane & (2 * H - 1)];  // lane i holds word i (i < 2 H)
+#pragma unroll
+        for (int v = 0; v < H; ++v) {  // nearest part to the left that has a start: ascending v, the last hit stays
+          const int last_v = __builtin_amdgcn_readlane(mine_or_theirs, 2 * v);
+          if (v < wave && last_v != kNone) pre_in = last_v;
+        }
+#pragma unroll
+        for (int v = H - 1; v >= 0; --v) {  // nearest part to the right: descending v
+          const int first_v = __builtin_amdgcn_readlane(mine_or_theirs, 2 * v + 1);
+          if (v > wave && first_v != kNone) suf_in = first_v;
         }
       }
       int pre[NC], suf[NC];
@@ -355,7 +359,9 @@ bool row_codes_exact(float w, int64_t sx) {
 bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
   // (rows of 1025..2048 voxels: two waves per row, the H = 2 form of the kernel; debug bit 0x4000000 leaves them to the
   // workgroup-phased kernel of edt_rows.hip)
-  const int64_t widest = (debug_mode() & 0x4000000) ? 1024 : 2048;
+  // (rows of 2049..4096 voxels: four waves per row; debug bit 32 -- the workgroup-phased kernel, which ends at 2048 --
+  // sends those to the line pipeline as before)
+  const int64_t widest = (debug_mode() & 0x4000000) ? 1024 : (debug_mode() & 32) ? 2048 : 4096;
   return sx >= 1 && sx <= widest && sy * sz < (int64_t)1 << 30 && sx * sy * sz < ((int64_t)1 << 40);
 }
 
@@ -366,11 +372,11 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
   const int64_t nby = ceil_div(sy, kBandRows);
   const int64_t ngroups = nby * sz;
   if (ngroups <= 0) return EDT_OK;
-  constexpr int GW = H == 2 ? 1 : kRowWaves;        // groups a workgroup works on at a time
-  constexpr int WAVES = H == 2 ? 2 : kRowWaves;     // its waves
-  const size_t lds = (size_t)(((sx + 3 + 3) & ~(int64_t)3) + 4) * sizeof(float);  // T table + the H = 2 exchange words
+  constexpr int GW = H >= 2 ? 1 : kRowWaves;        // groups a workgroup works on at a time
+  constexpr int WAVES = H >= 2 ? H : kRowWaves;     // its waves
+  const size_t lds = (size_t)(((sx + 3 + 3) & ~(int64_t)3) + 4 * H) * sizeof(float);  // T table + the H >= 2 exchange words
   int64_t blocks = ceil_div(ngroups, GW);
-  const int64_t resident = 256 * 8 * (kRowWaves / WAVES);  // persistent grid: the T table is built once per workgroup
+  const int64_t resident = 256 * 8 * (kRowWaves / WAVES > 0 ? kRowWaves / WAVES : 1);  // persistent grid: the T table is built once per workgroup
   if (blocks > resident) blocks = resident;
   const int xcd_sched = row_xcd_schedule(nby, sz, &blocks, GW, resident / 8);
 #define LAUNCH(Z, F, C)                                                                                   \
@@ -404,8 +410,13 @@ static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uin
   if (nc <= 20) GO2(10);
   if (nc <= 24) GO2(12);
   if (nc <= 28) GO2(14);
-  GO2(16);
+  if (nc <= 32) GO2(16);
 #undef GO2
+  // rows of 2049..4096 voxels: four waves per row (H = 4), parts of 12 or 16 chunks
+#define GO4(N) return launch_row_wave_tn<T, N, 4>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes)
+  if (nc <= 48) GO4(12);
+  GO4(16);
+#undef GO4
 }
 
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,

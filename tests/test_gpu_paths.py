@@ -224,19 +224,22 @@ def test_short_axes_thread_per_column(edt_gpu, oracle_port):
     assert same(edt_gpu.binary_edtsq(img, anisotropy=(2.0, 3.0), black_border=False), oracle_port.binary_edtsq(img, (2.0, 3.0), False))
 
 
-@pytest.mark.parametrize("sx", [1025, 1088, 1280, 1281, 1535, 1536, 1537, 1600, 1792, 1800, 2047, 2048])
+@pytest.mark.parametrize("sx", [1025, 1088, 1280, 1281, 1535, 1536, 1537, 1600, 1792, 1800, 2047, 2048,
+                                2049, 2304, 2560, 3000, 3071, 3072, 3073, 3500, 4095, 4096])
 def test_rows_of_1025_to_2048_voxels_two_waves_per_row(edt_gpu, oracle_port, sx):
-    """Rows of 1025..2048 voxels: pass X as two waves per row (edt_rowwave.hip, H = 2) that exchange one position per
-    row through LDS -- the last run start of the left half, the first of the right half.  Label patterns that stress the
-    exchange: runs that cross the middle of the row, rows whose starts all lie in ONE half, rows without any start, a
-    start exactly at the first voxel of the right half, single-voxel runs; odd numbers of rows in the last y-band (the
+    """Rows of 1025..2048 (4096) voxels: pass X as two (four) waves per row (edt_rowwave.hip, H = 2 / 4) that exchange
+    positions through LDS -- every part the last and the first run start of its own voxels.  Label patterns that stress
+    the exchange: runs that cross the parts' boundaries, rows whose starts all lie in ONE part, rows without any start, a
+    start exactly at the first / last voxel of a part, single-voxel runs; odd numbers of rows in the last y-band (the
     exchange words alternate from row to row across groups).  Against the oracle, with the 16-bit index form and with
-    fp32 between X and Y, and against the workgroup-phased kernel (debug bit 0x4000000)."""
+    fp32 between X and Y, and against the other kernels of pass X (debug bit 0x4000000: the workgroup-phased kernel up
+    to 2048 voxels, the line pipeline beyond)."""
     from edt import _lib
     lib = _lib.load()
     rng = np.random.default_rng(sx)
     nc = -(-sx // 64)
-    half = 64 * (10 if nc <= 20 else 12 if nc <= 24 else 14 if nc <= 28 else 16)  # (edt_rowwave.hip: launch_row_wave_t)
+    # voxels per wave (edt_rowwave.hip: launch_row_wave_t)
+    half = 64 * ((10 if nc <= 20 else 12 if nc <= 24 else 14 if nc <= 28 else 16) if nc <= 32 else (12 if nc <= 48 else 16))
     sy, sz = (37, 3) if sx % 2 else (70, 2)
     dt = [np.uint8, np.uint16, np.uint32, np.uint64, np.float32][sx % 5]
     lab = blocky_labels((sx, sy, sz), nlabels=3, zero_frac=0.15, block=int(rng.integers(200, 500)), rng=rng)
@@ -247,6 +250,11 @@ def test_rows_of_1025_to_2048_voxels_two_waves_per_row(edt_gpu, oracle_port, sx)
     lab[:, 4, :] = 2; lab[sx - 3, 4, :] = 1       # ... in the right half only
     lab[:, 5, :] = rng.integers(0, 3, size=(sx, sz))  # single-voxel runs everywhere
     lab[:, 6, :] = 0                              # background rows
+    for k in (2, 3):                              # (four waves per row) starts at the later parts' first / last voxels
+        if k * half < sx:
+            lab[:k * half, 5 + 2 * k, :] = 1; lab[k * half:, 5 + 2 * k, :] = 2
+            lab[:k * half - 1, 6 + 2 * k, :] = 3; lab[k * half - 1:, 6 + 2 * k, :] = 1
+    lab[:, 13, :] = 1; lab[sx // 2, 13, :] = 2     # one single-voxel run in the middle: every part looks past its neighbours
     lab = np.asfortranarray(lab.astype(dt))
     for an, bb in (((1.0, 1.0, 1.0), False), ((6.0, 6.0, 30.0), True), ((0.7, 1.3, 2.1), False), ((1.0, 2.0, 1.0), True)):
         want = oracle_port.edtsq(lab, an, bb)

@@ -120,6 +120,9 @@ struct Plan {
   unsigned char *line_ws = nullptr;  // scratch of the line pipeline when pass 1 runs over rows of more than 2048 voxels
   uint16_t *codes = nullptr;  // 16-bit distance indices of pass 1 (index form), one slab of xy_slab slices
   int64_t xy_slab = 0;        // slices per slab of the slab-wise X/Y passes (0: no index form for this shape)
+  // the tiles the 16-bit integer column kernel hands to the fp32 kernel (edt_colq16.hip): kQ16Slots counters, one per
+  // column-pass launch of a call, and one array of tile ids (launches are stream-ordered: the array is reused)
+  uint32_t *q16_counts = nullptr, *q16_ids = nullptr;
   size_t bytes = 0;
 };
 
@@ -147,6 +150,7 @@ static bool plan_needs_pingpong(int ndim, int64_t sx, int64_t sy, int64_t sz, in
 // volume's worth of parallelism) -- 256 MiB of scratch whatever the volume.  Shapes: the register-resident pass 1
 // and the wave column kernel, rows of whole 8-byte granules.  (debug bit 0x100000 switches the form off.)
 constexpr int64_t kCodeSlabVoxels = (int64_t)1 << 27;
+constexpr int kQ16Slots = 256;  // counters of the 16-bit integer column kernel's hand-over lists (one per launch)
 constexpr int EDT_FLAG_NO_INDEX_FORM = 0x8000;  // internal: plan without the index buffer
 static bool env_force_generic();
 static int64_t plan_code_slab(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
@@ -186,6 +190,12 @@ static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, v
     p.xy_slab = plan_code_slab(dtype, ndim, sx, sy, sz, flags);
     if (p.xy_slab > 0) p.codes = c.take<uint16_t>((size_t)(p.xy_slab * sx * sy));
   }
+  if (ndim >= 2 && !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic()) {
+    const int64_t ty = ceil_div(sx, 32) * (ceil_div(p.xy_slab > 0 ? p.xy_slab : sz, 8) * 8);
+    const int64_t tz = ceil_div(sx, 32) * (ceil_div(sy, 8) * 8);
+    p.q16_counts = c.take<uint32_t>(kQ16Slots);
+    p.q16_ids = c.take<uint32_t>((size_t)std::max(ty, tz));
+  }
   if (ndim == 1) (void)c.take<unsigned char>(line_workspace_bytes(sx));  // block scan + table of the 1-D pipeline
   // rows too long for the row kernels (sx > 2048): pass 1 runs as the line pipeline over the stack of rows
   if (ndim >= 2 && !row_pass_tiled_supported(sx) && !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic())
@@ -200,7 +210,9 @@ static bool column_inplace_supported(const AxisGeom &g) {
   return column_pass_wave_supported(g) || column_pass_tiled_supported(g);
 }
 static int launch_column_inplace(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                                 float w, int bb, int epi, hipStream_t stream) {
+                                 float w, int bb, int epi, hipStream_t stream, const TileList &list = TileList()) {
+  // (a list -- the tiles the 16-bit integer kernel refused -- only exists for axes of the wave kernel)
+  if (list.count != nullptr) return launch_column_pass_wave(F, nz, rs, g, w, bb, epi, stream, nullptr, ColumnOut(), list);
   // axes of at most 32 rows with many columns: a thread per column (edt_short.hip); the LDS-tiled kernels would
   // launch a single-wave workgroup per 32 columns.  (debug bit 0x1000000 keeps them on the wave kernel.)
   if (column_pass_short_supported(g) && g.sx * g.nouter >= 4096 && !(g_debug_mode & (64 | 0x1000000)))
@@ -301,6 +313,33 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     log_begin_call();
   }
 
+  // The 16-bit integer form of the column passes (edt_colq16.hip): voxel sizes that share a quantum.  Every column pass
+  // is then two launches: the integer kernel over all tiles, and the fp32 kernel over the list of tiles it refused.
+  float q16_q = 1.0f;
+  uint32_t q16_a[3] = {1u, 1u, 1u};
+  bool q16 = false;
+  int q16_slot = 0;
+  if (ndim >= 2 && p.q16_counts != nullptr) {
+    const float ws3[3] = {wx, wy, wz};
+    q16 = q16_quantum(ws3, (ndim == 3 && !(flags & EDT_FLAG_BATCH_2D)) ? 3 : 2, &q16_q, q16_a);
+    if (q16) EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, kQ16Slots * sizeof(uint32_t), stream));
+  }
+  // F in place (codes == nullptr) or from the 16-bit indices of pass X; returns the list for the fp32 launch that follows
+  auto q16_pass = [&](float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, int axis, int epi,
+                      TileList &list) -> int {
+    list = TileList();
+    // (the bits that force one form of the fp32 kernel on every tile -- the test tiers' way to cover them -- keep the call there)
+    if (!q16 || q16_slot >= kQ16Slots || !column_pass_q16_supported(g) || !column_pass_wave_supported(g) ||
+        (g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x400000)))
+      return EDT_OK;
+    uint32_t *count = p.q16_counts + q16_slot++;
+    const int r = launch_column_pass_q16(F, codes, rs, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, p.q16_ids, stream);
+    if (r != EDT_OK) return r;
+    list.count = count;
+    list.ids = p.q16_ids;
+    return EDT_OK;
+  };
+
   if (ndim == 1) {
     ScopedPass t("x_pass", stream);
     if (force_generic_1d(flags) || line_without_ws) return launch_row_pass_serial(dtype, d_labels, d_out, sx, 1, wx, bb, 0, want_sqrt, stream);
@@ -347,8 +386,11 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
         ScopedPass t(one ? "y_pass" : nullptr, stream);
         AxisGeom g = p.gy;
         g.nouter = zc;
+        TileList list;
+        rc = q16_pass(cur + z0 * sxy, p.codes, p.rs_y + z0 * wpl, g, 1, zpass ? 0 : last_epi, list);
+        if (rc != EDT_OK) return rc;
         rc = launch_column_pass_wave_codes(cur + z0 * sxy, p.codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
-                                           zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream);
+                                           zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream, nullptr, list);
         if (rc != EDT_OK) return rc;
       }
     }
@@ -383,7 +425,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     ScopedPass t("y_pass", stream);
     const int epi = zpass ? 0 : last_epi;
     if (tiled_y) {
-      rc = launch_column_inplace(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, stream);
+      TileList list;
+      rc = q16_pass(cur, nullptr, p.rs_y, p.gy, 1, epi, list);
+      if (rc != EDT_OK) return rc;
+      rc = launch_column_inplace(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, stream, list);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_y, p.rs_y, p.stack, p.gy, wy, bb, epi, stream);
       std::swap(cur, other);
@@ -403,7 +448,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   if (zpass) {
     ScopedPass t("z_pass", stream);
     if (tiled_z) {
-      rc = launch_column_inplace(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream);
+      TileList list;
+      rc = q16_pass(cur, nullptr, p.rs_z, p.gz, 2, last_epi, list);
+      if (rc != EDT_OK) return rc;
+      rc = launch_column_inplace(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream, list);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_z, p.rs_z, p.stack, p.gz, wz, bb, last_epi,
                                      stream);

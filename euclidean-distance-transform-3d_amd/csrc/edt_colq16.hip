@@ -1,0 +1,322 @@
+// edt_colq16.hip -- the 16-bit integer column pass (passes Y and Z) for gfx950.
+//
+// Replaces squared_edt_1d_parabolic_multi_seg over squared_edt_1d_parabolic (src/edt.hpp:168-377) wherever the voxel sizes
+// of the call share a quantum (edt_colq16_lane.h: quantum_of -- (1,1,1), (6,6,30), (4,4,40), (0.5,0.5,1) ...), i.e. on
+// every configuration of BASELINE.json; the mathematics, the exactness argument and the per-lane code are in
+// edt_colq16_lane.h.  This file is the workgroup around it:
+//
+//   workgroup = one tile of 32 adjacent columns x the whole scan axis (as in edt_colwave_kernel.h), 256 threads;
+//   LDS image = the tile as 16-bit integers N = F / q, row-major, 64 bytes per row, one 32-row band of +inf (0xFFFF)
+//               before and after it: 36 KiB for a 512-row axis (the fp32 kernel: 80 KiB), 68 KiB for 1024 rows -- three /
+//               two workgroups per CU with whole 128-byte lines per row where the fp32 kernel has two / needs 16-column tiles;
+//   fill      = through VGPRs: the 16-bit distance indices k of pass X (index form, edt_rowwave.hip C16: N = k^2 * ax) or
+//               fp32 values (N = F / q, checked to be exact); a tile that holds a value outside the 16-bit range or off the
+//               quantum grid (rows without any boundary, objects more than ~250 voxels deep) is NOT processed: its id goes
+//               to a list in device memory and the fp32 kernel (edt_colwave_kernel.h, list mode) takes it afterwards;
+//   scans     = run extents across bands by one thread per column and direction over the band words (LDS), break bits per
+//               block of 8 rows and column pair;
+//   windows   = lane = (column pair, block of 8 rows): a wave works on 16 pairs x the four blocks of one band, a contiguous
+//               32 x 32 patch, and walks the bands wave, wave + 4, ...;
+//   results   = converted once at the end, (float)N * q (exact), optional correctly rounded sqrt, 8-byte stores (16 lanes =
+//               one 128-byte line per row).
+#include "edt_common.h"
+#include "edt_kernels.h"
+
+#define EDT_LANE __device__ __forceinline__
+#define EDT_LANE_MEMBER __device__ __forceinline__
+#include "edt_colq16_lane.h"
+
+namespace edt_amd {
+
+struct Q16Args {
+  const uint16_t *codes;  // index form of pass X: [outer][row][x] with the strides of F; nullptr: F holds fp32 values
+  float q, rq;            // the quantum and its reciprocal (rounded; the conversion is verified value by value)
+  uint32_t a;             // c_d = a * d^2 quanta
+  uint32_t ain;           // index form: N = k^2 * ain
+  uint32_t kmax;          // index form: largest k with k^2 * ain <= nlim
+  uint32_t nlim;          // largest N a tile may hold: a * dmax^2
+  uint32_t dmax;          // largest d with a * d^2 <= 65534
+  uint32_t *count;        // tiles handed to the fp32 kernel: *count of them ...
+  uint32_t *ids;          // ... their (order-permuted) tile ids
+};
+
+namespace {
+
+constexpr int kQ16Threads = 256;
+
+__host__ __device__ constexpr int q16_lds_words(int NB) {
+  // image (NB + 2 bands of 32 rows x 16 words) + run-start plane + lo/hi plane + break masks (16 pairs x 6 words) + flags
+  return (NB + 2) * 32 * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 4;
+}
+
+}  // namespace
+
+// (not in the anonymous namespace: hipFuncSetAttribute refuses the stub of a kernel with internal linkage)
+template <bool BB, bool CODES, bool SC>
+__global__ void __launch_bounds__(kQ16Threads, 3)
+k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, AxisGeom g, int tiles_x, int epi, int dbg,
+                  Q16Args qa, const BandScatter *__restrict__ scatter) {
+  using namespace edt_q16;
+  extern __shared__ __attribute__((aligned(16))) uint32_t q16_smem[];
+  const int n = (int)g.n;
+  const int NB = (int)g.nbands;
+  const int nb32 = NB * 32;
+  uint32_t *img = q16_smem;                                // [(nb32 + 64)][16]
+  uint32_t *rsp = img + (NB + 2) * 32 * kRowWords;         // [NB][32]
+  uint32_t *lohi = rsp + NB * 32;                          // [NB][32]: (lo_in + 1) | (hi_out + 1) << 16
+  uint32_t *bm = lohi + NB * 32;                           // [16][6]: break bits of the pair's blocks, words 1..4 (0, 5: zero)
+  uint32_t *flags = bm + 16 * 6;                           // [4]: per wave, "the tile does not qualify"
+  const int t = (int)threadIdx.x;
+
+  // ---- tile -> (x-tile, outer index): the XCD-aware order of edt_colwave_kernel.h ----
+  int64_t tile_id = blockIdx.x;
+  const uint32_t utx = (uint32_t)tiles_x;
+  if (!(dbg & 0x800)) {
+    const uint32_t tt = (uint32_t)tile_id, x = tt & 7u, j = tt >> 3;
+    const uint32_t jq = j / utx, jr = j - jq * utx;
+    tile_id = (int64_t)((jq * 8u + x) * utx + jr);
+    if (tile_id >= (int64_t)tiles_x * g.nouter) return;
+  }
+  const uint32_t oq = (uint32_t)tile_id / utx;
+  const int64_t xt = (uint32_t)tile_id - oq * utx, o = oq;
+  const int64_t x0 = xt * 32;
+  const int64_t st = g.stride;
+  const int cols_left = (int)(g.sx - x0);
+
+  // ---- phase 0: the tile, HBM -> 16-bit LDS image ------------------------------------------
+  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int r_in = t >> 3, cg = t & 7;  // 32 rows per sweep of the workgroup, 8 threads x 4 columns per row
+  const bool col_ok = 4 * cg < cols_left;
+  bool bad = false;
+  if (t < 64) bm[t] = 0u, bm[t + 32] = 0u;  // (96 words)
+  {
+    // +inf around the column: 64 rows x 16 words, one 16-byte store per thread
+    const int row = t < 128 ? -kPad + (t >> 2) : nb32 + ((t - 128) >> 2);
+    *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (t & 3)) = (v4u){~0u, ~0u, ~0u, ~0u};
+  }
+  for (int u = t; u < NB * 32; u += kQ16Threads) {
+    const int band = u >> 5, col = u & 31;
+    rsp[u] = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
+  }
+  if constexpr (CODES) {
+    const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
+    const pk kmaxpk = pk_both(qa.kmax), ainpk = pk_both(qa.ain);
+    for (int i0 = 0; i0 < nb32; i0 += 32 * 16) {
+      v2u kk[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = i0 + 32 * j + r_in;
+        kk[j] = (v2u){0u, 0u};
+        if (row < n && col_ok) kk[j] = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(src + (int64_t)row * st));
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = i0 + 32 * j + r_in;
+        if (row < nb32) {
+          // k > kmax (also the "no boundary" index 0xFFFF): the tile does not qualify (k^2 may have wrapped: never used)
+          bad |= (pk_subs(kk[j][0], kmaxpk) | pk_subs(kk[j][1], kmaxpk)) != 0u;
+          v2u v = {pk_mul(pk_mul(kk[j][0], kk[j][0]), ainpk), pk_mul(pk_mul(kk[j][1], kk[j][1]), ainpk)};
+          if (row >= n) v = (v2u){~0u, ~0u};
+          *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = v;
+        }
+      }
+    }
+  } else {
+    const float *src = F + x0 + o * g.outer_stride + 4 * cg;
+    const float flim = (float)qa.nlim + 1.0f;
+    for (int i0 = 0; i0 < nb32; i0 += 32 * 8) {
+      v4f ff[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = i0 + 32 * j + r_in;
+        ff[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        if (row < n && col_ok) ff[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + (int64_t)row * st));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = i0 + 32 * j + r_in;
+        if (row < nb32) {
+          uint32_t u[4];
+          float err = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            // N = F / q, exact or the tile does not qualify: F - N * q as one fma (the product is exact)
+            const float f = ff[j][c];
+            const float tq = fminf(f * qa.rq, flim);
+            u[c] = (uint32_t)(tq + 0.5f);
+            const float e = fmaf(-(float)u[c], qa.q, f);
+            err = fmaxf(err, fabsf(e));  // (+inf in, NaN out: fmaxf keeps the other operand -- caught by the range test)
+          }
+          bad |= !(err == 0.0f) | (max(max(u[0], u[1]), max(u[2], u[3])) > qa.nlim);
+          v2u v = {u[0] | (u[1] << 16), u[2] | (u[3] << 16)};
+          if (row >= n) v = (v2u){~0u, ~0u};
+          *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = v;
+        }
+      }
+    }
+  }
+  // (every wave publishes its own verdict: no initialisation to order against, and no static LDS -- __syncthreads_or has
+  // some, and hipFuncSetAttribute then refuses the full 160 KiB of dynamic LDS)
+  if ((t & 63) == 0) flags[t >> 6] = 0u;
+  if (__ballot(bad) != 0ull && (t & 63) == 0) flags[t >> 6] = 1u;
+  __syncthreads();
+  if ((flags[0] | flags[1] | flags[2] | flags[3]) != 0u) {
+    if (t == 0) {
+      const uint32_t idx = atomicAdd(qa.count, 1u);
+      qa.ids[idx] = (uint32_t)tile_id;
+    }
+    return;
+  }
+
+  // ---- phase 1: run extents across bands (one thread per column and direction), break bits per block and pair ----
+  {
+    uint16_t *lohi16 = reinterpret_cast<uint16_t *>(lohi);
+    if (t < 32) scan_runs_lo(rsp + t, 32, NB, lohi16 + 2 * t, 64);
+    else if (t < 64) scan_runs_hi(rsp + (t - 32), 32, NB, n, lohi16 + 2 * (t - 32) + 1, 64);
+    const pk apk = pk_both(qa.a);
+    for (int u = t; u < 16 * NB; u += kQ16Threads) {
+      const int cp = u & 15, band = u >> 4;
+      const int valid = n - 32 * band;
+      const uint32_t bits = band_breaks(img + (32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32);
+      if (bits) atomicOr(&bm[cp * 6 + 1 + (band >> 3)], bits << (4 * (band & 7)));
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: the blocks ----------------------------------------------------------------------
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  const int cp = lane & 15, bq = lane >> 4;
+  const bool store_ok = 2 * cp < cols_left;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+  for (int s = wave; s < NB; s += kQ16Threads / 64) {
+    Block L;
+    L.img = img;
+    L.cp = cp;
+    L.p0 = 32 * s + 8 * bq;
+    L.n = n;
+    L.nb32 = nb32;
+    {
+      const v2u rs2 = *reinterpret_cast<const v2u *>(rsp + s * 32 + 2 * cp);
+      const v2u lh2 = *reinterpret_cast<const v2u *>(lohi + s * 32 + 2 * cp);
+      L.rswA = rs2[0];
+      L.rswB = rs2[1];
+      L.loA = (int)(lh2[0] & 0xFFFFu) - 1;
+      L.hiA = (int)(lh2[0] >> 16) - 1;
+      L.loB = (int)(lh2[1] & 0xFFFFu) - 1;
+      L.hiB = (int)(lh2[1] >> 16) - 1;
+    }
+    L.a = qa.a;
+    L.dmax = qa.dmax;
+    {
+      // the break bits of blocks gi - 32 .. gi + 31 (gi = 4 s + bq): bits gi .. gi + 63 of the padded mask
+      const int wi = s >> 3, sh = (4 * s + bq) & 31;
+      const uint32_t *m = bm + cp * 6 + wi;
+      const uint32_t e0 = m[0], e1 = m[1], e2 = m[2];
+      const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
+      const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
+      L.win = ((uint64_t)hi << 32) | lo;
+    }
+    pk best[kB];
+    block_eval<BB>(L, best);
+    // ---- results: (float)N * q is exact; sqrt of the last pass (src/edt.hpp:599-601) ----
+    float *dst;
+    if constexpr (SC) {
+      const int b = s < BandScatter::kBands ? s : 0;
+      dst = scatter->rows[b] + o * scatter->ostride[b] + x0 + 2 * cp - (int64_t)s * 32 * st;
+    } else {
+      dst = F + x0 + o * g.outer_stride + 2 * cp;
+    }
+    auto *gdst = (__attribute__((address_space(1))) float *)dst;
+    const float q = qa.q;
+    v2f out[kB];
+#pragma unroll
+    for (int j = 0; j < kB; ++j) out[j] = (v2f){(float)(best[j] & 0xFFFFu) * q, (float)(best[j] >> 16) * q};
+    if (epi & kEpiSqrt) {
+#pragma unroll
+      for (int j = 0; j < kB; ++j) out[j] = (v2f){sqrtf(out[j].x), sqrtf(out[j].y)};
+    }
+#pragma unroll
+    for (int j = 0; j < kB; ++j) {
+      const int row = L.p0 + j;
+      if (row < n && store_ok)
+        *reinterpret_cast<__attribute__((address_space(1))) v2f *>(gdst + (int64_t)row * st) = out[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------
+bool column_pass_q16_supported(const AxisGeom &g) {
+  // whole 16-byte granules per row piece; axes the LDS image fits twice per CU (two workgroups per CU keep the fill of
+  // one under the windows of the other); shorter axes than 4 bands leave most of the workgroup without a band
+  return g.sx % 4 == 0 && g.stride % 4 == 0 && g.outer_stride % 4 == 0 && g.nbands >= 4 && g.nbands <= 32 &&
+         !(debug_mode() & 0x8000000);
+}
+
+// list: [0 .. 63] counters (zeroed by the caller once per call), [64 ..] tile ids; `slot` picks this launch's counter
+template <bool BB, bool CODES>
+static int launch_q16_bc(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa0, int epi,
+                         hipStream_t stream, const BandScatter *scatter) {
+  Q16Args qa = qa0;
+  qa.codes = codes;
+  const int NB = (int)g.nbands;
+  const size_t lds = (size_t)q16_lds_words(NB) * sizeof(uint32_t);
+  const int64_t tiles_x = ceil_div(g.sx, 32);
+  int64_t tiles = tiles_x * g.nouter;
+  if (tiles <= 0) return EDT_OK;
+  if (!(debug_mode() & 0x800)) tiles = tiles_x * (ceil_div(g.nouter, 8) * 8);
+  if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
+  if (scatter != nullptr) {
+    static std::atomic<uint64_t> attr_done{0};
+    EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_q16<BB, CODES, true>)));
+    hipLaunchKernelGGL((k_column_pass_q16<BB, CODES, true>), dim3((unsigned)tiles), dim3(kQ16Threads), lds, stream, F, rs, g,
+                       (int)tiles_x, epi, debug_mode(), qa, scatter);
+  } else {
+    static std::atomic<uint64_t> attr_done{0};
+    EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_q16<BB, CODES, false>)));
+    hipLaunchKernelGGL((k_column_pass_q16<BB, CODES, false>), dim3((unsigned)tiles), dim3(kQ16Threads), lds, stream, F, rs, g,
+                       (int)tiles_x, epi, debug_mode(), qa, scatter);
+  }
+  EDT_HIP_TRY(hipGetLastError());
+  return EDT_OK;
+}
+
+// a: c_d = a * d^2 quanta of this pass; ain: quanta per squared index of pass X (codes != nullptr)
+int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
+                           uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
+                           const BandScatter *scatter) {
+  Q16Args qa;
+  qa.codes = codes;
+  qa.q = q;
+  qa.rq = 1.0f / q;
+  qa.a = a;
+  qa.ain = ain;
+  qa.dmax = edt_q16::q16_dmax(a);
+  qa.nlim = a * qa.dmax * qa.dmax;
+  uint32_t kmax = 0;
+  while ((uint64_t)(kmax + 1) * (kmax + 1) * ain <= qa.nlim && kmax < 65534u) ++kmax;
+  qa.kmax = kmax;
+  qa.count = count;
+  qa.ids = ids;
+  if (codes)
+    return bb ? launch_q16_bc<true, true>(F, codes, rs, g, qa, epi, stream, scatter)
+              : launch_q16_bc<false, true>(F, codes, rs, g, qa, epi, stream, scatter);
+  return bb ? launch_q16_bc<true, false>(F, codes, rs, g, qa, epi, stream, scatter)
+            : launch_q16_bc<false, false>(F, codes, rs, g, qa, epi, stream, scatter);
+}
+
+// the quantum of a call (edt_colq16_lane.h: quantum_of), host side
+bool q16_quantum(const float *w, int naxes, float *q, uint32_t *a) {
+  const edt_q16::Quantum Q = edt_q16::quantum_of(w, naxes);
+  if (!Q.ok) return false;
+  *q = Q.q;
+  for (int i = 0; i < 3; ++i) a[i] = Q.a[i];
+  return true;
+}
+
+}  // namespace edt_amd

@@ -1,0 +1,408 @@
+// edt_colq16_lane.h -- per-lane logic of the 16-bit integer column pass (passes Y and Z; edt_colq16.hip).
+//
+// Where the voxel sizes share a quantum q -- w_i^2 = a_i * q with small integers a_i: (1,1,1), (6,6,30), (4,4,40),
+// (0.5,0.5,1) ... -- every value the column passes meet is an integer multiple N * q: pass X leaves (k*wx)^2 = k^2 * ax * q,
+// a candidate of the envelope is c_d + F[j] = (a * d^2 + N[j]) * q, the border parabolas are a * d^2 * q.  As long as
+// N < 2^16 and N * (odd part of q) < 2^24 all of these are exact in fp32 AND in the reference's fp64 intermediates
+// (src/edt.hpp:181, :230, :258, :307: w2 * sq(d) + ff[j], rounded once to fp32), so the reference's result is the exact
+// integer minimum times q and the whole pass can run on 16-bit integers, TWO ADJACENT COLUMNS PER LANE in packed
+// instructions (v_pk_min_u16, v_pk_add_u16 clamp: 3 instructions per step for two voxels against 2.2 per voxel in the
+// fp32 form, edt_colwave_lane.h), on an LDS tile of half the size.  Tiles that do not qualify (a value that is not a
+// multiple of q or too large: rows without any boundary, very large objects) are handed to the fp32 kernel through a
+// list (edt_colq16.hip).
+//
+// The mathematics is that of the windowed path (edt_colwave_lane.h, "brute"):
+//     result[p] = min( B_p, min_{1<=d<=R} ( c_d + min(N[p-d], N[p+d]) ) ),   B_p = min(N[p], border parabolas),
+// for every R with c_{R+1} >= B_p, with no label test inside the window; a block whose neighbourhood has no "break"
+// (|N[r] - N[r-1]| > a) within reach skips the window.  Differences: the border distances are packed counters, the breaks
+// are kept per BLOCK of 8 rows and per column PAIR (conservative: fewer skips, never a wrong one) and count every link,
+// also those across a run boundary (where a window is needed anyway), and the 64 blocks a wave works on at a time are
+// CONTIGUOUS (16 column pairs x the four blocks of one 32-row band).
+//
+// Compiled twice like edt_colwave_lane.h: by hipcc into the kernel and by g++ into tests/q16_emul.cpp, which plays every
+// lane on the host against the oracle (tests/test_q16_logic.py).
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+
+#ifndef EDT_LANE
+#error "define EDT_LANE (function qualifiers) before including edt_colq16_lane.h"
+#endif
+#ifndef EDT_HOSTFN
+#define EDT_HOSTFN static inline  // host-side helpers (the quantum of a call)
+#endif
+
+namespace edt_q16 {
+
+typedef uint32_t pk;  // two unsigned 16-bit values: low half = the even column of the pair, high half = the odd one
+
+constexpr int kPad = 32;          // rows of +inf (0xFFFF) before row 0 and after the last band of the image
+constexpr int kRowWords = 16;     // 32-bit words per image row (32 columns x 16 bit)
+constexpr int kK = 32;            // register-resident radius of the window
+constexpr int kB = 8;             // rows per block
+constexpr uint32_t kInf = 0xFFFFu;
+constexpr uint32_t kFar = 0x4000u;  // "no border on this side" distance (stays below 2^15 after n <= 2048 increments)
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned short q16_us2 __attribute__((ext_vector_type(2)));
+typedef short q16_s2 __attribute__((ext_vector_type(2)));
+EDT_LANE q16_us2 q16_v(pk x) { return __builtin_bit_cast(q16_us2, x); }
+EDT_LANE pk q16_p(q16_us2 v) { return __builtin_bit_cast(pk, v); }
+EDT_LANE pk pk_min(pk a, pk b) { return q16_p(__builtin_elementwise_min(q16_v(a), q16_v(b))); }
+EDT_LANE pk pk_max(pk a, pk b) { return q16_p(__builtin_elementwise_max(q16_v(a), q16_v(b))); }
+EDT_LANE pk pk_adds(pk a, pk b) { return q16_p(__builtin_elementwise_add_sat(q16_v(a), q16_v(b))); }
+EDT_LANE pk pk_subs(pk a, pk b) { return q16_p(__builtin_elementwise_sub_sat(q16_v(a), q16_v(b))); }
+EDT_LANE pk pk_add(pk a, pk b) { return q16_p(q16_v(a) + q16_v(b)); }
+EDT_LANE pk pk_mul(pk a, pk b) { return q16_p(q16_v(a) * q16_v(b)); }
+template <int S>
+EDT_LANE pk pk_shl(pk a) { return q16_p(q16_v(a) << (unsigned short)S); }
+EDT_LANE pk pk_sar15(pk a) { return __builtin_bit_cast(pk, __builtin_bit_cast(q16_s2, a) >> (short)15); }
+EDT_LANE int q16_clz(uint32_t v) { return __builtin_clz(v); }
+EDT_LANE int q16_ctz(uint32_t v) { return __builtin_ctz(v); }
+#define EDT_Q16_ANY(cond) (__ballot(cond) != 0ull)
+#define EDT_Q16_UNROLL _Pragma("unroll")
+// (keeps the compiler from re-deriving a select mask as two 16-bit compares, two selects and a byte permute)
+#define EDT_Q16_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+EDT_LANE uint32_t q16_sat(uint32_t v) { return v > 0xFFFFu ? 0xFFFFu : v; }
+EDT_LANE pk q16_mk(uint32_t lo, uint32_t hi) { return (lo & 0xFFFFu) | (hi << 16); }
+EDT_LANE pk pk_min(pk a, pk b) {
+  const uint32_t al = a & 0xFFFFu, bl = b & 0xFFFFu, ah = a >> 16, bh = b >> 16;
+  return q16_mk(al < bl ? al : bl, ah < bh ? ah : bh);
+}
+EDT_LANE pk pk_max(pk a, pk b) {
+  const uint32_t al = a & 0xFFFFu, bl = b & 0xFFFFu, ah = a >> 16, bh = b >> 16;
+  return q16_mk(al > bl ? al : bl, ah > bh ? ah : bh);
+}
+EDT_LANE pk pk_adds(pk a, pk b) { return q16_mk(q16_sat((a & 0xFFFFu) + (b & 0xFFFFu)), q16_sat((a >> 16) + (b >> 16))); }
+EDT_LANE pk pk_subs(pk a, pk b) {
+  const uint32_t al = a & 0xFFFFu, bl = b & 0xFFFFu, ah = a >> 16, bh = b >> 16;
+  return q16_mk(al > bl ? al - bl : 0u, ah > bh ? ah - bh : 0u);
+}
+EDT_LANE pk pk_add(pk a, pk b) { return q16_mk((a & 0xFFFFu) + (b & 0xFFFFu), ((a >> 16) + (b >> 16)) & 0xFFFFu); }
+EDT_LANE pk pk_mul(pk a, pk b) { return q16_mk((a & 0xFFFFu) * (b & 0xFFFFu), ((a >> 16) * (b >> 16)) & 0xFFFFu); }
+template <int S>
+EDT_LANE pk pk_shl(pk a) { return q16_mk((a & 0xFFFFu) << S, ((a >> 16) << S) & 0xFFFFu); }
+EDT_LANE pk pk_sar15(pk a) { return q16_mk((a & 0x8000u) ? 0xFFFFu : 0u, (a & 0x80000000u) ? 0xFFFFu : 0u); }
+EDT_LANE int q16_clz(uint32_t v) { return __builtin_clz(v); }
+EDT_LANE int q16_ctz(uint32_t v) { return __builtin_ctz(v); }
+#define EDT_Q16_ANY(cond) (cond)
+#define EDT_Q16_UNROLL
+#define EDT_Q16_OPAQUE(x) ((void)0)
+#endif
+
+EDT_LANE pk pk_both(uint32_t v) { return (v & 0xFFFFu) * 0x10001u; }
+EDT_LANE pk pk_sel(pk mask, pk a, pk b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
+
+// ---------------------------------------------------------------------------------------
+// The quantum of a call (host): w_i^2 = a_i * q for every axis of the call, q = odd * 2^e with odd <= 255, so that
+// N * q is exact in fp32 for every N < 2^16.  ok = false: no such quantum (the fp32 kernels keep the call).
+// ---------------------------------------------------------------------------------------
+struct Quantum {
+  bool ok;
+  float q;         // the quantum
+  uint32_t a[3];   // w_i^2 / q  (1 for an unused axis)
+};
+
+EDT_HOSTFN uint64_t q16_gcd(uint64_t a, uint64_t b) {
+  while (b) { const uint64_t t = a % b; a = b; b = t; }
+  return a;
+}
+
+EDT_HOSTFN Quantum quantum_of(const float *w, int naxes) {
+  Quantum Q;
+  Q.ok = false;
+  Q.q = 1.0f;
+  Q.a[0] = Q.a[1] = Q.a[2] = 1u;
+  uint64_t m[3];
+  int e[3];
+  int emin = 1 << 30;
+  for (int i = 0; i < naxes; ++i) {
+    const float w2 = w[i] * w[i];  // the reference's fp32 product (src/edt.hpp:181, :258)
+    if (!(w2 >= 1.17549435e-38f) || !(w2 < 1.0e30f)) return Q;
+    if ((double)w2 != (double)w[i] * (double)w[i]) return Q;  // w^2 must be exact: pass X leaves (k*w)^2 = k^2 * w^2
+    int ex;
+    const double fr = frexp((double)w2, &ex);      // w2 = fr * 2^ex, fr in [0.5, 1)
+    uint64_t mi = (uint64_t)ldexp(fr, 24);         // 24-bit integer mantissa
+    int ei = ex - 24;
+    while (!(mi & 1u)) { mi >>= 1; ++ei; }
+    m[i] = mi;
+    e[i] = ei;
+    if (ei < emin) emin = ei;
+  }
+  uint64_t g = 0;
+  for (int i = 0; i < naxes; ++i) {
+    if (e[i] - emin > 20) return Q;
+    m[i] <<= (e[i] - emin);
+    if (m[i] >= (1ull << 40)) return Q;
+    g = q16_gcd(g, m[i]);
+  }
+  // q = g * 2^emin; its odd part must leave room for a 16-bit factor in an fp32 significand
+  uint64_t odd = g;
+  int e2 = emin;
+  while (!(odd & 1u)) { odd >>= 1; ++e2; }
+  if (odd > 255u) return Q;
+  if (e2 < -140 || e2 > 100) return Q;
+  for (int i = 0; i < naxes; ++i) {
+    const uint64_t ai = m[i] / g;
+    if (ai == 0 || ai > 16384u) return Q;  // (a window needs at least two rows: a * 2^2 < 2^16)
+    Q.a[i] = (uint32_t)ai;
+  }
+  Q.q = (float)ldexp((double)odd, e2);
+  Q.ok = true;
+  return Q;
+}
+
+// largest d with a * d^2 <= 65534 (0xFFFF is +inf)
+EDT_HOSTFN uint32_t q16_dmax(uint32_t a) {
+  uint32_t d = 1;
+  while ((uint64_t)a * (d + 1) * (d + 1) <= 65534u) ++d;
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------
+// Breaks of one band of a column pair: bit k of the result = some link r-1 -> r with r in block k of the band
+// (rows 8k .. 8k+7) has |N[r] - N[r-1]| > a in either column.  rows[0] = the row before the band, rows[1..32] the band.
+// (|x - y| > a  <=>  x > y + a or y > x + a: one saturating add per row, shared by the two links the row is part of)
+// ---------------------------------------------------------------------------------------
+// band0: word of (first row of the band, pair).  top: the band is the column's first (no link into its first row).
+// valid: rows of the band that are rows of the column (32 but for the last band; the +inf rows after them are no links).
+EDT_LANE uint32_t band_breaks(const uint32_t *band0, pk apk, bool top, int valid) {
+  uint32_t bits = 0;
+  pk y = top ? band0[0] : band0[-kRowWords];
+  pk ty = pk_adds(y, apk);
+  EDT_Q16_UNROLL
+  for (int k = 0; k < 4; ++k) {
+    pk acc = 0;
+    EDT_Q16_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      pk x = band0[(8 * k + j) * kRowWords];
+      if (valid < 32 && 8 * k + j >= valid) x = y;
+      const pk tx = pk_adds(x, apk);
+      acc |= pk_subs(x, ty) | pk_subs(y, tx);
+      y = x;
+      ty = tx;
+    }
+    bits |= acc ? (1u << k) : 0u;
+  }
+  return bits;
+}
+
+// Flat reach of block gi of a column pair (in rows): no break lies within this distance of the block's rows.
+// bm: the break bits of the pair's blocks gi-32 .. gi+31 (bit 32 = the block itself).
+EDT_LANE int flat_reach(uint64_t win) {
+  if ((win >> 32) & 1u) return 0;
+  const uint32_t below = (uint32_t)win, above = (uint32_t)(win >> 33);
+  // nearest break block below: gi - 32 + hb  ->  its last row is at least 8 * (32 - hb) - 7 rows below the block
+  const int dlo = below ? 8 * (q16_clz(below) + 1) - 7 : 8 * 33 - 7;
+  const int dhi = above ? 8 * q16_ctz(above) : 8 * 31;
+  return dlo < dhi ? dlo : dhi;
+}
+
+// ---------------------------------------------------------------------------------------
+// One block of a lane: rows p0 .. p0+7 of the column pair cp.
+// ---------------------------------------------------------------------------------------
+struct Block {
+  const uint32_t *img;   // the image: word of (row r, pair cp) = img[(r + kPad) * kRowWords + cp]
+  int cp;                // column pair inside the tile (0..15)
+  int p0;                // first row of the block (a multiple of 8)
+  int n;                 // rows of the column
+  int nb32;              // rows of the image without the padding (whole bands)
+  uint32_t rswA, rswB;   // run-start words of the band, even / odd column
+  int loA, loB;          // last run start in an earlier band (-1: none), even / odd column
+  int hiA, hiB;          // row before the first run start in a later band (n-1: none)
+  uint32_t a;            // c_d = a * d^2
+  uint32_t dmax;         // q16_dmax(a)
+  uint64_t win;          // break bits around the block (flat_reach)
+};
+
+template <bool BB>
+struct Steps {
+  static constexpr int K = kK, B = kB, RW = kRowWords;
+  const Block &L;
+  pk (&w)[B + 2 * K];
+  pk (&best)[B];
+  const uint32_t *PB;  // word of (row p0 - K, pair cp)
+  pk bmax;             // upper bound of the current minima of the block (both halves)
+  uint32_t a;
+
+  EDT_LANE_MEMBER void refresh_bound() {
+    pk m = best[0];
+    EDT_Q16_UNROLL
+    for (int i = 1; i < B; ++i) m = pk_max(m, best[i]);
+    bmax = m;
+  }
+  // c_d as a packed constant (wave-uniform: scalar arithmetic), +inf once it leaves 16 bits
+  EDT_LANE_MEMBER pk cpk(int d) const {
+    const uint32_t c = a * (uint32_t)(d * d);
+    return pk_both(c < kInf ? c : kInf);
+  }
+
+  template <int D>
+  EDT_LANE_MEMBER void run() {
+    if constexpr (D < K) {
+      if constexpr (D > 1 && (D - 1) % 4 == 0) refresh_bound();
+      const pk c1 = cpk(D), c2 = cpk(D + 1);
+      // a candidate at distance d is at least c_d: once c_d >= every current minimum of the wave nothing further away
+      // can lower any of them
+      if (!EDT_Q16_ANY(pk_subs(bmax, c1) != 0u)) return;
+      w[K - D] = PB[(K - D) * RW];
+      w[K + B - 1 + D] = PB[(K + B - 1 + D) * RW];
+      w[K - D - 1] = PB[(K - D - 1) * RW];
+      w[K + B + D] = PB[(K + B + D) * RW];
+      EDT_Q16_UNROLL
+      for (int ii = 0; ii < B; ++ii) {
+        // (the first and the last row of the block need the rows just requested: they come last)
+        const int i = ii < B - 2 ? ii + 1 : (ii == B - 2 ? 0 : B - 1);
+        const pk m1 = pk_min(w[K + i - D], w[K + i + D]);
+        const pk m2 = pk_min(w[K + i - D - 1], w[K + i + D + 1]);
+        best[i] = pk_min(pk_min(best[i], pk_adds(m1, c1)), pk_adds(m2, c2));
+      }
+      run<D + 2>();
+    } else {
+      // Windows beyond the register-resident part: the same step as a rolled loop.  At step d row i looks at the rows
+      // p0+i-d and p0+i+d, i.e. at the B rows that entered the window most recently on either side: rings of 16 registers
+      // indexed by d mod 16, static once the loop body covers 16 consecutive steps.  Eight consecutive steps read eight
+      // consecutive rows on either side through one address; a stretch beyond the image is moved onto +inf rows.
+      constexpr int R = 16;
+      static_assert((K % R) == 0 && B < R, "ring phase / size");
+      pk rlo[R], rhi[R];
+      EDT_Q16_UNROLL
+      for (int s = K - B + 2; s <= K; ++s) {
+        rlo[s % R] = w[K - s];
+        rhi[s % R] = w[K + B - 1 + s];
+      }
+      const uint32_t *slo = L.img, *shi = L.img;
+      for (int d0 = K + 1; d0 < 4096; d0 += R) {
+        bool done = false;
+        EDT_Q16_UNROLL
+        for (int e = 0; e < R; e += 2) {  // steps d, d + 1 with d = d0 + e;  d mod R == (1 + e) mod R
+          const int d = d0 + e;
+          if (e % 4 == 0) refresh_bound();
+          const pk c1 = cpk(d), c2 = cpk(d + 1);
+          if (!EDT_Q16_ANY(pk_subs(bmax, c1) != 0u)) { done = true; break; }
+          if (e % 8 == 0) {
+            int rl = L.p0 - d - 7, rh = L.p0 + B - 1 + d;  // the rows of the next eight steps: rl .. rl+7, rh .. rh+7
+            rl = rl < -kPad ? -kPad : rl;
+            rh = rh > L.nb32 + kPad - 8 ? L.nb32 + kPad - 8 : rh;
+            slo = L.img + (rl + kPad) * RW + L.cp;
+            shi = L.img + (rh + kPad) * RW + L.cp;
+          }
+          const int s1 = (1 + e) % R, s2 = (2 + e) % R;
+          rlo[s1] = slo[(7 - e % 8) * RW];
+          rhi[s1] = shi[(e % 8) * RW];
+          rlo[s2] = slo[(6 - e % 8) * RW];
+          rhi[s2] = shi[(e % 8 + 1) * RW];
+          EDT_Q16_UNROLL
+          for (int i = 0; i < B; ++i) {
+            // row p0+i-d entered at step d-i, row p0+i+d at step d-(B-1-i)
+            const pk m1 = pk_min(rlo[(s1 - i + R) % R], rhi[(s1 - (B - 1 - i) + R) % R]);
+            const pk m2 = pk_min(rlo[(s2 - i + R) % R], rhi[(s2 - (B - 1 - i) + R) % R]);
+            best[i] = pk_min(pk_min(best[i], pk_adds(m1, c1)), pk_adds(m2, c2));
+          }
+        }
+        if (done) break;
+      }
+    }
+  }
+};
+
+// distance of the row before the block to the row before ITS run (kFar: that run has no border below), one column
+template <bool BB>
+EDT_LANE uint32_t dist_below(uint32_t rsw, int lo_in, int row0, int k0) {
+  const uint32_t lowm = k0 > 0 ? rsw & (0xFFFFFFFFu >> (32 - k0)) : 0u;  // run starts at rows < k0 of this band
+  const int s = lowm ? row0 + 31 - q16_clz(lowm) : lo_in;               // first row of the run of row p0 - 1
+  return (BB || s > 0) ? (uint32_t)(row0 + k0 - s) : kFar;
+}
+// distance of the row after the block to the first row of the next run (kFar: no border above), one column
+template <bool BB>
+EDT_LANE uint32_t dist_above(uint32_t rsw, int hi_out, int row0, int k0, int n) {
+  const uint32_t m = k0 + kB < 32 ? rsw & (0xFFFFFFFFu << (k0 + kB)) : 0u;
+  const int e = m ? row0 + q16_ctz(m) : hi_out + 1;
+  return (BB || e < n) ? (uint32_t)(e - (row0 + k0 + kB)) : kFar;
+}
+
+// best[i] = result of row p0 + i (both columns), in quanta
+template <bool BB>
+EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
+  constexpr int K = kK, B = kB, RW = kRowWords;
+  const int row0 = L.p0 & ~31, k0 = L.p0 & 31;
+  const uint32_t *PB = L.img + (L.p0 - K + kPad) * RW + L.cp;
+  pk w[B + 2 * K];
+  EDT_Q16_UNROLL
+  for (int j = 0; j < B; ++j) w[K + j] = PB[(K + j) * RW];
+  // ---- B_p: border distances as packed counters from run start to run start ----
+  const pk starts = ((L.rswA >> k0) & 0xFFu) | (((L.rswB >> k0) & 0xFFu) << 16);  // bit j of a half: a run starts at row p0 + j
+  pk dl = dist_below<BB>(L.rswA, L.loA, row0, k0) | (dist_below<BB>(L.rswB, L.loB, row0, k0) << 16);
+  // (a block that reaches beyond the column's last row has a "negative" distance above: the counters are 16-bit modular,
+  // the rows of the column come out right and the others are not rows)
+  pk dr = (dist_above<BB>(L.rswA, L.hiA, row0, k0, L.n) & 0xFFFFu) | (dist_above<BB>(L.rswB, L.hiB, row0, k0, L.n) << 16);
+  const pk one = 0x00010001u;
+  // a run that starts at row 0 of the column has a border below it only with black_border
+  const pk first0 = (BB || L.p0 > 0) ? one : pk_both(kFar);
+  pk mask[B], dlv[B];
+  {
+#define EDT_Q16_ROW_UP(J)                                                   \
+    mask[J] = pk_sar15(pk_shl<15 - J>(starts));                             \
+    EDT_Q16_OPAQUE(mask[J]);                                                \
+    dl = pk_sel(mask[J], J == 0 ? first0 : one, pk_add(dl, one));           \
+    dlv[J] = dl;
+    EDT_Q16_ROW_UP(0) EDT_Q16_ROW_UP(1) EDT_Q16_ROW_UP(2) EDT_Q16_ROW_UP(3)
+    EDT_Q16_ROW_UP(4) EDT_Q16_ROW_UP(5) EDT_Q16_ROW_UP(6) EDT_Q16_ROW_UP(7)
+#undef EDT_Q16_ROW_UP
+  }
+  const pk dmaxpk = pk_both(L.dmax), apk = pk_both(L.a);
+  pk bmax = 0;
+  EDT_Q16_UNROLL
+  for (int j = B - 1; j >= 0; --j) {
+    dr = pk_add(dr, one);
+    const pk dm = pk_min(pk_min(dlv[j], dr), dmaxpk);
+    // a * min(d, dmax)^2 fits 16 bits; a tile on this path holds no value above a * dmax^2, so the clamp changes no minimum
+    const pk bord = pk_mul(pk_mul(dm, dm), apk);
+    best[j] = pk_min(w[K + j], bord);
+    dr = dr & ~mask[j];  // (a set bit is a real row: the border site of the rows below it)
+  }
+  // rows that complete the last band are not rows of the column
+  if (L.p0 + B > L.n) {
+    EDT_Q16_UNROLL
+    for (int j = 0; j < B; ++j)
+      if (L.p0 + j >= L.n) best[j] = 0u;
+  }
+  EDT_Q16_UNROLL
+  for (int j = 0; j < B; ++j) bmax = pk_max(bmax, best[j]);
+  // ---- flat neighbourhood: nothing within reach can improve any row of the wave's blocks ----
+  {
+    uint32_t D1 = (uint32_t)flat_reach(L.win) + 1u;
+    D1 = D1 < L.dmax + 1u ? D1 : L.dmax + 1u;
+    const uint32_t cD = L.a * D1 * D1;
+    if (!EDT_Q16_ANY(pk_subs(bmax, pk_both(cD < kInf ? cD : kInf)) != 0u)) return;
+  }
+  Steps<BB> steps{L, w, best, PB, bmax, L.a};
+  steps.template run<1>();
+}
+
+// ---------------------------------------------------------------------------------------
+// Run structure across the bands of one column (one thread per column and direction walks the band words):
+// lo[b] = last run start in a band before b (-1: none), hi[b] = row before the first run start in a band after b
+// (n - 1: none).  Stored as lo + 1 / hi + 1 in 16-bit planes.
+// ---------------------------------------------------------------------------------------
+EDT_LANE void scan_runs_lo(const uint32_t *rs_col, int stride, int NB, uint16_t *lo_col, int ostride) {
+  int last = -1;
+  for (int b = 0; b < NB; ++b) {
+    lo_col[b * ostride] = (uint16_t)(last + 1);
+    const uint32_t r = rs_col[b * stride];
+    if (r) last = 32 * b + 31 - q16_clz(r);
+  }
+}
+EDT_LANE void scan_runs_hi(const uint32_t *rs_col, int stride, int NB, int n, uint16_t *hi_col, int ostride) {
+  int first = n;
+  for (int b = NB - 1; b >= 0; --b) {
+    hi_col[b * ostride] = (uint16_t)first;  // (= hi_out + 1)
+    const uint32_t r = rs_col[b * stride];
+    if (r) first = 32 * b + q16_ctz(r);
+  }
+}
+
+}  // namespace edt_q16

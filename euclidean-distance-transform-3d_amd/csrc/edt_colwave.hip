@@ -10,13 +10,14 @@ namespace edt_amd {
 
 template <int CW>
 int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w, int bb, int epi,
-                  const XFuse *xf, hipStream_t stream, const BandScatter *scatter, bool sc_al, const ColumnOut &out_stride);
-extern template int launch_wave_c<32>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
-extern template int launch_wave_c<16>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
-extern template int launch_wave_c<8>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
-extern template int launch_wave_c<4>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
-extern template int launch_wave_c<2>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
-extern template int launch_wave_c<1>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
+                  const XFuse *xf, hipStream_t stream, const BandScatter *scatter, bool sc_al, const ColumnOut &out_stride,
+                  const TileList &list);
+extern template int launch_wave_c<32>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &, const TileList &);
+extern template int launch_wave_c<16>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &, const TileList &);
+extern template int launch_wave_c<8>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &, const TileList &);
+extern template int launch_wave_c<4>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &, const TileList &);
+extern template int launch_wave_c<2>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &, const TileList &);
+extern template int launch_wave_c<1>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int, const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &, const TileList &);
 
 // Largest window of the windowed path (edt_colwave_lane.h: brute_band): a tile takes it when no row can be
 // improved by a row further than this away.  EDT_HIP_WINDOW_LIMIT overrides the default (experiments).
@@ -52,33 +53,35 @@ bool column_pass_wave_supported(const AxisGeom &g) {
 
 static int launch_wave_any(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int bb, int epi, const XFuse *xf, hipStream_t stream,
-                           const BandScatter *sc = nullptr, bool sc_al = false, const ColumnOut &out_stride = ColumnOut()) {
+                           const BandScatter *sc = nullptr, bool sc_al = false, const ColumnOut &out_stride = ColumnOut(),
+                           const TileList &list = TileList()) {
   const int64_t NB = g.nbands;
-  if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
-  if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
-  if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
-  if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
-  if (NB <= 32) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
-  if (NB <= 64) return launch_wave_c<1>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride);
+  if (NB <= 2) return launch_wave_c<32>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride, list);
+  if (NB <= 4) return launch_wave_c<16>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride, list);
+  if (NB <= 8) return launch_wave_c<8>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride, list);
+  if (NB <= 16) return launch_wave_c<4>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride, list);
+  if (NB <= 32) return launch_wave_c<2>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride, list);
+  if (NB <= 64) return launch_wave_c<1>(F, nz, rs, g, w, bb, epi, xf, stream, sc, sc_al, out_stride, list);
   set_error("axis too long for the wave column pass");
   return EDT_ERR_UNSUPPORTED;
 }
 
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                            float w, int bb, int epi, hipStream_t stream, const BandScatter *scatter, const ColumnOut &out_stride) {
+                            float w, int bb, int epi, hipStream_t stream, const BandScatter *scatter, const ColumnOut &out_stride,
+                            const TileList &list) {
   // (the caller of the scattering variant guarantees 16-byte aligned destinations when sx % 4 == 0)
-  return launch_wave_any(F, nz, rs, g, w, bb, epi, nullptr, stream, scatter, scatter != nullptr, out_stride);
+  return launch_wave_any(F, nz, rs, g, w, bb, epi, nullptr, stream, scatter, scatter != nullptr, out_stride, list);
 }
 
 // First column pass reading pass 1 as 16-bit distance indices (edt_rowwave.hip, C16): F is only written.
 int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_t *nz, const uint32_t *rs,
                                   const AxisGeom &g, float w, int bb, int epi, float wx, int to_finite,
-                                  hipStream_t stream, const BandScatter *scatter) {
+                                  hipStream_t stream, const BandScatter *scatter, const TileList &list) {
   XFuse xf;
   xf.codes = codes;
   xf.w = wx;
   xf.flim = to_finite ? 0x7f7fffff : 0x7f800000;
-  return launch_wave_any(F, nz, rs, g, w, bb, epi, &xf, stream, scatter, scatter != nullptr);
+  return launch_wave_any(F, nz, rs, g, w, bb, epi, &xf, stream, scatter, scatter != nullptr, ColumnOut(), list);
 }
 
 }  // namespace edt_amd

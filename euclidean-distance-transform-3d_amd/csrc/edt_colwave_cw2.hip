@@ -4,5 +4,6 @@
 
 namespace edt_amd {
 template int launch_wave_c<2>(float *, const uint32_t *, const uint32_t *, const AxisGeom &, float, int, int,
-                               const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &);
+                               const XFuse *, hipStream_t, const BandScatter *, bool, const ColumnOut &,
+                               const TileList &);
 }  // namespace edt_amd

@@ -67,6 +67,9 @@ struct BruteArgs {
   // mono_lo_bits < bits(v) <= mono_hi_bits (mono_hi_bits = 0: never; mono_force: every tile up to mono_hi_bits)
   uint32_t mono_lo_bits, mono_hi_bits;
   int mono_force;
+  // list mode (nullptr: every tile of the grid): the launch serves the tiles the 16-bit integer kernel handed over
+  // (edt_colq16.hip) -- workgroup b takes tile list_ids[b] (already in the XCD-aware order) if b < *list_count
+  const uint32_t *list_count, *list_ids;
 };
 int window_limit();  // edt_colwave.hip: largest window (rows) the windowed path is used for
 int mono_from();     // edt_colwave.hip: tiles with windows beyond this many rows take the bracket path (where it applies)
@@ -387,7 +390,10 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   // restores the plain order.
   // (tile ids fit 31 bits -- the launcher checks: 32-bit divisions, not 64-bit ones, ahead of every wave's first load)
   const uint32_t utx = (uint32_t)tiles_x;
-  if (!(dbg & 0x800)) {
+  if (ba.list_count != nullptr) {  // (wave-uniform: kernel argument)
+    if (blockIdx.x >= *ba.list_count) return;
+    tile_id = ba.list_ids[blockIdx.x];
+  } else if (!(dbg & 0x800)) {
     const uint32_t t = (uint32_t)tile_id, x = t & 7u, j = t >> 3;
     const uint32_t jq = j / utx, jr = j - jq * utx;
     tile_id = (int64_t)((jq * 8u + x) * utx + jr);
@@ -672,7 +678,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
 template <int CW, bool BB, bool XF, bool SC>
 static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
-                           bool scatter_aligned, const ColumnOut &out_stride) {
+                           bool scatter_aligned, const ColumnOut &out_stride, const TileList &list) {
   constexpr int NBP = 64 / CW;
   using TG = edt_lane::TileGeom<CW>;
   constexpr int TC = TG::kCols;
@@ -721,6 +727,8 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
   // every tile the exactness conditions allow, whatever its windows.)
   ba.mono_lo_bits = ba.mono_hi_bits = 0u;
   ba.mono_force = 0;
+  ba.list_count = list.count;
+  ba.list_ids = list.ids;
 #ifdef EDT_MONO
   if (!(debug_mode() & 0x800000) && ba.stride == 1 && ba.compact == nullptr &&
       edt_lane::mono_limits(w, (int)g.n, mono_from(), ba.mono_lo_bits, ba.mono_hi_bits)) {
@@ -748,24 +756,24 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
 template <int CW, bool BB, bool XF>
 static int launch_wave_cbx(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                            int epi, const XFuse &xf, hipStream_t stream, const BandScatter *scatter,
-                           bool scatter_aligned, const ColumnOut &out_stride) {
+                           bool scatter_aligned, const ColumnOut &out_stride, const TileList &list) {
   // the scattering epilogue (Z-sharded path) is a compile-time variant
   if (scatter != nullptr)
-    return launch_wave_cbx_sc<CW, BB, XF, true>(F, nz, rs, g, w, epi, xf, stream, scatter, scatter_aligned, out_stride);
-  return launch_wave_cbx_sc<CW, BB, XF, false>(F, nz, rs, g, w, epi, xf, stream, nullptr, false, out_stride);
+    return launch_wave_cbx_sc<CW, BB, XF, true>(F, nz, rs, g, w, epi, xf, stream, scatter, scatter_aligned, out_stride, list);
+  return launch_wave_cbx_sc<CW, BB, XF, false>(F, nz, rs, g, w, epi, xf, stream, nullptr, false, out_stride, list);
 }
 
 template <int CW>
 int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g, float w,
                          int bb, int epi, const XFuse *xf, hipStream_t stream, const BandScatter *scatter,
-                         bool sc_al, const ColumnOut &out_stride) {
+                         bool sc_al, const ColumnOut &out_stride, const TileList &list) {
   // the border rule and the index form of pass 1 are compile-time variants, the epilogue a run-time one
   const XFuse none = {nullptr, 0.0f, 0};
   if (xf)
-    return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride)
-              : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride);
-  return bb ? launch_wave_cbx<CW, true, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al, out_stride)
-            : launch_wave_cbx<CW, false, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al, out_stride);
+    return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride, list)
+              : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride, list);
+  return bb ? launch_wave_cbx<CW, true, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al, out_stride, list)
+            : launch_wave_cbx<CW, false, false>(F, nz, rs, g, w, epi, none, stream, scatter, sc_al, out_stride, list);
 }
 
 }  // namespace edt_amd

@@ -121,16 +121,32 @@ struct ColumnOut {
                              // column (x, outer index o) goes to compact[x + o * outer + (r / 2) * row2]
   int64_t outer = 0, row2 = 0;
 };
+// The tiles a launch of the fp32 column kernel serves: every tile of its grid (count = nullptr), or -- list mode -- the
+// tiles the 16-bit integer kernel (edt_colq16.hip) handed over: workgroup b takes ids[b] if b < *count (device memory).
+struct TileList {
+  const uint32_t *count = nullptr;
+  const uint32_t *ids = nullptr;
+};
 // scatter != nullptr (device table): the rows are written to the slab records instead of F
 // out: see ColumnOut (default: every row, in place) -- (tiles on the windowed path evaluate and write
 // just those; tiles on the hull path still write every row)
 int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
                             float w, int bb, int epi, hipStream_t stream,
-                            const BandScatter *scatter = nullptr, const ColumnOut &out = ColumnOut());
+                            const BandScatter *scatter = nullptr, const ColumnOut &out = ColumnOut(),
+                            const TileList &list = TileList());
 // the same reading pass 1 as 16-bit distance indices (F is write-only): see XFuse
 int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_t *nz, const uint32_t *rs,
                                   const AxisGeom &g, float w, int bb, int epi, float wx, int to_finite,
-                                  hipStream_t stream, const BandScatter *scatter = nullptr);
+                                  hipStream_t stream, const BandScatter *scatter = nullptr, const TileList &list = TileList());
+// ---- 16-bit integer column pass: edt_colq16.hip ---------------------------------------------------
+// the quantum of a call: w_i^2 = a[i] * q (false: the voxel sizes share none, the fp32 kernels keep the call)
+bool q16_quantum(const float *w, int naxes, float *q, uint32_t *a);
+bool column_pass_q16_supported(const AxisGeom &g);
+// codes != nullptr: pass X in index form (N = k^2 * ain), F is only written; else F is read (N = F / q, verified) and
+// written in place.  a: c_d = a * d^2 quanta.  Tiles that do not qualify are appended to (count, ids) for the fp32 kernel.
+int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
+                           uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
+                           const BandScatter *scatter = nullptr);
 }  // namespace edt_amd
 
 namespace edt_amd {

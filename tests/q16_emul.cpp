@@ -1,0 +1,152 @@
+// tests/q16_emul.cpp -- TEST FIXTURE: lane-by-lane host emulation of the 16-bit integer column pass
+// (euclidean-distance-transform-3d_amd/csrc/edt_colq16_lane.h + the workgroup logic of edt_colq16.hip).
+//
+// Compiles the SAME per-lane header the HIP kernel is built from with g++ and plays the fill, the scans and every block of
+// every tile in sequence, ordinary arrays standing in for LDS, so that the CPU tier (tests/test_q16_logic.py) can hold the
+// packed border counters, the break bits, the window steps and the tile qualification against the oracle without a GPU.
+// Never linked into the product library.
+//
+//   g++ -O2 -ffp-contract=off -shared -fPIC -I<csrc> tests/q16_emul.cpp -o libq16_emul.so
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#define EDT_LANE static inline
+#define EDT_LANE_MEMBER inline
+#include "edt_colq16_lane.h"
+
+using namespace edt_q16;
+
+namespace {
+
+// one tile: columns x0 .. x0+31.  Returns false if the tile does not qualify (nothing is written then).
+template <bool BB>
+bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, float *out, int64_t sx, int n, int64_t x0,
+               float q, uint32_t a, uint32_t ain, int epi, long *steps_taken) {
+  const int NB = (n + 31) / 32, nb32 = NB * 32;
+  const int cols_left = (int)(sx - x0);
+  const uint32_t dmax = q16_dmax(a), nlim = a * dmax * dmax;
+  uint32_t kmax = 0;
+  while ((uint64_t)(kmax + 1) * (kmax + 1) * ain <= nlim && kmax < 65534u) ++kmax;
+  std::vector<uint32_t> img((size_t)(nb32 + 2 * kPad) * kRowWords, 0xFFFFFFFFu);
+  std::vector<uint32_t> rsp((size_t)NB * 32, 0), lohi((size_t)NB * 32, 0), bm(16 * 6, 0);
+  bool bad = false;
+  // ---- fill (edt_colq16.hip, phase 0) ----
+  auto put = [&](int row, int col, uint32_t v) {
+    uint32_t &wd = img[(size_t)(row + kPad) * kRowWords + col / 2];
+    wd = (col & 1) ? ((wd & 0xFFFFu) | (v << 16)) : ((wd & 0xFFFF0000u) | (v & 0xFFFFu));
+  };
+  for (int row = 0; row < nb32; ++row)
+    for (int col = 0; col < 32; ++col) {
+      uint32_t v = 0;
+      if (row >= n) v = 0xFFFFu;
+      else if (col < cols_left) {
+        if (codes) {
+          const uint32_t k = codes[(int64_t)row * sx + x0 + col];
+          if (k > kmax) bad = true;
+          v = (uint32_t)(uint16_t)((uint16_t)(k * k) * (uint16_t)ain);  // (wraps like the packed multiply; unused if bad)
+        } else {
+          const float f = Fin[(int64_t)row * sx + x0 + col];
+          const float flim = (float)nlim + 1.0f;
+          const float tq = fminf(f * (1.0f / q), flim);
+          const uint32_t u = (uint32_t)(tq + 0.5f);
+          const float e = fmaf(-(float)u, q, f);
+          if (!(fabsf(e) == 0.0f) || u > nlim) bad = true;
+          v = u & 0xFFFFu;
+        }
+      }
+      put(row, col, v);
+    }
+  for (int band = 0; band < NB; ++band)
+    for (int col = 0; col < 32; ++col)
+      rsp[(size_t)band * 32 + col] = col < cols_left ? rsbits[(size_t)band * sx + x0 + col] : 0u;
+  if (bad) return false;
+  // ---- scans + breaks (phase 1) ----
+  uint16_t *lohi16 = reinterpret_cast<uint16_t *>(lohi.data());
+  for (int t = 0; t < 32; ++t) {
+    scan_runs_lo(rsp.data() + t, 32, NB, lohi16 + 2 * t, 64);
+    scan_runs_hi(rsp.data() + t, 32, NB, n, lohi16 + 2 * t + 1, 64);
+  }
+  const pk apk = pk_both(a);
+  for (int u = 0; u < 16 * NB; ++u) {
+    const int cp = u & 15, band = u >> 4;
+    const int valid = n - 32 * band;
+    const uint32_t bits = band_breaks(img.data() + (size_t)(32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32);
+    bm[cp * 6 + 1 + (band >> 3)] |= bits << (4 * (band & 7));
+  }
+  // ---- blocks (phase 2) ----
+  for (int s = 0; s < NB; ++s)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int cp = lane & 15, bq = lane >> 4;
+      Block L;
+      L.img = img.data();
+      L.cp = cp;
+      L.p0 = 32 * s + 8 * bq;
+      L.n = n;
+      L.nb32 = nb32;
+      L.rswA = rsp[(size_t)s * 32 + 2 * cp];
+      L.rswB = rsp[(size_t)s * 32 + 2 * cp + 1];
+      const uint32_t lhA = lohi[(size_t)s * 32 + 2 * cp], lhB = lohi[(size_t)s * 32 + 2 * cp + 1];
+      L.loA = (int)(lhA & 0xFFFFu) - 1;
+      L.hiA = (int)(lhA >> 16) - 1;
+      L.loB = (int)(lhB & 0xFFFFu) - 1;
+      L.hiB = (int)(lhB >> 16) - 1;
+      L.a = a;
+      L.dmax = dmax;
+      {
+        const int wi = s >> 3, sh = (4 * s + bq) & 31;
+        const uint32_t *m = bm.data() + cp * 6 + wi;
+        const uint32_t e0 = m[0], e1 = m[1], e2 = m[2];
+        const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
+        const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
+        L.win = ((uint64_t)hi << 32) | lo;
+      }
+      pk best[kB];
+      block_eval<BB>(L, best);
+      (void)steps_taken;
+      for (int j = 0; j < kB; ++j) {
+        const int row = L.p0 + j;
+        if (row >= n) continue;
+        for (int h = 0; h < 2; ++h) {
+          const int col = 2 * cp + h;
+          if (col >= cols_left) continue;
+          float v = (float)((best[j] >> (16 * h)) & 0xFFFFu) * q;
+          if (epi & 2) v = sqrtf(v);
+          out[(int64_t)row * sx + x0 + col] = v;
+        }
+      }
+    }
+  return true;
+}
+
+}  // namespace
+
+// labels [n][sx] uint32 (the run structure along the scan axis), Fin [n][sx] fp32 or codes [n][sx] u16 (exactly one of
+// them), out [n][sx].  tile_ok[i] = 1 if x-tile i qualified (and was written).  Returns the number of tiles that did.
+extern "C" int q16_emul_column_pass(const uint32_t *labels, const float *Fin, const uint16_t *codes, float *out, int64_t sx,
+                                    int64_t n, float q, uint32_t a, uint32_t ain, int bb, int epi, uint8_t *tile_ok) {
+  const int NB = (int)((n + 31) / 32);
+  std::vector<uint32_t> rs((size_t)NB * sx, 0);
+  for (int64_t x = 0; x < sx; ++x)
+    for (int64_t y = 0; y < n; ++y) {
+      const uint32_t lab = labels[y * sx + x];
+      const bool start = (y == 0) || lab != labels[(y - 1) * sx + x];
+      if (start) rs[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
+    }
+  int ok = 0;
+  for (int64_t x0 = 0, i = 0; x0 < sx; x0 += 32, ++i) {
+    const bool r = bb ? tile_pass<true>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr)
+                      : tile_pass<false>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr);
+    tile_ok[i] = r ? 1 : 0;
+    ok += r ? 1 : 0;
+  }
+  return ok;
+}
+
+extern "C" int q16_emul_quantum(const float *w, int naxes, float *q, uint32_t *a) {
+  const Quantum Q = quantum_of(w, naxes);
+  *q = Q.q;
+  for (int i = 0; i < 3; ++i) a[i] = Q.a[i];
+  return Q.ok ? 1 : 0;
+}

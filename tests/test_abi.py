@@ -50,13 +50,14 @@ def test_argument_validation_needs_no_gpu(lib):
     # distance indices of pass 1, one slab of at most 2^27 voxels of them (256 MiB) whatever the volume ...
     v = 64 * 64 * 64
     assert 4 * v // 8 + 2 * v <= lib.edt_hip_workspace_bytes(_lib.U32, 3, 64, 64, 64) <= 4 * v // 8 + 2 * v + 4096
-    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 1024, 1024, 1024) <= (1 << 29) + (1 << 28) + 4096   # 0.75 GiB for 1024^3
-    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 2048, 2048, 512) <= (1 << 30) + (1 << 28) + 4096
+    # (+ the hand-over list of the 16-bit integer column kernel: 4 bytes per tile)
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 1024, 1024, 1024) <= (1 << 29) + (1 << 28) + (1 << 18)   # 0.75 GiB for 1024^3
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 2048, 2048, 512) <= (1 << 30) + (1 << 28) + (1 << 20)
     # ... which a caller can decline (EDT_FLAG_SMALL_WORKSPACE: fp32 between passes X and Y): 0.5 GiB for 1024^3
-    assert lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 1024, 1024, 1024, _lib.FLAG_SMALL_WORKSPACE) <= (1 << 29) + 4096
-    assert lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 64, 64, 64, _lib.FLAG_SMALL_WORKSPACE) <= 4 * v // 8 + 4096
+    assert lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 1024, 1024, 1024, _lib.FLAG_SMALL_WORKSPACE) <= (1 << 29) + (1 << 18)
+    assert lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 64, 64, 64, _lib.FLAG_SMALL_WORKSPACE) <= 4 * v // 8 + 8192
     # (rows that are not whole 8-byte granules of indices keep the fp32 form of pass 1: bit planes only)
-    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 63, 64, 64) <= 4 * 64 * 64 * 64 // 8 + 4096
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 63, 64, 64) <= 4 * 64 * 64 * 64 // 8 + 8192
     # ... only the size-agnostic kernels need a second fp32 volume and the hull stacks
     assert (lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 64, 64, 64, _lib.FLAG_FORCE_GENERIC)
             >= 2 * 64 * 64 * 64 * 4)

@@ -1,0 +1,162 @@
+"""CPU tier: the 16-bit integer column pass (csrc/edt_colq16_lane.h), emulated lane by lane.
+
+tests/q16_emul.cpp compiles the SAME per-lane header the HIP kernel is built from with g++ and plays the fill, the scans,
+the break bits and every block of every tile.  Checked bit for bit against the oracle on 2-D images: pass 1 comes from the
+oracle's 1-D transform (as fp32 values, or as the 16-bit distance indices of the index form), the emulation supplies
+pass 2, the oracle's 2-D transform is the expected result.  Tiles that do not qualify (values beyond 16 bits, values off
+the quantum grid) must be refused, never written.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from synth import blocky_labels
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "euclidean-distance-transform-3d_amd", "csrc")
+BUILD = os.path.join(ROOT, "tests", "_build")
+FLT_MAX = np.float32(3.402823466e+38)
+
+
+@pytest.fixture(scope="module")
+def q16():
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "libq16_emul.so")
+    src = os.path.join(ROOT, "tests", "q16_emul.cpp")
+    hdr = os.path.join(CSRC, "edt_colq16_lane.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        tmp = f"{so}.{os.getpid()}.tmp"
+        subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC",
+                        f"-I{CSRC}", src, "-o", tmp], check=True)
+        os.replace(tmp, so)
+    lib = ctypes.CDLL(so)
+    lib.q16_emul_column_pass.restype = ctypes.c_int
+    lib.q16_emul_quantum.restype = ctypes.c_int
+    return lib
+
+
+def quantum(lib, w):
+    wa = (ctypes.c_float * 3)(*[float(v) for v in w], *([1.0] * (3 - len(w))))
+    q = ctypes.c_float(0)
+    a = (ctypes.c_uint32 * 3)()
+    ok = lib.q16_emul_quantum(wa, ctypes.c_int(len(w)), ctypes.byref(q), a)
+    return bool(ok), q.value, [int(v) for v in a]
+
+
+def column_pass(lib, labels_yx, f_yx, codes_yx, q, a, ain, bb, epi):
+    n, sx = labels_yx.shape
+    lab = np.ascontiguousarray(labels_yx, dtype=np.uint32)
+    out = np.full((n, sx), -1.0, dtype=np.float32)
+    ok = np.zeros((sx + 31) // 32, dtype=np.uint8)
+    f = None if f_yx is None else np.ascontiguousarray(f_yx, dtype=np.float32)
+    c = None if codes_yx is None else np.ascontiguousarray(codes_yx, dtype=np.uint16)
+    lib.q16_emul_column_pass(lab.ctypes.data_as(ctypes.c_void_p),
+                             f.ctypes.data_as(ctypes.c_void_p) if f is not None else None,
+                             c.ctypes.data_as(ctypes.c_void_p) if c is not None else None,
+                             out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(sx), ctypes.c_int64(n),
+                             ctypes.c_float(q), ctypes.c_uint32(a), ctypes.c_uint32(ain), ctypes.c_int(int(bb)),
+                             ctypes.c_int(epi), ok.ctypes.data_as(ctypes.c_void_p))
+    return out, ok.astype(bool)
+
+
+def x_pass(oracle, labels_yx, wx, bb):
+    rows = [oracle.raw1d(np.ascontiguousarray(r, dtype=np.uint32), 2, r.size, wx, bb) for r in labels_yx]
+    f = np.stack(rows).astype(np.float32)
+    codes = np.where(np.isinf(f), 0xFFFF, np.rint(np.sqrt(f.astype(np.float64)) / wx)).astype(np.uint16)
+    if not bb:
+        f[np.isinf(f)] = FLT_MAX  # tofinite (src/edt.hpp:39-45)
+    return f, codes
+
+
+def make_labels(n, sx, kind, rng):
+    if kind == "ones":
+        return np.ones((n, sx), dtype=np.uint32)
+    if kind == "blocky":
+        return blocky_labels((n, sx), nlabels=4, zero_frac=0.15, block=int(rng.integers(3, 40)), rng=rng).astype(np.uint32)
+    if kind == "noise":
+        return rng.integers(0, 3, size=(n, sx)).astype(np.uint32)
+    if kind == "cells":
+        return blocky_labels((n, sx), nlabels=200, zero_frac=0.0, block=int(rng.integers(20, 90)), rng=rng).astype(np.uint32)
+    lab = blocky_labels((n, sx), nlabels=2, zero_frac=0.0, block=int(rng.integers(20, 200)), rng=rng).astype(np.uint32)
+    lab[rng.random((n, sx)) < 0.01] = 0
+    return lab
+
+
+CASES = []
+for n, sx in ((1024, 32), (1000, 36), (900, 64), (513, 8), (512, 64), (512, 96), (500, 36), (300, 40), (257, 40), (256, 32),
+              (130, 96), (128, 8), (100, 44), (64, 32), (33, 64), (32, 4), (17, 12), (8, 8), (1, 8)):
+    for kind in ("ones", "blocky", "noise", "membrane", "cells"):
+        CASES.append((n, sx, kind))
+
+
+@pytest.mark.parametrize("n,sx,kind", CASES)
+def test_q16_column_pass_matches_oracle(q16, oracle_port, n, sx, kind):
+    rng = np.random.default_rng(n * 1000 + sx)
+    lab = make_labels(n, sx, kind, rng)
+    for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (30.0, 6.0), (0.5, 1.0), (4.0, 40.0)):
+        ok, q, a = quantum(q16, (wx, wy))
+        assert ok, (wx, wy)
+        assert np.float32(q) * a[0] == np.float32(wx) ** 2 and np.float32(q) * a[1] == np.float32(wy) ** 2
+        for bb in (True, False):
+            f1, codes = x_pass(oracle_port, lab, wx, bb)
+            want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
+            for form in ("f32", "codes"):
+                got, tiles = column_pass(q16, lab, f1 if form == "f32" else None, codes if form == "codes" else None,
+                                         q, a[1], a[0], bb, 0)
+                got_s, tiles_s = column_pass(q16, lab, f1 if form == "f32" else None, codes if form == "codes" else None,
+                                             q, a[1], a[0], bb, 2)
+                assert np.array_equal(tiles, tiles_s)
+                for i, t_ok in enumerate(tiles):
+                    sl = slice(32 * i, min(sx, 32 * i + 32))
+                    if t_ok:
+                        assert np.array_equal(got[:, sl], want[:, sl]), (n, sx, kind, wx, wy, bb, form, i)
+                        assert np.array_equal(got_s[:, sl], np.sqrt(want[:, sl])), (n, sx, kind, wx, wy, bb, form, i, "sqrt")
+                    else:
+                        assert (got[:, sl] == -1.0).all(), "a refused tile was written"
+                        # a refusal has a reason: a value beyond the tile limit (rows without a boundary included)
+                        dmax = int(np.floor(np.sqrt(65534 / a[1])))
+                        assert (f1[:, sl].astype(np.float64) / q).max() > a[1] * dmax * dmax or \
+                            (codes[:, sl].astype(np.int64) ** 2 * a[0]).max() > a[1] * dmax * dmax
+                # (without a black border a row inside one label has no boundary at all: FLT_MAX, the tile is refused)
+                if bb and (kind in ("blocky", "noise", "cells") or (kind == "membrane" and n <= 512)) and wx <= 6.0:
+                    assert tiles.any(), (n, sx, kind, wx, wy, bb, form)
+
+
+def test_q16_refuses_values_off_the_quantum_grid(q16, oracle_port):
+    rng = np.random.default_rng(5)
+    lab = make_labels(128, 64, "cells", rng)
+    f1, _ = x_pass(oracle_port, lab, 1.0, True)
+    f1[40, 5] = np.float32(2.5)           # not a multiple of q = 1
+    f1[90, 40] = np.float32(70000.0)      # beyond 16 bits
+    _, tiles = column_pass(q16, lab, f1, None, 1.0, 1, 1, True, 0)
+    assert list(tiles) == [False, False]
+    f1[40, 5] = np.float32(2.0)
+    _, tiles = column_pass(q16, lab, f1, None, 1.0, 1, 1, True, 0)
+    assert list(tiles) == [True, False]
+
+
+def test_quantum_of_voxel_sizes(q16):
+    assert quantum(q16, (1.0, 1.0, 1.0)) == (True, 1.0, [1, 1, 1])
+    assert quantum(q16, (6.0, 6.0, 30.0)) == (True, 36.0, [1, 1, 25])
+    assert quantum(q16, (4.0, 4.0, 40.0)) == (True, 16.0, [1, 1, 100])
+    assert quantum(q16, (0.5, 0.5, 1.0)) == (True, 0.25, [1, 1, 4])
+    assert quantum(q16, (3.0, 5.0)) == (True, 1.0, [9, 25, 1])
+    ok, q, a = quantum(q16, (2.0 ** -30, 2.0 ** -30, 2.0 ** -29))
+    assert ok and a == [1, 1, 4] and q == 2.0 ** -60
+    for w in ((3.58, 3.58, 40.0), (1.1, 1.1, 1.1), (0.7, 1.3), (1.0, 1.0, 1000.0), (1.0, 1e-3), (16381.0, 1.0), (1.0, 0.0),
+              (float("nan"), 1.0), (1.0, float("inf"))):
+        assert not quantum(q16, w)[0], w
+    # every quantum reproduces the squares exactly, and N * q is exact for 16-bit N
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        w = [float(np.float32(rng.integers(1, 64) * 2.0 ** int(rng.integers(-6, 6)))) for _ in range(3)]
+        ok, q, a = quantum(q16, w)
+        if not ok:
+            continue
+        for wi, ai in zip(w, a):
+            assert np.float32(q) * np.float32(ai) == np.float32(wi) * np.float32(wi)
+        for N in (1, 3, 65533, 65534):
+            assert float(np.float32(N) * np.float32(q)) == N * float(q)

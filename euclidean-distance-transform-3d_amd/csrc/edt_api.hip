@@ -123,6 +123,9 @@ struct Plan {
   // the tiles the 16-bit integer column kernel hands to the fp32 kernel (edt_colq16.hip): kQ16Slots counters, one per
   // column-pass launch of a call, and one array of tile ids (launches are stream-ordered: the array is reused)
   uint32_t *q16_counts = nullptr, *q16_ids = nullptr;
+  // which tiles of pass Y left their results in the 16-bit plane (= codes): one bit per (x-tile, z), behind the counters
+  uint32_t *q16_map = nullptr;
+  int q16_map_words = 0;  // words per x-tile
   size_t bytes = 0;
 };
 
@@ -193,7 +196,9 @@ static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, v
   if (ndim >= 2 && !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic()) {
     const int64_t ty = ceil_div(sx, 32) * (ceil_div(p.xy_slab > 0 ? p.xy_slab : sz, 8) * 8);
     const int64_t tz = ceil_div(sx, 32) * (ceil_div(sy, 8) * 8);
-    p.q16_counts = c.take<uint32_t>(kQ16Slots);
+    p.q16_map_words = (int)ceil_div(sz, 32);
+    p.q16_counts = c.take<uint32_t>(kQ16Slots + (size_t)(ceil_div(sx, 32) * p.q16_map_words));  // (zeroed together)
+    p.q16_map = p.q16_counts ? p.q16_counts + kQ16Slots : nullptr;
     p.q16_ids = c.take<uint32_t>((size_t)std::max(ty, tz));
   }
   if (ndim == 1) (void)c.take<unsigned char>(line_workspace_bytes(sx));  // block scan + table of the 1-D pipeline
@@ -322,18 +327,20 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   if (ndim >= 2 && p.q16_counts != nullptr) {
     const float ws3[3] = {wx, wy, wz};
     q16 = q16_quantum(ws3, (ndim == 3 && !(flags & EDT_FLAG_BATCH_2D)) ? 3 : 2, &q16_q, q16_a);
-    if (q16) EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, kQ16Slots * sizeof(uint32_t), stream));
+    if (q16) EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, (kQ16Slots + (size_t)(ceil_div(sx, 32) * p.q16_map_words)) * sizeof(uint32_t), stream));
   }
+  constexpr int kQ16Off = 16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x400000;
   // F in place (codes == nullptr) or from the 16-bit indices of pass X; returns the list for the fp32 launch that follows
   auto q16_pass = [&](float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, int axis, int epi,
-                      TileList &list) -> int {
+                      TileList &list, uint16_t *plane = nullptr) -> int {
     list = TileList();
     // (the bits that force one form of the fp32 kernel on every tile -- the test tiers' way to cover them -- keep the call there)
     if (!q16 || q16_slot >= kQ16Slots || !column_pass_q16_supported(g) || !column_pass_wave_supported(g) ||
-        (g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x400000)))
+        (g_debug_mode & kQ16Off))
       return EDT_OK;
     uint32_t *count = p.q16_counts + q16_slot++;
-    const int r = launch_column_pass_q16(F, codes, rs, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, p.q16_ids, stream);
+    const int r = launch_column_pass_q16(F, codes, rs, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, p.q16_ids, stream,
+                                         nullptr, plane, p.q16_map, p.q16_map_words);
     if (r != EDT_OK) return r;
     list.count = count;
     list.ids = p.q16_ids;
@@ -360,6 +367,13 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   // them into F while it fills its tile -- 2 B less written and 2 B less read per voxel.  Bit-identical only where
   // every multiple k * wx of the row is exact in fp32 (row_codes_exact); other voxel sizes keep the fp32 form.
   const bool index_form = p.codes != nullptr && tiled_x && tiled_y && row_codes_exact(wx, sx);
+  // The 16-bit plane between passes Y and Z: where both run on the integer kernel and the indices of pass X cover the whole
+  // volume (one slab), the tiles of pass Y that qualify write their results over their indices -- 2 bytes per voxel out
+  // of pass Y and into pass Z instead of 4 -- and pass Z reads every row from wherever pass Y left it.  (debug bit
+  // 0x10000000: fp32 between the passes.)
+  const bool plane16 = q16 && index_form && zpass && p.xy_slab >= sz && !(g_debug_mode & (kQ16Off | 0x10000000)) &&
+                       column_pass_q16_supported(p.gy) && column_pass_q16_supported(p.gz) &&
+                       column_pass_wave_supported(p.gy) && column_pass_wave_supported(p.gz);
   if (index_form) {
     const int64_t sxy = sx * sy, wpl = p.gy.sx * p.gy.nbands;  // voxels / bit words per slice
     const size_t lsz = dtype_size(dtype);
@@ -387,7 +401,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
         AxisGeom g = p.gy;
         g.nouter = zc;
         TileList list;
-        rc = q16_pass(cur + z0 * sxy, p.codes, p.rs_y + z0 * wpl, g, 1, zpass ? 0 : last_epi, list);
+        rc = q16_pass(cur + z0 * sxy, p.codes, p.rs_y + z0 * wpl, g, 1, zpass ? 0 : last_epi, list, plane16 ? p.codes : nullptr);
         if (rc != EDT_OK) return rc;
         rc = launch_column_pass_wave_codes(cur + z0 * sxy, p.codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
                                            zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream, nullptr, list);
@@ -449,7 +463,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     ScopedPass t("z_pass", stream);
     if (tiled_z) {
       TileList list;
-      rc = q16_pass(cur, nullptr, p.rs_z, p.gz, 2, last_epi, list);
+      rc = q16_pass(cur, nullptr, p.rs_z, p.gz, 2, last_epi, list, plane16 ? p.codes : nullptr);
       if (rc != EDT_OK) return rc;
       rc = launch_column_inplace(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream, list);
     } else {

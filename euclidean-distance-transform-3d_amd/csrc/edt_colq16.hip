@@ -22,6 +22,8 @@
 #include "edt_common.h"
 #include "edt_kernels.h"
 
+#include <cstdlib>
+
 #define EDT_LANE __device__ __forceinline__
 #define EDT_LANE_MEMBER __device__ __forceinline__
 #include "edt_colq16_lane.h"
@@ -38,7 +40,14 @@ struct Q16Args {
   uint32_t dmax;          // largest d with a * d^2 <= 65534
   uint32_t *count;        // tiles handed to the fp32 kernel: *count of them ...
   uint32_t *ids;          // ... their (order-permuted) tile ids
+  // The 16-bit plane between passes Y and Z (volumes whose indices fit one slab): a tile of pass Y that qualifies writes its
+  // results N over its indices (plane == codes, in place) instead of fp32 values to F and sets its bit in `map`
+  // ([x-tile][outer index / 32], zeroed by the caller); pass Z takes every row from wherever pass Y left it.
+  uint16_t *plane;
+  uint32_t *map;
+  int map_words;          // words per x-tile
 };
+enum : int { kQ16InF32 = 0, kQ16InCodes = 1, kQ16InMixed = 2 };
 
 namespace {
 
@@ -46,14 +55,16 @@ constexpr int kQ16Threads = 256;
 
 __host__ __device__ constexpr int q16_lds_words(int NB) {
   // image (NB + 2 bands of 32 rows x 16 words) + run-start plane + lo/hi plane + break masks (16 pairs x 6 words) + flags
-  return (NB + 2) * 32 * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 4;
+  return (NB * 32 + 2 * edt_q16::kPad) * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 4;
 }
 
 }  // namespace
 
 // (not in the anonymous namespace: hipFuncSetAttribute refuses the stub of a kernel with internal linkage)
-template <bool BB, bool CODES, bool SC>
-__global__ void __launch_bounds__(kQ16Threads, 3)
+// IN: where the tile comes from (fp32 values / indices of pass X / per row the 16-bit plane or fp32 values);
+// O16: the results go to the 16-bit plane (in place over the indices) instead of F; SC: ... to the slab records
+template <bool BB, int IN, bool O16, bool SC>
+__global__ void __launch_bounds__(kQ16Threads, 4)
 k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, AxisGeom g, int tiles_x, int epi, int dbg,
                   Q16Args qa, const BandScatter *__restrict__ scatter) {
   using namespace edt_q16;
@@ -62,7 +73,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   const int NB = (int)g.nbands;
   const int nb32 = NB * 32;
   uint32_t *img = q16_smem;                                // [(nb32 + 64)][16]
-  uint32_t *rsp = img + (NB + 2) * 32 * kRowWords;         // [NB][32]
+  uint32_t *rsp = img + (nb32 + 2 * kPad) * kRowWords;     // [NB][32]
   uint32_t *lohi = rsp + NB * 32;                          // [NB][32]: (lo_in + 1) | (hi_out + 1) << 16
   uint32_t *bm = lohi + NB * 32;                           // [16][6]: break bits of the pair's blocks, words 1..4 (0, 5: zero)
   uint32_t *flags = bm + 16 * 6;                           // [4]: per wave, "the tile does not qualify"
@@ -91,16 +102,16 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   const bool col_ok = 4 * cg < cols_left;
   bool bad = false;
   if (t < 64) bm[t] = 0u, bm[t + 32] = 0u;  // (96 words)
-  {
-    // +inf around the column: 64 rows x 16 words, one 16-byte store per thread
-    const int row = t < 128 ? -kPad + (t >> 2) : nb32 + ((t - 128) >> 2);
+  if (t < 8 * kPad) {
+    // +inf around the column: 2 x kPad rows x 16 words, one 16-byte store per thread
+    const int row = t < 4 * kPad ? -kPad + (t >> 2) : nb32 + ((t - 4 * kPad) >> 2);
     *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (t & 3)) = (v4u){~0u, ~0u, ~0u, ~0u};
   }
   for (int u = t; u < NB * 32; u += kQ16Threads) {
     const int band = u >> 5, col = u & 31;
     rsp[u] = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
   }
-  if constexpr (CODES) {
+  if constexpr (IN == kQ16InCodes) {
     const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
     const pk kmaxpk = pk_both(qa.kmax), ainpk = pk_both(qa.ain);
     for (int i0 = 0; i0 < nb32; i0 += 32 * 16) {
@@ -125,25 +136,47 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     }
   } else {
     const float *src = F + x0 + o * g.outer_stride + 4 * cg;
+    const uint16_t *src16 = qa.plane + x0 + o * g.outer_stride + 4 * cg;
+    const uint32_t *mapw = qa.map + xt * qa.map_words;  // (IN == kQ16InMixed: bit z = row z of this x-tile is in the plane)
+    const pk nlimpk = pk_both(qa.nlim);
     const float flim = (float)qa.nlim + 1.0f;
-    for (int i0 = 0; i0 < nb32; i0 += 32 * 8) {
-      v4f ff[8];
+    // (eight loads per thread in flight; all sixteen of a 512-row tile at once measured no faster -- cfg2 Z 0.237 vs
+    // 0.239 ms -- and cost 40-90 VGPRs)
+    constexpr int NL = 8;
+    for (int i0 = 0; i0 < nb32; i0 += 32 * NL) {
+      v4u raw[NL];
+      uint32_t in16 = 0;  // bit j: row i0 + 32 j + r_in comes from the 16-bit plane
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NL; ++j) {
         const int row = i0 + 32 * j + r_in;
-        ff[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-        if (row < n && col_ok) ff[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + (int64_t)row * st));
+        raw[j] = (v4u){0u, 0u, 0u, 0u};
+        // (the map word of rows i0 + 32 j .. + 31 is wave-uniform: a scalar load)
+        const bool p16 = IN == kQ16InMixed && row < n && ((mapw[(i0 >> 5) + j] >> r_in) & 1u) != 0u;
+        if (p16) {
+          in16 |= 1u << j;
+          if (col_ok) {
+            const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(src16 + (int64_t)row * st));
+            raw[j][0] = v[0];
+            raw[j][1] = v[1];
+          }
+        } else if (row < n && col_ok) {
+          raw[j] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src + (int64_t)row * st));
+        }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NL; ++j) {
         const int row = i0 + 32 * j + r_in;
-        if (row < nb32) {
+        if (row < nb32 && ((in16 >> j) & 1u)) {
+          // (pass Y's limit may be the larger one)
+          bad |= (pk_subs(raw[j][0], nlimpk) | pk_subs(raw[j][1], nlimpk)) != 0u;
+          *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = (v2u){raw[j][0], raw[j][1]};
+        } else if (row < nb32) {
           uint32_t u[4];
           float err = 0.0f;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             // N = F / q, exact or the tile does not qualify: F - N * q as one fma (the product is exact)
-            const float f = ff[j][c];
+            const float f = __uint_as_float(raw[j][c]);
             const float tq = fminf(f * qa.rq, flim);
             u[c] = (uint32_t)(tq + 0.5f);
             const float e = fmaf(-(float)u[c], qa.q, f);
@@ -163,11 +196,26 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   if (__ballot(bad) != 0ull && (t & 63) == 0) flags[t >> 6] = 1u;
   __syncthreads();
   if ((flags[0] | flags[1] | flags[2] | flags[3]) != 0u) {
+    if constexpr (IN == kQ16InMixed) {
+      // the fp32 kernel reads F: the rows this tile has in the 16-bit plane become fp32 values there first (exact)
+      const uint32_t *mapw = qa.map + xt * qa.map_words;
+      float *dstF = F + x0 + o * g.outer_stride + 4 * cg;
+      for (int row = r_in; row < n; row += 32) {
+        if (((mapw[row >> 5] >> (row & 31)) & 1u) != 0u && col_ok) {
+          const v2u v = *reinterpret_cast<const v2u *>(img + (row + kPad) * kRowWords + 2 * cg);
+          *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) =
+              (v4f){(float)(v[0] & 0xFFFFu) * qa.q, (float)(v[0] >> 16) * qa.q, (float)(v[1] & 0xFFFFu) * qa.q, (float)(v[1] >> 16) * qa.q};
+        }
+      }
+    }
     if (t == 0) {
       const uint32_t idx = atomicAdd(qa.count, 1u);
       qa.ids[idx] = (uint32_t)tile_id;
     }
     return;
+  }
+  if constexpr (O16) {
+    if (t == 0) atomicOr(qa.map + xt * qa.map_words + (int)(o >> 5), 1u << (o & 31));
   }
 
   // ---- phase 1: run extents across bands (one thread per column and direction), break bits per block and pair ----
@@ -230,6 +278,15 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     } else {
       dst = F + x0 + o * g.outer_stride + 2 * cp;
     }
+    if constexpr (O16) {
+      auto *ndst = (__attribute__((address_space(1))) uint32_t *)(qa.plane + x0 + o * g.outer_stride + 2 * cp);
+#pragma unroll
+      for (int j = 0; j < kB; ++j) {
+        const int row = L.p0 + j;
+        if (row < n && store_ok) ndst[((int64_t)row * st) >> 1] = best[j];  // (st % 4 == 0: the pair is a whole word)
+      }
+      continue;
+    }
     auto *gdst = (__attribute__((address_space(1))) float *)dst;
     const float q = qa.q;
     v2f out[kB];
@@ -258,38 +315,48 @@ bool column_pass_q16_supported(const AxisGeom &g) {
          !(debug_mode() & 0x8000000);
 }
 
-// list: [0 .. 63] counters (zeroed by the caller once per call), [64 ..] tile ids; `slot` picks this launch's counter
-template <bool BB, bool CODES>
-static int launch_q16_bc(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa0, int epi,
-                         hipStream_t stream, const BandScatter *scatter) {
-  Q16Args qa = qa0;
-  qa.codes = codes;
+template <bool BB, int IN, bool O16, bool SC>
+static int launch_q16_k(float *F, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa, int epi, hipStream_t stream,
+                        const BandScatter *scatter) {
   const int NB = (int)g.nbands;
-  const size_t lds = (size_t)q16_lds_words(NB) * sizeof(uint32_t);
+  // (EDT_Q16_EXTRA_LDS: experiments -- bytes of LDS asked for on top, i.e. fewer workgroups per CU)
+  static const size_t extra_lds = [] { const char *e = getenv("EDT_Q16_EXTRA_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+  const size_t lds = (size_t)q16_lds_words(NB) * sizeof(uint32_t) + extra_lds;
   const int64_t tiles_x = ceil_div(g.sx, 32);
   int64_t tiles = tiles_x * g.nouter;
   if (tiles <= 0) return EDT_OK;
   if (!(debug_mode() & 0x800)) tiles = tiles_x * (ceil_div(g.nouter, 8) * 8);
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
-  if (scatter != nullptr) {
-    static std::atomic<uint64_t> attr_done{0};
-    EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_q16<BB, CODES, true>)));
-    hipLaunchKernelGGL((k_column_pass_q16<BB, CODES, true>), dim3((unsigned)tiles), dim3(kQ16Threads), lds, stream, F, rs, g,
-                       (int)tiles_x, epi, debug_mode(), qa, scatter);
-  } else {
-    static std::atomic<uint64_t> attr_done{0};
-    EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_q16<BB, CODES, false>)));
-    hipLaunchKernelGGL((k_column_pass_q16<BB, CODES, false>), dim3((unsigned)tiles), dim3(kQ16Threads), lds, stream, F, rs, g,
-                       (int)tiles_x, epi, debug_mode(), qa, scatter);
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_q16<BB, IN, O16, SC>)));
+  hipLaunchKernelGGL((k_column_pass_q16<BB, IN, O16, SC>), dim3((unsigned)tiles), dim3(kQ16Threads), lds, stream, F, rs, g,
+                     (int)tiles_x, epi, debug_mode(), qa, scatter);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }
 
-// a: c_d = a * d^2 quanta of this pass; ain: quanta per squared index of pass X (codes != nullptr)
+template <bool BB>
+static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa, int in, bool o16, int epi,
+                        hipStream_t stream, const BandScatter *scatter) {
+  if (scatter != nullptr) {
+    if (o16 || in == kQ16InMixed) { set_error("internal: 16-bit plane with slab records"); return EDT_ERR_BAD_ARG; }
+    return in == kQ16InCodes ? launch_q16_k<BB, kQ16InCodes, false, true>(F, rs, g, qa, epi, stream, scatter)
+                             : launch_q16_k<BB, kQ16InF32, false, true>(F, rs, g, qa, epi, stream, scatter);
+  }
+  if (in == kQ16InCodes)
+    return o16 ? launch_q16_k<BB, kQ16InCodes, true, false>(F, rs, g, qa, epi, stream, nullptr)
+               : launch_q16_k<BB, kQ16InCodes, false, false>(F, rs, g, qa, epi, stream, nullptr);
+  if (o16) { set_error("internal: 16-bit plane without the index form"); return EDT_ERR_BAD_ARG; }
+  return in == kQ16InMixed ? launch_q16_k<BB, kQ16InMixed, false, false>(F, rs, g, qa, epi, stream, nullptr)
+                           : launch_q16_k<BB, kQ16InF32, false, false>(F, rs, g, qa, epi, stream, nullptr);
+}
+
+// a: c_d = a * d^2 quanta of this pass; ain: quanta per squared index of pass X (codes != nullptr).
+// plane / map != nullptr: with codes -- the results go to the 16-bit plane (= codes, in place) and the tile's bit is set in
+// map; without -- the rows are taken from the plane wherever map says so (the pass after such a pass).
 int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
                            uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
-                           const BandScatter *scatter) {
+                           const BandScatter *scatter, uint16_t *plane, uint32_t *map, int map_words) {
   Q16Args qa;
   qa.codes = codes;
   qa.q = q;
@@ -303,11 +370,13 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
   qa.kmax = kmax;
   qa.count = count;
   qa.ids = ids;
-  if (codes)
-    return bb ? launch_q16_bc<true, true>(F, codes, rs, g, qa, epi, stream, scatter)
-              : launch_q16_bc<false, true>(F, codes, rs, g, qa, epi, stream, scatter);
-  return bb ? launch_q16_bc<true, false>(F, codes, rs, g, qa, epi, stream, scatter)
-            : launch_q16_bc<false, false>(F, codes, rs, g, qa, epi, stream, scatter);
+  qa.plane = plane;
+  qa.map = map;
+  qa.map_words = map_words;
+  const int in = codes ? kQ16InCodes : (plane ? kQ16InMixed : kQ16InF32);
+  const bool o16 = codes != nullptr && plane != nullptr;
+  return bb ? launch_q16_b<true>(F, rs, g, qa, in, o16, epi, stream, scatter)
+            : launch_q16_b<false>(F, rs, g, qa, in, o16, epi, stream, scatter);
 }
 
 // the quantum of a call (edt_colq16_lane.h: quantum_of), host side

@@ -38,9 +38,12 @@ namespace edt_q16 {
 
 typedef uint32_t pk;  // two unsigned 16-bit values: low half = the even column of the pair, high half = the odd one
 
-constexpr int kPad = 32;          // rows of +inf (0xFFFF) before row 0 and after the last band of the image
+#ifndef EDT_Q16_K
+#define EDT_Q16_K 16  // (16: the image of a 512-row axis with its planes is 39.3 KiB, four workgroups per CU; 32: 41.4 KiB, three)
+#endif
+constexpr int kK = EDT_Q16_K;     // register-resident radius of the window (compile-time steps); further steps: rolled loop
+constexpr int kPad = kK;          // rows of +inf (0xFFFF) before row 0 and after the last band of the image
 constexpr int kRowWords = 16;     // 32-bit words per image row (32 columns x 16 bit)
-constexpr int kK = 32;            // register-resident radius of the window
 constexpr int kB = 8;             // rows per block
 constexpr uint32_t kInf = 0xFFFFu;
 constexpr uint32_t kFar = 0x4000u;  // "no border on this side" distance (stays below 2^15 after n <= 2048 increments)

@@ -38,8 +38,9 @@ void set_error(const std::string &msg);
 //   0x2000000     inexact voxel sizes: fp64 candidates even where fp32 fma candidates are exact
 //   0x4000000     rows of 1025..2048 voxels: the workgroup-phased kernel of pass X, not the two-wave form
 //   0x8000000     no 16-bit integer column kernel (edt_colq16.hip): every tile on the fp32 kernels
+//   0x10000000    integer column kernels: fp32 values between passes Y and Z, not the 16-bit plane
 constexpr int kDiagFormBits = 16 | 32 | 64 | 256 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |
-                              0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000 | 0x2000000 | 0x4000000 | 0x8000000;
+                              0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000 | 0x2000000 | 0x4000000 | 0x8000000 | 0x10000000;
 #ifdef EDT_DIAG
 #define EDT_DIAG_BITS(dbg, bits) ((dbg) & (bits))
 #else

@@ -144,9 +144,13 @@ bool q16_quantum(const float *w, int naxes, float *q, uint32_t *a);
 bool column_pass_q16_supported(const AxisGeom &g);
 // codes != nullptr: pass X in index form (N = k^2 * ain), F is only written; else F is read (N = F / q, verified) and
 // written in place.  a: c_d = a * d^2 quanta.  Tiles that do not qualify are appended to (count, ids) for the fp32 kernel.
+// plane / map (volumes whose indices fit one slab): with codes, the results stay 16-bit -- written over the indices
+// (plane == codes), the tile's bit set in map [x-tile][map_words]; without codes, every row is read from the plane where
+// map says so and from F elsewhere (the pass after such a pass).
 int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
                            uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
-                           const BandScatter *scatter = nullptr);
+                           const BandScatter *scatter = nullptr, uint16_t *plane = nullptr, uint32_t *map = nullptr,
+                           int map_words = 0);
 }  // namespace edt_amd
 
 namespace edt_amd {

@@ -23,7 +23,8 @@ namespace {
 // one tile: columns x0 .. x0+31.  Returns false if the tile does not qualify (nothing is written then).
 template <bool BB>
 bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, float *out, int64_t sx, int n, int64_t x0,
-               float q, uint32_t a, uint32_t ain, int epi, long *steps_taken) {
+               float q, uint32_t a, uint32_t ain, int epi, long *steps_taken, const uint16_t *plane_in = nullptr,
+               const uint8_t *row_in_plane = nullptr, uint16_t *plane_out = nullptr) {
   const int NB = (n + 31) / 32, nb32 = NB * 32;
   const int cols_left = (int)(sx - x0);
   const uint32_t dmax = q16_dmax(a), nlim = a * dmax * dmax;
@@ -42,7 +43,10 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
       uint32_t v = 0;
       if (row >= n) v = 0xFFFFu;
       else if (col < cols_left) {
-        if (codes) {
+        if (plane_in && row_in_plane[row]) {  // (mixed input: this row of the tile is in the 16-bit plane)
+          v = plane_in[(int64_t)row * sx + x0 + col];
+          if (v > nlim) bad = true;
+        } else if (codes) {
           const uint32_t k = codes[(int64_t)row * sx + x0 + col];
           if (k > kmax) bad = true;
           v = (uint32_t)(uint16_t)((uint16_t)(k * k) * (uint16_t)ain);  // (wraps like the packed multiply; unused if bad)
@@ -61,7 +65,15 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
   for (int band = 0; band < NB; ++band)
     for (int col = 0; col < 32; ++col)
       rsp[(size_t)band * 32 + col] = col < cols_left ? rsbits[(size_t)band * sx + x0 + col] : 0u;
-  if (bad) return false;
+  if (bad) {
+    // mixed input: the rows the tile has in the plane become fp32 values (the fp32 kernel reads F)
+    if (plane_in)
+      for (int row = 0; row < n; ++row)
+        if (row_in_plane[row])
+          for (int col = 0; col < 32 && col < cols_left; ++col)
+            out[(int64_t)row * sx + x0 + col] = (float)plane_in[(int64_t)row * sx + x0 + col] * q;
+    return false;
+  }
   // ---- scans + breaks (phase 1) ----
   uint16_t *lohi16 = reinterpret_cast<uint16_t *>(lohi.data());
   for (int t = 0; t < 32; ++t) {
@@ -111,6 +123,7 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
         for (int h = 0; h < 2; ++h) {
           const int col = 2 * cp + h;
           if (col >= cols_left) continue;
+          if (plane_out) { plane_out[(int64_t)row * sx + x0 + col] = (uint16_t)((best[j] >> (16 * h)) & 0xFFFFu); continue; }
           float v = (float)((best[j] >> (16 * h)) & 0xFFFFu) * q;
           if (epi & 2) v = sqrtf(v);
           out[(int64_t)row * sx + x0 + col] = v;
@@ -138,6 +151,29 @@ extern "C" int q16_emul_column_pass(const uint32_t *labels, const float *Fin, co
   for (int64_t x0 = 0, i = 0; x0 < sx; x0 += 32, ++i) {
     const bool r = bb ? tile_pass<true>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr)
                       : tile_pass<false>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr);
+    tile_ok[i] = r ? 1 : 0;
+    ok += r ? 1 : 0;
+  }
+  return ok;
+}
+
+// the 16-bit plane: plane_in + row_in_plane[n] (rows of every tile that come from the plane; Fin serves the others),
+// plane_out (the results stay 16-bit: written there instead of out)
+extern "C" int q16_emul_column_pass_plane(const uint32_t *labels, const float *Fin, const uint16_t *codes, float *out, int64_t sx,
+                                          int64_t n, float q, uint32_t a, uint32_t ain, int bb, int epi, uint8_t *tile_ok,
+                                          const uint16_t *plane_in, const uint8_t *row_in_plane, uint16_t *plane_out) {
+  const int NB = (int)((n + 31) / 32);
+  std::vector<uint32_t> rs((size_t)NB * sx, 0);
+  for (int64_t x = 0; x < sx; ++x)
+    for (int64_t y = 0; y < n; ++y) {
+      const uint32_t lab = labels[y * sx + x];
+      const bool start = (y == 0) || lab != labels[(y - 1) * sx + x];
+      if (start) rs[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
+    }
+  int ok = 0;
+  for (int64_t x0 = 0, i = 0; x0 < sx; x0 += 32, ++i) {
+    const bool r = bb ? tile_pass<true>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr, plane_in, row_in_plane, plane_out)
+                      : tile_pass<false>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr, plane_in, row_in_plane, plane_out);
     tile_ok[i] = r ? 1 : 0;
     ok += r ? 1 : 0;
   }

@@ -138,6 +138,51 @@ def test_q16_refuses_values_off_the_quantum_grid(q16, oracle_port):
     assert list(tiles) == [True, False]
 
 
+def test_q16_plane_between_passes(q16, oracle_port):
+    """the results of a pass stay 16-bit (plane out), the next pass takes every row from the plane or from fp32 values
+    (mixed input); a refused tile of the mixed form leaves its plane rows as fp32 values for the fp32 kernel"""
+    rng = np.random.default_rng(11)
+    for (n, sx, kind) in ((512, 64, "cells"), (300, 40, "blocky"), (130, 96, "membrane")):
+        lab = make_labels(n, sx, kind, rng)
+        for (wx, wy) in ((1.0, 1.0), (6.0, 30.0)):
+            ok, q, a = quantum(q16, (wx, wy))
+            f1, codes = x_pass(oracle_port, lab, wx, True)
+            want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), True).reshape(n, sx)
+            labc = np.ascontiguousarray(lab, dtype=np.uint32)
+            tiles = np.zeros((sx + 31) // 32, dtype=np.uint8)
+            # plane out: N = result / q as 16-bit integers
+            plane = np.full((n, sx), 0xABCD, dtype=np.uint16)
+            cc = np.ascontiguousarray(codes)
+            q16.q16_emul_column_pass_plane(labc.ctypes.data_as(ctypes.c_void_p), None, cc.ctypes.data_as(ctypes.c_void_p), None,
+                                           ctypes.c_int64(sx), ctypes.c_int64(n), ctypes.c_float(q), ctypes.c_uint32(a[1]),
+                                           ctypes.c_uint32(a[0]), 1, 0, tiles.ctypes.data_as(ctypes.c_void_p), None, None,
+                                           plane.ctypes.data_as(ctypes.c_void_p))
+            assert tiles.all()
+            assert np.array_equal(plane.astype(np.float32) * np.float32(q), want)
+            # mixed input: a random half of the rows from a plane holding f1 / q, the others as fp32 values
+            rows = (rng.random(n) < 0.5).astype(np.uint8)
+            pin = np.where(rows[:, None] == 1, np.rint(f1 / np.float32(q)), 0xEEEE).astype(np.uint16)
+            fin = np.where(rows[:, None] == 1, np.float32(-7.0), f1).astype(np.float32)
+            out = np.full((n, sx), -1.0, dtype=np.float32)
+            q16.q16_emul_column_pass_plane(labc.ctypes.data_as(ctypes.c_void_p), fin.ctypes.data_as(ctypes.c_void_p), None,
+                                           out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(sx), ctypes.c_int64(n),
+                                           ctypes.c_float(q), ctypes.c_uint32(a[1]), ctypes.c_uint32(a[0]), 1, 0,
+                                           tiles.ctypes.data_as(ctypes.c_void_p), pin.ctypes.data_as(ctypes.c_void_p),
+                                           rows.ctypes.data_as(ctypes.c_void_p), None)
+            assert tiles.all() and np.array_equal(out, want), (n, sx, kind, wx, wy)
+            # a value off the grid in an fp32 row: the tile is refused, its plane rows arrive as fp32 values
+            r0 = int(np.flatnonzero(rows == 0)[0])
+            fin[r0, 3] = np.float32(2.5) * np.float32(q)
+            out[:] = -1.0
+            q16.q16_emul_column_pass_plane(labc.ctypes.data_as(ctypes.c_void_p), fin.ctypes.data_as(ctypes.c_void_p), None,
+                                           out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(sx), ctypes.c_int64(n),
+                                           ctypes.c_float(q), ctypes.c_uint32(a[1]), ctypes.c_uint32(a[0]), 1, 0,
+                                           tiles.ctypes.data_as(ctypes.c_void_p), pin.ctypes.data_as(ctypes.c_void_p),
+                                           rows.ctypes.data_as(ctypes.c_void_p), None)
+            assert not tiles[0]
+            assert np.array_equal(out[rows == 1, :32], f1[rows == 1, :32]) and (out[rows == 0, :32] == -1.0).all()
+
+
 def test_quantum_of_voxel_sizes(q16):
     assert quantum(q16, (1.0, 1.0, 1.0)) == (True, 1.0, [1, 1, 1])
     assert quantum(q16, (6.0, 6.0, 30.0)) == (True, 36.0, [1, 1, 25])

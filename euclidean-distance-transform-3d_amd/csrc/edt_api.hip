@@ -194,8 +194,9 @@ static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, v
     if (p.xy_slab > 0) p.codes = c.take<uint16_t>((size_t)(p.xy_slab * sx * sy));
   }
   if (ndim >= 2 && !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic()) {
-    const int64_t ty = ceil_div(sx, 32) * (ceil_div(p.xy_slab > 0 ? p.xy_slab : sz, 8) * 8);
-    const int64_t tz = ceil_div(sx, 32) * (ceil_div(sy, 8) * 8);
+    // (ids in the fp32 kernel's geometry: 16-column tiles for axes of more than 512 rows)
+    const int64_t ty = ceil_div(sx, 16) * (ceil_div(p.xy_slab > 0 ? p.xy_slab : sz, 8) * 8);
+    const int64_t tz = ceil_div(sx, 16) * (ceil_div(sy, 8) * 8);
     p.q16_map_words = (int)ceil_div(sz, 32);
     p.q16_counts = c.take<uint32_t>(kQ16Slots + (size_t)(ceil_div(sx, 32) * p.q16_map_words));  // (zeroed together)
     p.q16_map = p.q16_counts ? p.q16_counts + kQ16Slots : nullptr;

@@ -39,7 +39,8 @@ struct Q16Args {
   uint32_t nlim;          // largest N a tile may hold: a * dmax^2
   uint32_t dmax;          // largest d with a * d^2 <= 65534
   uint32_t *count;        // tiles handed to the fp32 kernel: *count of them ...
-  uint32_t *ids;          // ... their (order-permuted) tile ids
+  uint32_t *ids;          // ... their tile ids (outer index * x-tiles + x-tile) in the fp32 kernel's geometry:
+  int list_cols;          // its tiles are 32 columns wide, or 16 (axes of more than 512 rows: two ids per refused tile)
   // The 16-bit plane between passes Y and Z (volumes whose indices fit one slab): a tile of pass Y that qualifies writes its
   // results N over its indices (plane == codes, in place) instead of fp32 values to F and sets its bit in `map`
   // ([x-tile][outer index / 32], zeroed by the caller); pass Z takes every row from wherever pass Y left it.
@@ -209,8 +210,16 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       }
     }
     if (t == 0) {
-      const uint32_t idx = atomicAdd(qa.count, 1u);
-      qa.ids[idx] = (uint32_t)tile_id;
+      if (qa.list_cols == 32) {
+        const uint32_t idx = atomicAdd(qa.count, 1u);
+        qa.ids[idx] = (uint32_t)tile_id;
+      } else {
+        const uint32_t tx16 = (uint32_t)((g.sx + 15) >> 4), first = oq * tx16 + 2u * (uint32_t)xt;
+        const uint32_t k = 2u * (uint32_t)xt + 1u < tx16 ? 2u : 1u;
+        const uint32_t idx = atomicAdd(qa.count, k);
+        qa.ids[idx] = first;
+        if (k == 2u) qa.ids[idx + 1] = first + 1u;
+      }
     }
     return;
   }
@@ -370,6 +379,7 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
   qa.kmax = kmax;
   qa.count = count;
   qa.ids = ids;
+  qa.list_cols = g.nbands > 16 ? 16 : 32;  // (edt_colwave_lane.h: TileGeom -- 16-column tiles for the 1- and 2-column waves)
   qa.plane = plane;
   qa.map = map;
   qa.map_words = map_words;

@@ -51,10 +51,10 @@ def test_argument_validation_needs_no_gpu(lib):
     v = 64 * 64 * 64
     assert 4 * v // 8 + 2 * v <= lib.edt_hip_workspace_bytes(_lib.U32, 3, 64, 64, 64) <= 4 * v // 8 + 2 * v + 4096
     # (+ the hand-over list of the 16-bit integer column kernel: 4 bytes per tile)
-    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 1024, 1024, 1024) <= (1 << 29) + (1 << 28) + (1 << 18)   # 0.75 GiB for 1024^3
-    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 2048, 2048, 512) <= (1 << 30) + (1 << 28) + (1 << 20)
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 1024, 1024, 1024) <= (1 << 29) + (1 << 28) + (1 << 19)   # 0.75 GiB for 1024^3
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 2048, 2048, 512) <= (1 << 30) + (1 << 28) + (1 << 21)
     # ... which a caller can decline (EDT_FLAG_SMALL_WORKSPACE: fp32 between passes X and Y): 0.5 GiB for 1024^3
-    assert lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 1024, 1024, 1024, _lib.FLAG_SMALL_WORKSPACE) <= (1 << 29) + (1 << 18)
+    assert lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 1024, 1024, 1024, _lib.FLAG_SMALL_WORKSPACE) <= (1 << 29) + (1 << 19)
     assert lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 64, 64, 64, _lib.FLAG_SMALL_WORKSPACE) <= 4 * v // 8 + 8192
     # (rows that are not whole 8-byte granules of indices keep the fp32 form of pass 1: bit planes only)
     assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 63, 64, 64) <= 4 * 64 * 64 * 64 // 8 + 8192

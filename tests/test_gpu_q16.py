@@ -1,0 +1,79 @@
+"""GPU tier: the 16-bit integer column kernel (csrc/edt_colq16.hip) and its hand-over to the fp32 kernel.
+
+Every case is compared bit for bit with the oracle, and with this library's own fp32 kernels (debug bit 0x8000000: no
+integer kernel; 0x10000000: integer kernels with fp32 values between passes Y and Z instead of the 16-bit plane).  The
+shapes are chosen so that tiles are refused for every reason there is: rows without any boundary (black_border off), objects
+deeper than 255 voxels (values beyond 16 bits), axes of more than 512 rows (the fp32 kernel then works on 16-column tiles:
+two list entries per refused tile), volumes of several index slabs (no plane), and partial tiles."""
+import numpy as np
+import pytest
+
+from synth import blocky_labels, voronoi_labels
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(0, "q16 + plane"), (0x10000000, "q16, fp32 between Y and Z"), (0x8000000, "fp32 kernels")]
+
+
+def run_modes(edt_gpu, lab, an, bb):
+    from edt import _lib
+    lib = _lib.load()
+    outs = []
+    try:
+        for mode, _ in MODES:
+            lib.edt_hip_set_debug_mode(mode)
+            outs.append(edt_gpu.edtsq(lab, anisotropy=an, black_border=bb))
+    finally:
+        lib.edt_hip_set_debug_mode(0)
+    return outs
+
+
+@pytest.mark.parametrize("shape", [(160, 300, 140), (40, 1000, 36), (72, 136, 1024), (512, 512, 20), (260, 200, 130),
+                                   (100, 640, 520), (36, 128, 128)])
+def test_q16_against_oracle_and_fp32_kernels(edt_gpu, oracle_port, shape):
+    rng = np.random.default_rng(sum(shape))
+    labs = [voronoi_labels(shape, nseeds=30, seed=sum(shape), upsample=4, membrane=0.03),
+            blocky_labels(shape, nlabels=3, zero_frac=0.3, block=int(rng.integers(20, 90)), rng=rng).astype(np.uint16)]
+    for lab in labs:
+        lab = np.asfortranarray(lab)
+        for an, bb in (((1, 1, 1), False), ((6, 6, 30), True), ((1.0, 1.5, 0.5), False), ((4, 4, 40), True)):
+            want = oracle_port.edtsq(lab, an, bb)
+            for got, (_, name) in zip(run_modes(edt_gpu, lab, an, bb), MODES):
+                assert np.array_equal(got, want), (shape, an, bb, name)
+            assert np.array_equal(edt_gpu.edt(lab, anisotropy=an, black_border=bb), np.sqrt(want)), (shape, an, bb, "sqrt")
+
+
+def test_q16_deep_objects_leave_the_16_bit_range(edt_gpu, oracle_port):
+    """a box 600 voxels deep: the middle of its rows holds x-distances of up to 300 voxels -- more than 16 bits of squares;
+    those tiles go to the fp32 kernel, their neighbours stay on the integer kernel (closed form: the box)"""
+    from synth import box_edtsq_closed_form
+    lab = np.ones((600, 300, 280), dtype=np.uint8, order="F")
+    for an in ((1.0, 1.0, 1.0), (6.0, 6.0, 30.0)):
+        want = box_edtsq_closed_form(lab.shape, an)
+        for got, (_, name) in zip(run_modes(edt_gpu, lab, an, True), MODES):
+            assert np.array_equal(got, want), (an, name)
+    # the same object inside a background: borders from the labels, black_border off
+    lab2 = np.zeros((640, 260, 200), dtype=np.uint8, order="F")
+    lab2[20:620, 10:250, 8:192] = 1
+    want = oracle_port.edtsq(lab2, (1, 1, 1), False)
+    for got, (_, name) in zip(run_modes(edt_gpu, lab2, (1, 1, 1), False), MODES):
+        assert np.array_equal(got, want), name
+
+
+def test_q16_two_dimensional_and_stacks(edt_gpu, oracle_port):
+    rng = np.random.default_rng(3)
+    for shape in ((300, 260), (1000, 200), (128, 1024)):
+        img = np.asfortranarray(blocky_labels(shape, nlabels=6, zero_frac=0.1, block=17, rng=rng).astype(np.uint32))
+        for an, bb in (((1, 1), True), ((2, 3), False), ((6, 30), True)):
+            want = oracle_port.edtsq(img, an, bb)
+            for got, (_, name) in zip(run_modes(edt_gpu, img, an, bb), MODES):
+                assert np.array_equal(got, want), (shape, an, bb, name)
+            assert np.array_equal(edt_gpu.edt(img, anisotropy=an, black_border=bb), np.sqrt(want))
+
+
+def test_q16_binary_route_and_bool(edt_gpu, oracle_port):
+    rng = np.random.default_rng(9)
+    lab = np.asfortranarray((rng.random((200, 180, 150)) < 0.97))
+    want = oracle_port.edtsq(lab, (1, 1, 2), True)
+    for got, (_, name) in zip(run_modes(edt_gpu, lab, (1, 1, 2), True), MODES):
+        assert np.array_equal(got, want), name

@@ -30,6 +30,20 @@ except Exception as e:
     print(c, "ERR", e, open(f"gpurun_out/bench_{c}.err").read()[-600:])
 PY
       done ;;
+    benchsz)  # benchsz <size> <cfg>...: the same at another edge length (cfg4 at 1024)
+      local sz=$1; shift
+      for c in "$@"; do
+        python bench.py --steps 10 --warmup 2 --size $sz --no-cpu-baseline --no-secondary --config $c > gpurun_out/bench_${c}_$sz.json 2> gpurun_out/bench_${c}_$sz.err
+        python - $c $sz <<'PY'
+import json, sys
+c, sz = sys.argv[1], sys.argv[2]
+try:
+    d = json.load(open(f"gpurun_out/bench_{c}_{sz}.json"))
+    print(c, sz, d["ms_per_step"], d["roofline"]["kernel_ms"], "frac32B", d["roofline"]["whole_job_frac"], d["config"]["output_verified"])
+except Exception as e:
+    print(c, sz, "ERR", e, open(f"gpurun_out/bench_{c}_{sz}.err").read()[-600:])
+PY
+      done ;;
     prof)
       rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$1_$2 -o p -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --config $2 > gpurun_out/prof_$1_$2.log 2>&1
       echo "prof $1 $2 rc=$?"

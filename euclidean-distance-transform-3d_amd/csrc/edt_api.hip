@@ -786,6 +786,7 @@ struct RecordPlan {
   uint32_t *nz_y = nullptr, *ys_y = nullptr, *zs_y = nullptr;  // y-packed planes of the slab
   uint32_t *nz_z = nullptr, *rs_z = nullptr;               // z-packed planes (Z phase)
   BandScatter *table = nullptr;
+  uint32_t *q16_counts = nullptr, *q16_ids = nullptr;      // hand-over list of the integer column kernel (one phase per call)
   size_t bytes = 0;
 };
 
@@ -802,6 +803,8 @@ static RecordPlan make_record_plan(int64_t sx, int64_t sy, int64_t sz, void *ws)
   p.nz_z = c.take<uint32_t>(wz);
   p.rs_z = c.take<uint32_t>(wz);
   p.table = c.take<BandScatter>(1);
+  p.q16_counts = c.take<uint32_t>(4);
+  p.q16_ids = c.take<uint32_t>((size_t)(ceil_div(sx, 16) * (ceil_div(std::max(sy, sz), 8) * 8)));
   p.bytes = align_up(c.off, 256) + 256;
   return p;
 }
@@ -1180,9 +1183,24 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
     if (rc != EDT_OK) return rc;
   }
   ScopedPass t("y_pass", stream);
+  // the integer column kernel where wx and wy share a quantum (edt_colq16.hip), the tiles it refuses to the fp32 kernel
+  TileList list;
+  {
+    const float w2[2] = {wx, wy};
+    float q = 1.0f;
+    uint32_t a[3];
+    if (!(g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x400000)) && q16_quantum(w2, 2, &q, a) &&
+        column_pass_q16_supported(gy) && column_pass_wave_supported(gy) && aligned) {
+      EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, 4 * sizeof(uint32_t), stream));
+      rc = launch_column_pass_q16(p.F, codes, p.ys_y, gy, q, a[1], a[0], bb, 0, p.q16_counts, p.q16_ids, stream, p.table);
+      if (rc != EDT_OK) return rc;
+      list.count = p.q16_counts;
+      list.ids = p.q16_ids;
+    }
+  }
   if (index_form)
-    return launch_column_pass_wave_codes(p.F, codes, p.nz_y, p.ys_y, gy, wy, bb, 0, wx, bb ? 0 : 1, stream, p.table);
-  return launch_column_pass_wave(p.F, p.nz_y, p.ys_y, gy, wy, bb, 0, stream, p.table);
+    return launch_column_pass_wave_codes(p.F, codes, p.nz_y, p.ys_y, gy, wy, bb, 0, wx, bb ? 0 : 1, stream, p.table, list);
+  return launch_column_pass_wave(p.F, p.nz_y, p.ys_y, gy, wy, bb, 0, stream, p.table, ColumnOut(), list);
 }
 
 int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz,
@@ -1191,9 +1209,25 @@ int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_loca
                                            stream_);
 }
 
+static int shard_z_records(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz, float field_floor,
+                           const float *w3, int flags, void *d_workspace, size_t workspace_bytes, void *stream_);
+
 int edt_hip_shard_z_records_device_ex(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz,
                                       float field_floor, int flags, void *d_workspace, size_t workspace_bytes,
                                       void *stream_) {
+  return shard_z_records(d_records, sx, sy_local, sz, wz, field_floor, nullptr, flags, d_workspace, workspace_bytes, stream_);
+}
+
+int edt_hip_shard_z_records_device_w(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wx, float wy,
+                                     float wz, int flags, void *d_workspace, size_t workspace_bytes, void *stream_) {
+  const float w3[3] = {wx, wy, wz};
+  return shard_z_records(d_records, sx, sy_local, sz, wz, edt_hip_field_floor(wx, wy), w3, flags, d_workspace,
+                         workspace_bytes, stream_);
+}
+
+// w3 != nullptr: the caller named all three voxel sizes -- the integer column kernel where they share a quantum
+static int shard_z_records(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz, float field_floor,
+                           const float *w3, int flags, void *d_workspace, size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
   if (rc != EDT_OK) return rc;
@@ -1222,7 +1256,20 @@ int edt_hip_shard_z_records_device_ex(float *d_records, int64_t sx, int64_t sy_l
   gz.nbands = ceil_div(sz, kBandRows);
   gz.fmin = field_floor > 0.0f ? field_floor : 0.0f;
   ScopedPass t("z_pass", stream);
-  return launch_column_pass_wave(d_records, p.nz_z, p.rs_z, gz, wz, bb, epi, stream);
+  TileList list;
+  if (w3 != nullptr) {
+    float q = 1.0f;
+    uint32_t a[3];
+    if (!(g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x400000)) && q16_quantum(w3, 3, &q, a) &&
+        column_pass_q16_supported(gz) && column_pass_wave_supported(gz) && (reinterpret_cast<uintptr_t>(d_records) % 16) == 0) {
+      EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, 4 * sizeof(uint32_t), stream));
+      rc = launch_column_pass_q16(d_records, nullptr, p.rs_z, gz, q, a[2], a[0], bb, epi, p.q16_counts, p.q16_ids, stream);
+      if (rc != EDT_OK) return rc;
+      list.count = p.q16_counts;
+      list.ids = p.q16_ids;
+    }
+  }
+  return launch_column_pass_wave(d_records, p.nz_z, p.rs_z, gz, wz, bb, epi, stream, nullptr, ColumnOut(), list);
 }
 
 int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, int64_t count,

@@ -52,11 +52,9 @@ enum : int { kQ16InF32 = 0, kQ16InCodes = 1, kQ16InMixed = 2 };
 
 namespace {
 
-constexpr int kQ16Threads = 256;
-
 __host__ __device__ constexpr int q16_lds_words(int NB) {
   // image (NB + 2 bands of 32 rows x 16 words) + run-start plane + lo/hi plane + break masks (16 pairs x 6 words) + flags
-  return (NB * 32 + 2 * edt_q16::kPad) * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 4;
+  return (NB * 32 + 2 * edt_q16::kPad) * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 8;
 }
 
 }  // namespace
@@ -64,8 +62,10 @@ __host__ __device__ constexpr int q16_lds_words(int NB) {
 // (not in the anonymous namespace: hipFuncSetAttribute refuses the stub of a kernel with internal linkage)
 // IN: where the tile comes from (fp32 values / indices of pass X / per row the 16-bit plane or fp32 values);
 // O16: the results go to the 16-bit plane (in place over the indices) instead of F; SC: ... to the slab records
-template <bool BB, int IN, bool O16, bool SC>
-__global__ void __launch_bounds__(kQ16Threads, 4)
+// T: threads of the workgroup -- 256 (four waves) up to 512 rows, 512 beyond (a 1024-row image leaves room for two
+// workgroups per CU: eight waves each keep the SIMDs as busy as the four workgroups of four waves of the shorter axes)
+template <bool BB, int IN, bool O16, bool SC, int T>
+__global__ void __launch_bounds__(T, 4)
 k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, AxisGeom g, int tiles_x, int epi, int dbg,
                   Q16Args qa, const BandScatter *__restrict__ scatter) {
   using namespace edt_q16;
@@ -77,7 +77,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   uint32_t *rsp = img + (nb32 + 2 * kPad) * kRowWords;     // [NB][32]
   uint32_t *lohi = rsp + NB * 32;                          // [NB][32]: (lo_in + 1) | (hi_out + 1) << 16
   uint32_t *bm = lohi + NB * 32;                           // [16][6]: break bits of the pair's blocks, words 1..4 (0, 5: zero)
-  uint32_t *flags = bm + 16 * 6;                           // [4]: per wave, "the tile does not qualify"
+  uint32_t *flags = bm + 16 * 6;                           // [T / 64]: per wave, "the tile does not qualify"
   const int t = (int)threadIdx.x;
 
   // ---- tile -> (x-tile, outer index): the XCD-aware order of edt_colwave_kernel.h ----
@@ -99,7 +99,8 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   typedef uint32_t v2u __attribute__((ext_vector_type(2)));
   typedef uint32_t v4u __attribute__((ext_vector_type(4)));
   typedef float v4f __attribute__((ext_vector_type(4)));
-  const int r_in = t >> 3, cg = t & 7;  // 32 rows per sweep of the workgroup, 8 threads x 4 columns per row
+  constexpr int RPS = T / 8;            // rows per sweep of the workgroup: 8 threads x 4 columns per row
+  const int r_in = t >> 3, cg = t & 7;
   const bool col_ok = 4 * cg < cols_left;
   bool bad = false;
   if (t < 64) bm[t] = 0u, bm[t + 32] = 0u;  // (96 words)
@@ -108,24 +109,24 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     const int row = t < 4 * kPad ? -kPad + (t >> 2) : nb32 + ((t - 4 * kPad) >> 2);
     *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (t & 3)) = (v4u){~0u, ~0u, ~0u, ~0u};
   }
-  for (int u = t; u < NB * 32; u += kQ16Threads) {
+  for (int u = t; u < NB * 32; u += T) {
     const int band = u >> 5, col = u & 31;
     rsp[u] = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
   }
   if constexpr (IN == kQ16InCodes) {
     const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
     const pk kmaxpk = pk_both(qa.kmax), ainpk = pk_both(qa.ain);
-    for (int i0 = 0; i0 < nb32; i0 += 32 * 16) {
+    for (int i0 = 0; i0 < nb32; i0 += RPS * 16) {
       v2u kk[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int row = i0 + 32 * j + r_in;
+        const int row = i0 + RPS * j + r_in;
         kk[j] = (v2u){0u, 0u};
         if (row < n && col_ok) kk[j] = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(src + (int64_t)row * st));
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int row = i0 + 32 * j + r_in;
+        const int row = i0 + RPS * j + r_in;
         if (row < nb32) {
           // k > kmax (also the "no boundary" index 0xFFFF): the tile does not qualify (k^2 may have wrapped: never used)
           bad |= (pk_subs(kk[j][0], kmaxpk) | pk_subs(kk[j][1], kmaxpk)) != 0u;
@@ -144,15 +145,21 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     // (eight loads per thread in flight; all sixteen of a 512-row tile at once measured no faster -- cfg2 Z 0.237 vs
     // 0.239 ms -- and cost 40-90 VGPRs)
     constexpr int NL = 8;
-    for (int i0 = 0; i0 < nb32; i0 += 32 * NL) {
+    for (int i0 = 0; i0 < nb32; i0 += RPS * NL) {
       v4u raw[NL];
       uint32_t in16 = 0;  // bit j: row i0 + 32 j + r_in comes from the 16-bit plane
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        const int row = i0 + 32 * j + r_in;
+        const int row = i0 + RPS * j + r_in;
         raw[j] = (v4u){0u, 0u, 0u, 0u};
-        // (the map word of rows i0 + 32 j .. + 31 is wave-uniform: a scalar load)
-        const bool p16 = IN == kQ16InMixed && row < n && ((mapw[(i0 >> 5) + j] >> r_in) & 1u) != 0u;
+        // (a wave covers 8 consecutive rows: the map word is wave-uniform -- a scalar load, not a vector load the fill
+        // would have to wait for: cfg3's Z pass 0.276 -> 0.233 ms)
+        bool p16 = false;
+        if constexpr (IN == kQ16InMixed) {
+          const int mrow = row < n ? row : 0;
+          const uint32_t mw = mapw[__builtin_amdgcn_readfirstlane(mrow >> 5)];
+          p16 = row < n && ((mw >> (row & 31)) & 1u) != 0u;
+        }
         if (p16) {
           in16 |= 1u << j;
           if (col_ok) {
@@ -166,7 +173,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       }
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        const int row = i0 + 32 * j + r_in;
+        const int row = i0 + RPS * j + r_in;
         if (row < nb32 && ((in16 >> j) & 1u)) {
           // (pass Y's limit may be the larger one)
           bad |= (pk_subs(raw[j][0], nlimpk) | pk_subs(raw[j][1], nlimpk)) != 0u;
@@ -196,12 +203,15 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   if ((t & 63) == 0) flags[t >> 6] = 0u;
   if (__ballot(bad) != 0ull && (t & 63) == 0) flags[t >> 6] = 1u;
   __syncthreads();
-  if ((flags[0] | flags[1] | flags[2] | flags[3]) != 0u) {
+  uint32_t refused = 0;
+#pragma unroll
+  for (int i = 0; i < T / 64; ++i) refused |= flags[i];
+  if (refused != 0u) {
     if constexpr (IN == kQ16InMixed) {
       // the fp32 kernel reads F: the rows this tile has in the 16-bit plane become fp32 values there first (exact)
       const uint32_t *mapw = qa.map + xt * qa.map_words;
       float *dstF = F + x0 + o * g.outer_stride + 4 * cg;
-      for (int row = r_in; row < n; row += 32) {
+      for (int row = r_in; row < n; row += RPS) {
         if (((mapw[row >> 5] >> (row & 31)) & 1u) != 0u && col_ok) {
           const v2u v = *reinterpret_cast<const v2u *>(img + (row + kPad) * kRowWords + 2 * cg);
           *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) =
@@ -233,7 +243,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     if (t < 32) scan_runs_lo(rsp + t, 32, NB, lohi16 + 2 * t, 64);
     else if (t < 64) scan_runs_hi(rsp + (t - 32), 32, NB, n, lohi16 + 2 * (t - 32) + 1, 64);
     const pk apk = pk_both(qa.a);
-    for (int u = t; u < 16 * NB; u += kQ16Threads) {
+    for (int u = t; u < 16 * NB; u += T) {
       const int cp = u & 15, band = u >> 4;
       const int valid = n - 32 * band;
       const uint32_t bits = band_breaks(img + (32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32);
@@ -249,7 +259,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   const bool store_ok = 2 * cp < cols_left;
   typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll 1
-  for (int s = wave; s < NB; s += kQ16Threads / 64) {
+  for (int s = wave; s < NB; s += T / 64) {
     Block L;
     L.img = img;
     L.cp = cp;
@@ -324,9 +334,9 @@ bool column_pass_q16_supported(const AxisGeom &g) {
          !(debug_mode() & 0x8000000);
 }
 
-template <bool BB, int IN, bool O16, bool SC>
-static int launch_q16_k(float *F, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa, int epi, hipStream_t stream,
-                        const BandScatter *scatter) {
+template <bool BB, int IN, bool O16, bool SC, int T>
+static int launch_q16_kt(float *F, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa, int epi, hipStream_t stream,
+                         const BandScatter *scatter) {
   const int NB = (int)g.nbands;
   // (EDT_Q16_EXTRA_LDS: experiments -- bytes of LDS asked for on top, i.e. fewer workgroups per CU)
   static const size_t extra_lds = [] { const char *e = getenv("EDT_Q16_EXTRA_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
@@ -337,11 +347,18 @@ static int launch_q16_k(float *F, const uint32_t *rs, const AxisGeom &g, const Q
   if (!(debug_mode() & 0x800)) tiles = tiles_x * (ceil_div(g.nouter, 8) * 8);
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
   static std::atomic<uint64_t> attr_done{0};
-  EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_q16<BB, IN, O16, SC>)));
-  hipLaunchKernelGGL((k_column_pass_q16<BB, IN, O16, SC>), dim3((unsigned)tiles), dim3(kQ16Threads), lds, stream, F, rs, g,
+  EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_q16<BB, IN, O16, SC, T>)));
+  hipLaunchKernelGGL((k_column_pass_q16<BB, IN, O16, SC, T>), dim3((unsigned)tiles), dim3(T), lds, stream, F, rs, g,
                      (int)tiles_x, epi, debug_mode(), qa, scatter);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
+}
+
+template <bool BB, int IN, bool O16, bool SC>
+static int launch_q16_k(float *F, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa, int epi, hipStream_t stream,
+                        const BandScatter *scatter) {
+  if (g.nbands > 16) return launch_q16_kt<BB, IN, O16, SC, 512>(F, rs, g, qa, epi, stream, scatter);
+  return launch_q16_kt<BB, IN, O16, SC, 256>(F, rs, g, qa, epi, stream, scatter);
 }
 
 template <bool BB>

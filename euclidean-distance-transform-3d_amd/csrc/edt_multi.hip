@@ -281,7 +281,7 @@ int run_multi(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz,
     for (int h = 0; h < n; ++h) all_ok = all_ok && sh.rc[h] == EDT_OK;
     // ---- Z pass over [all z][my y rows], then my rows of every slice back to the host ----
     if (all_ok) {
-      const int r = edt_hip_shard_z_records_device_ex(d_recv, sx, ylen, sz, wz, edt_hip_field_floor(wx, wy), flags & (EDT_FLAG_BLACK_BORDER | EDT_FLAG_SQRT),
+      const int r = edt_hip_shard_z_records_device_w(d_recv, sx, ylen, sz, wx, wy, wz, flags & (EDT_FLAG_BLACK_BORDER | EDT_FLAG_SQRT),
                                                    slot.ws.p, wbytes, stream);
       if (r != EDT_OK) { rc = r; err = edt_hip_last_error(); }
       if (rc == EDT_OK)

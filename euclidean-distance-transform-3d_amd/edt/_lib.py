@@ -77,6 +77,7 @@ SIGNATURES = {
     "edt_hip_shard_z_records_device": (_i, [_vp, _i64, _i64, _i64, _f, _i, _vp, _sz, _vp]),
     "edt_hip_shard_z_device_ex": (_i, [_vp, _vp, _i64, _i64, _i64, _f, _f, _i, _vp, _sz, _vp]),
     "edt_hip_shard_z_records_device_ex": (_i, [_vp, _i64, _i64, _i64, _f, _f, _i, _vp, _sz, _vp]),
+    "edt_hip_shard_z_records_device_w": (_i, [_vp, _i64, _i64, _i64, _f, _f, _f, _i, _vp, _sz, _vp]),
     "edt_hip_field_floor": (_f, [_f, _f]),
     "edt_hip_subtract_device": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "edt_hip_voxel_graph_workspace_bytes": (_sz, [_i, _i64, _i64, _i64]),

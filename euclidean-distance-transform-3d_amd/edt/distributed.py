@@ -62,11 +62,7 @@ class HipOps:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
-        self.field_floor = 0.0  # lower bound of the non-zero values the Z phase reads (edt_hip.h: field_floor); 0 = unknown
 
-    def set_voxel_sizes(self, wx, wy):
-        """The caller of both phases knows what the XY phase leaves: every non-zero value >= min(fl32(wx^2), fl32(wy^2))."""
-        self.field_floor = float(self.lib.edt_hip_field_floor(wx, wy))
 
     def _workspace(self, nbytes, device, slot=0):
         """Scratch of one stream of work (`slot`): calls that may overlap use different slots."""
@@ -112,19 +108,27 @@ class HipOps:
             weights[0], weights[1], flags, len(blocks), splits, ptrs, ctypes.c_void_p(ws.data_ptr()),
             ws.numel(), self._stream()))
 
-    def z_records(self, records, sx, syl, wz, flags):
-        """Z pass in place over the gathered (sz, record_floats) buffer."""
+    def z_records(self, records, sx, syl, wz, flags, wxy=None):
+        """Z pass in place over the gathered (sz, record_floats) buffer.  wxy = (wx, wy) of the XY phase that produced the
+        records, where the caller knows them (an argument of THIS call, never remembered): the Z pass may then run on the
+        integer column kernel and form fp32 candidates -- the same bits either way (edt_hip.h)."""
         sz = records.shape[0]
         ws = self._workspace(self.lib.edt_hip_shard_records_workspace_bytes(_lib.U8, sx, syl, sz), records.device)
-        _lib.check(self.lib.edt_hip_shard_z_records_device_ex(
-            ctypes.c_void_p(records.data_ptr()), sx, syl, sz, wz, self.field_floor, flags, ctypes.c_void_p(ws.data_ptr()),
-            ws.numel(), self._stream()))
+        if wxy is not None:
+            _lib.check(self.lib.edt_hip_shard_z_records_device_w(
+                ctypes.c_void_p(records.data_ptr()), sx, syl, sz, wxy[0], wxy[1], wz, flags, ctypes.c_void_p(ws.data_ptr()),
+                ws.numel(), self._stream()))
+        else:
+            _lib.check(self.lib.edt_hip_shard_z_records_device_ex(
+                ctypes.c_void_p(records.data_ptr()), sx, syl, sz, wz, 0.0, flags, ctypes.c_void_p(ws.data_ptr()),
+                ws.numel(), self._stream()))
 
-    def z(self, partial, zflags, wz, flags):
+    def z(self, partial, zflags, wz, flags, wxy=None):
         sz, syl, sx = partial.shape
         ws = self._workspace(self.lib.edt_hip_shard_workspace_bytes(_lib.U8, sx, syl, sz), partial.device)
+        floor = float(self.lib.edt_hip_field_floor(wxy[0], wxy[1])) if wxy is not None else 0.0
         _lib.check(self.lib.edt_hip_shard_z_device_ex(
-            ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(zflags.data_ptr()), sx, syl, sz, wz, self.field_floor,
+            ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(zflags.data_ptr()), sx, syl, sz, wz, floor,
             flags, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
         return partial
 
@@ -316,7 +320,7 @@ class ShardedEDT:
             req.wait()
         if timed:
             self._ev[1].record()
-        self.ops.z_records(dst, self.sx, ye - ys, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0))
+        self.ops.z_records(dst, self.sx, ye - ys, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0), wxy=(w[0], w[1]))
         # the result is the float part of every record: a (sz, syl, sx) view with z-stride = record
         return dst[:, :(ye - ys) * self.sx].view(self.sz, ye - ys, self.sx)
 
@@ -368,8 +372,6 @@ class ShardedEDT:
             raise ValueError(f"rank {self.rank}: expected a contiguous ({ze - zs}, {self.sy}, {self.sx}) slab")
         w = tuple(float(np.float32(v)) for v in weights_xyz)
         flags = (_lib.FLAG_BLACK_BORDER if black_border else 0)
-        if hasattr(self.ops, "set_voxel_sizes"):  # (the GPU phases: the Z phase may use what the XY phase guarantees)
-            self.ops.set_voxel_sizes(w[0], w[1])
         halo = self._halo(labels)
         if self.records:
             out = self._run_records(labels, w, flags, sqrt, halo)
@@ -378,7 +380,7 @@ class ShardedEDT:
             return out
         partial, zflags = self.ops.xy(labels, halo, self.code, w, flags)
         partial_y, zflags_y = self._reshard([partial, zflags], to_y=True)
-        out = self.ops.z(partial_y, zflags_y, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0))
+        out = self.ops.z(partial_y, zflags_y, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0), wxy=(w[0], w[1]))
         if gather_back:
             out = self._reshard([out], to_y=False)[0]
         return out

@@ -261,6 +261,11 @@ int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_loca
 int edt_hip_shard_z_records_device_ex(float *d_records, int64_t sx, int64_t sy_local, int64_t sz,
                                       float wz, float field_floor, int flags, void *d_workspace,
                                       size_t workspace_bytes, void *stream);
+/* The same for a caller that names all three voxel sizes (the ones of the XY phase that produced the records and this
+ * phase's): field_floor = edt_hip_field_floor(wx, wy), and where the three sizes share a quantum ((1,1,1), (6,6,30) ...)
+ * the pass runs on the 16-bit integer column kernel (csrc/edt_colq16.hip); the same bits either way. */
+int edt_hip_shard_z_records_device_w(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wx, float wy,
+                                     float wz, int flags, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---- fused helpers on device-resident data ------------------------------------------ */
 /* out[i] = a[i] - b[i]  (src/edt.pyx:156-158, sdf = edt(x) - edt(x == 0)) */

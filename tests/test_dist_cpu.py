@@ -42,7 +42,7 @@ class OracleOps:
         assert rc == 0
         return torch.from_numpy(partial), torch.from_numpy(zflags)
 
-    def z(self, partial, zflags, wz, flags):
+    def z(self, partial, zflags, wz, flags, wxy=None):
         sz, syl, sx = partial.shape
         p = partial.numpy()
         rc = self.lib.oracle_shard_z(ctypes.c_void_p(p.ctypes.data),
@@ -77,7 +77,7 @@ class OracleOps:
                 bits[:, 1, r // 32, :] |= ((row >> 1) & 1) << (r % 32)
             raw[:, ylen * sx:] = bits.reshape(szl, -1)
 
-    def z_records(self, records, sx, syl, wz, flags):
+    def z_records(self, records, sx, syl, wz, flags, wxy=None):
         raw = records.numpy().view(np.uint32)
         sz, words = raw.shape[0], -(-syl // 32)
         partial = raw[:, :syl * sx].view(np.float32).reshape(sz, syl, sx).copy()

@@ -87,7 +87,7 @@ def test_uneven_1024_world8_virtual_ranks_against_compiled_reference(edt_gpu, or
     del t
     got = np.empty((sz, sy, sx), dtype=np.float32)
     for h, (ys, ye) in enumerate(yparts):
-        ops.z_records(dst[h], sx, ye - ys, an[2], 0)
+        ops.z_records(dst[h], sx, ye - ys, an[2], 0, wxy=(an[0], an[1]))
         got[:, ys:ye, :] = dst[h][:, :(ye - ys) * sx].reshape(sz, ye - ys, sx).cpu().numpy()
     assert np.array_equal(got.T, want)
 

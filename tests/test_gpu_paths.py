@@ -83,7 +83,6 @@ def test_shard_phases_as_virtual_ranks(edt_gpu, oracle_port, world, shape):
     # edt_hip_shard_z_device_ex's field_floor, fp32 fma candidates)
     for an, bb, sqrt in (((6.0, 6.0, 30.0), True, False), ((1.0, 1.5, 0.5), False, True), ((1.1, 0.7, 1.3), False, False)):
         flags = _lib.FLAG_BLACK_BORDER if bb else 0
-        ops.set_voxel_sizes(an[0], an[1])
         partial, zflags = [], []
         for r, (zs, ze) in enumerate(zparts):
             halo = t[zs - 1].contiguous() if r > 0 else None  # the previous rank's last slice
@@ -95,7 +94,7 @@ def test_shard_phases_as_virtual_ranks(edt_gpu, oracle_port, world, shape):
         outs = []
         for (ys, ye) in yparts:  # the all-to-all: rank h receives (all z, its y range)
             o = ops.z(partial[:, ys:ye, :].contiguous(), zflags[:, ys:ye, :].contiguous(), an[2],
-                      flags | (_lib.FLAG_SQRT if sqrt else 0))
+                      flags | (_lib.FLAG_SQRT if sqrt else 0), wxy=(an[0], an[1]))
             outs.append(o.clone())
         got = torch.cat(outs, 1).cpu().numpy().T
         want = oracle_port.edtsq(lab, an, bb)
@@ -147,7 +146,6 @@ def test_shard_records_as_virtual_ranks(edt_gpu, oracle_port, world, chunks, sha
     rec = [ops.record_floats(sx, b - a) for a, b in yparts]
     for (an, bb, sqrt), want in zip(runs, wants):
         flags = _lib.FLAG_BLACK_BORDER if bb else 0
-        ops.set_voxel_sizes(an[0], an[1])  # (the Z phase may use fp32 fma candidates: edt_hip.h, field_floor)
         dst = [torch.full((sz, rec[h]), float("nan"), dtype=torch.float32, device=dev) for h in range(world)]
         for r, (zs, ze) in enumerate(zparts):
             halo = t[zs - 1] if r > 0 else None  # the previous rank's last slice
@@ -161,7 +159,10 @@ def test_shard_records_as_virtual_ranks(edt_gpu, oracle_port, world, chunks, sha
                 halo = t[zs + c1 - 1]
         outs = []
         for h, (ys, ye) in enumerate(yparts):
-            ops.z_records(dst[h], sx, ye - ys, an[2], flags | (_lib.FLAG_SQRT if sqrt else 0))
+            # (the Z phase is told the voxel sizes of the XY phase: integer column kernel / fp32 fma candidates, edt_hip.h;
+            # every other rank without them -- the fp32 kernels with fp64 candidates: the same bits)
+            ops.z_records(dst[h], sx, ye - ys, an[2], flags | (_lib.FLAG_SQRT if sqrt else 0),
+                          wxy=(an[0], an[1]) if h % 2 == 0 else None)
             outs.append(dst[h][:, :(ye - ys) * sx].reshape(sz, ye - ys, sx))
         got = torch.cat(outs, 1).cpu().numpy().T
         assert same(got, want), (world, shape, an, bb)

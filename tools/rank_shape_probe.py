@@ -28,7 +28,7 @@ blocks = [dst[zs:ze] if h == rank else torch.empty((ze - zs, rec[h]), dtype=torc
 an = (1.0, 1.0, 1.0)
 def run():
     ops.xy_records(labels, halo, _lib.U32, an, 0, y_splits, blocks)
-    ops.z_records(dst, sx, yparts[rank][1] - yparts[rank][0], an[2], 0)
+    ops.z_records(dst, sx, yparts[rank][1] - yparts[rank][0], an[2], 0, wxy=(an[0], an[1]))
 for _ in range(2): run()
 torch.cuda.synchronize()
 device.set_profiling(True); acc = {}

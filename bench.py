@@ -102,6 +102,11 @@ def real_traffic_fields(ms_per_step, kernel_ms, dom, config):
     return out
 
 
+# the arithmetic the column passes compute in: exact 16-bit integer multiples of the voxel sizes' common quantum
+# (csrc/edt_colq16.hip) wherever a tile's values fit, the reference's fp64 envelope arithmetic elsewhere; fp32 storage
+DTYPE = "u16 integer quanta (exact) with f64 envelope fallback / f32 storage / u32 labels"
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -111,6 +116,29 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def physical_cores():
+    """Physical cores of the host (unique (package, core) pairs of /proc/cpuinfo); os.cpu_count() counts hardware threads."""
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
 
 
 def reference_lib():
@@ -348,10 +376,18 @@ def sharded_main(args, rank, world, dev):
     import torch.distributed as dist
     from edt import _lib
     from edt.distributed import ShardedEDT, global_extents
-    ext = global_extents(world, args.size)
-    kind = os.environ.get("EDT_BENCH_LABELS", "cfg4")  # "ones": the single-label box (closed-form check)
+    # Three readings of a --gpus N line (stated in the line itself: "scaling", "reading"):
+    #   default               WEAK scaling on configs[3]: args.size^3 voxels of the multi-label segmentation per GPU
+    #   --labels ones         WEAK scaling on the headline's workload (configs[1]: single label, (6,6,30), black border):
+    #                         the series that continues the --gpus 1 headline
+    #   --global-size S       STRONG scaling: ONE S^3 volume whatever N (the metric's "512^3 @ 1/2/4/8 GPU" read literally)
+    kind = args.labels or os.environ.get("EDT_BENCH_LABELS", "cfg4")  # "ones": the single-label box (closed-form check)
+    strong = args.global_size > 0
+    ext = (args.global_size,) * 3 if strong else global_extents(world, args.size)
     an, bb = ((6.0, 6.0, 30.0), True) if kind == "ones" else ((1.0, 1.0, 1.0), False)
-    plan = ShardedEDT(ext, _lib.U32)
+    if (args.selftest or world > 1) and not args.no_selftest:
+        selftest(rank, world, dev, ext, kind)
+    plan = ShardedEDT(ext, _lib.U32, reuse_output=True)  # (every step's result is consumed before the next step)
     zs, ze = plan.local_z()
     labels = slab_labels(ext, zs, ze, dev, kind)
 
@@ -428,12 +464,12 @@ def sharded_main(args, rank, world, dev):
     # path), timed on rank 0 while the others wait: what `value` of this weak-scaling line is to be compared with
     # (the --gpus 1 line's headline is the single-label box, a lighter workload)
     same_n1 = None
-    if rank == 0 and kind != "ones":
+    if rank == 0:
         try:
             from edt import device as _dev
-            cube = (args.size,) * 3
-            lab1 = slab_labels(cube, 0, args.size, dev, kind)
-            out1 = torch.empty(cube, dtype=torch.float32, device=dev)
+            cube = ext if strong else (args.size,) * 3   # strong scaling: the SAME volume on one GPU
+            lab1 = slab_labels(cube, 0, cube[2], dev, kind)
+            out1 = torch.empty(cube[::-1], dtype=torch.float32, device=dev)
             plan1 = _dev.Plan(cube, _lib.U32, dev)
             for _ in range(3):
                 plan1.run(lab1, an, black_border=bb, out=out1)
@@ -443,8 +479,9 @@ def sharded_main(args, rank, world, dev):
                 plan1.run(lab1, an, black_border=bb, out=out1)
             torch.cuda.synchronize()
             ms1 = (time.perf_counter() - t1) / 10 * 1e3
-            same_n1 = {"ms_per_step": round(ms1, 4), "mvox_per_s": round(args.size ** 3 / ms1 / 1e3, 1),
-                       "what": f"{args.size}^3 voxels of the same segmentation on ONE GPU (single-device path), rank 0"}
+            vox1 = cube[0] * cube[1] * cube[2]
+            same_n1 = {"ms_per_step": round(ms1, 4), "mvox_per_s": round(vox1 / ms1 / 1e3, 1),
+                       "what": f"{cube[0]}x{cube[1]}x{cube[2]} voxels of the same workload on ONE GPU (single-device path), rank 0"}
             del lab1, out1, plan1
         except Exception as e:  # pragma: no cover
             same_n1 = {"error": repr(e)}
@@ -467,16 +504,36 @@ def sharded_main(args, rank, world, dev):
                         "whole_job_frac": round(whole / (8000.0 * world), 4),
                         "note": "per rank; the exchange is not a kernel of this library and is not listed; "
                                 "whole_job_frac = 32 B/voxel over ms_per_step against world x 8 TB/s"}
+        value = round(vox / (elapsed / args.steps) / 1e6, 1)
+        what = "single label (configs[1], the --gpus 1 headline's workload)" if kind == "ones" else \
+            "multi-label segmentation, 16000 seeds per 1024^3 (configs[3])"
+        if strong:
+            reading = (f"STRONG scaling: the same {ext[0]}^3 volume ({what}) on {world} GPU(s); "
+                       "scaling_efficiency = value / (n_gpus x the same volume's rate on one GPU)")
+        elif kind == "ones":
+            reading = (f"WEAK scaling on the headline workload: {args.size}^3 voxels per GPU of the single-label box; continues the "
+                       "--gpus 1 headline; scaling_efficiency = value / (n_gpus x one GPU's rate on its share)")
+        else:
+            reading = (f"WEAK scaling on configs[3]: {args.size}^3 voxels per GPU of the multi-label segmentation -- NOT the --gpus 1 "
+                       "headline's workload (single label); compare with single_gpu_same_workload, not with the N = 1 line; "
+                       "scaling_efficiency = value / (n_gpus x single_gpu_same_workload.mvox_per_s)")
+        eff = None
+        if same_n1 and same_n1.get("mvox_per_s"):
+            eff = round(value / (world * same_n1["mvox_per_s"]), 4)
         line = {
-            "metric": "Mvox/s edt3dsq 512^3 uint32", "value": round(vox / (elapsed / args.steps) / 1e6, 1),
+            "metric": "Mvox/s edt3dsq 512^3 uint32", "value": value,
             "unit": "Mvox/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 envelope / f32 storage / u32 labels", "data": "synthetic",
-            "config": {"workload": f"WEAK scaling: one {ext[0]}x{ext[1]}x{ext[2]} uint32 volume = {args.size}^3 voxels "
-                                   f"per GPU ({'single label' if kind == 'ones' else 'multi-label segmentation, 16000 seeds per 1024^3 (configs[3])'}), "
+            "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "reading": reading,
+            "single_gpu_same_workload": same_n1,
+            "scaling_efficiency": eff,
+            "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": f"{'STRONG' if strong else 'WEAK'} scaling: one {ext[0]}x{ext[1]}x{ext[2]} uint32 volume"
+                                   f"{'' if strong else f' = {args.size}^3 voxels per GPU'} ({what}), "
                                    f"anisotropy {an}, black_border={bb}, Z-sharded over {world} GPUs, "
                                    "one all-to-all (Z-slabs -> Y-slabs) before the z pass",
+                       "labels": kind, "global_extents": list(ext),
                        "form": "slab records" if plan.records else "byte flags",
                        "chunks": getattr(plan, "nchunks", 1),
                        "output_verified": verified, "verified_by": how,
@@ -512,12 +569,71 @@ def sharded_main(args, rank, world, dev):
         print(json.dumps(line), flush=True)
 
 
-def _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev):
+def selftest(rank, world, dev, ext, kind):
+    """Before anything is timed: what a failure on a multi-GPU box has to be diagnosed from.  Rank 0 prints (stdout, prefix
+    [selftest]) the RCCL version, the peer-access matrix of the visible devices, the per-peer message sizes of the
+    all-to-all of the run to come, and the result of one tiny sharded transform checked bit for bit against the CPU
+    checker.  Any exception is printed with its rank and re-raised."""
+    import torch.distributed as dist
+    from edt import _lib
+    from edt.distributed import ShardedEDT
+
+    def say(*a):
+        if rank == 0:
+            print("[selftest]", *a, flush=True)
+
+    try:
+        try:
+            nccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # pragma: no cover
+            nccl = f"unknown ({e!r})"
+        say(f"torch {torch.__version__}, backend {dist.get_backend()}, RCCL/NCCL {nccl}, world {world}, "
+            f"devices visible to rank 0: {torch.cuda.device_count()}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}")
+        ndev = torch.cuda.device_count()
+        me = dev.index if dev.index is not None else torch.cuda.current_device()
+        row = [1 if (j == me or torch.cuda.can_device_access_peer(me, j)) else 0 for j in range(ndev)]
+        rows = [None] * world
+        dist.all_gather_object(rows, (rank, me, torch.cuda.get_device_name(me), row))
+        for r, d, name, acc in rows:
+            say(f"rank {r}: cuda:{d} {name}, peer access to cuda:0..{len(acc) - 1}: {acc}")
+        # message sizes of the real run (slab records): what rank r sends to rank h per chunk and per step
+        plan = ShardedEDT(ext, _lib.U32)
+        if plan.records:
+            rec = [plan.ops.record_floats(plan.sx, b - a) for a, b in plan.yparts]
+            for r in range(world):
+                per_chunk = [[4 * (plan._chunk(r, k)[1] - plan._chunk(r, k)[0]) * rec[h] if h != r else 0 for h in range(world)]
+                             for k in range(plan.nchunks)]
+                if r == 0 or r == world - 1:
+                    say(f"all_to_all of rank {r}: {plan.nchunks} chunk(s), bytes to each rank per chunk {per_chunk[0]}"
+                        f"{' ... ' + str(per_chunk[-1]) if plan.nchunks > 1 else ''}, per step {sum(sum(c) for c in per_chunk)}")
+        else:
+            say("the slab-record form does not apply to these extents: byte-flag form (one group of point-to-point transfers)")
+        say(f"y ranges per rank {plan.yparts}, z ranges per rank {plan.zparts}")
+        del plan
+        # one tiny sharded transform, verified: uneven cuts on purpose
+        small = (96, 32 * world + 40, 8 * world + 5)
+        tiny = ShardedEDT(small, _lib.U32, chunks=2)
+        zs, ze = tiny.local_z()
+        lab = slab_labels(small, zs, ze, dev, "cfg4")
+        out = tiny.run(lab, (1.0, 1.0, 2.0), black_border=False)
+        torch.cuda.synchronize()
+        ok, how, _ = _verify_against_reference(tiny, lab, out, small, (1.0, 1.0, 2.0), False, rank, world, dev, force=True)
+        say(f"tiny volume {small} over {world} rank(s), form {'slab records' if tiny.records else 'byte flags'}: "
+            f"output_verified={ok} ({how})")
+        dist.barrier()
+        if rank == 0 and ok is False:
+            raise SystemExit("[selftest] the tiny sharded transform differs from the CPU checker")
+    except BaseException as e:
+        print(f"[selftest] rank {rank} FAILED: {e!r}", flush=True)
+        raise
+
+
+def _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev, force=False):
     """Bit-for-bit check of the timed multi-GPU output: rank 0 collects every rank's label slab and result
     slab and runs the CPU reference (oracle/_ref, test infrastructure) on the whole volume with all host
     threads.  Returns (verified | None, how, cpu_baseline | None).  EDT_BENCH_VERIFY=0 skips it."""
     import torch.distributed as dist
-    if os.environ.get("EDT_BENCH_VERIFY", "1") == "0":
+    if os.environ.get("EDT_BENCH_VERIFY", "1") == "0" and not force:
         return None, "skipped (EDT_BENCH_VERIFY=0)", None
     have = torch.tensor([0], device=dev)
     lib = None
@@ -526,6 +642,9 @@ def _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev):
             from oracle import harness
             if harness.have_ref():
                 lib = harness.ref(fast=True)
+                have[0] = 1
+            elif force and harness.have_port():  # (the self-test's tiny volume: the plain-C restatement serves)
+                lib = harness.port()
                 have[0] = 1
         except Exception:
             lib = None
@@ -566,7 +685,8 @@ def _verify_against_reference(plan, labels, out, ext, an, bb, rank, world, dev):
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(want, res_full.reshape(-1)))
     model = cpu_model()
-    cpu = {"value": round(sx * sy * sz / dt / 1e6, 2), "unit": "Mvox/s", "cores": cores, "kind": "reference",
+    cpu = {"value": round(sx * sy * sz / dt / 1e6, 2), "unit": "Mvox/s", "cores": physical_cores(), "host_threads": cores,
+           "kind": "reference",
            "cpu": model, "sample": f"the whole {sx}x{sy}x{sz} volume of this run, one pass with {cores} threads "
                                    "(the pass that also checks the GPU output bit for bit)"}
     return ok, f"compiled CPU reference on the whole volume, {cores} threads", cpu
@@ -581,6 +701,14 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg3f", "cfg3m", "cfg4", "cfg5", "cfg3L", "cfg3La",
                                                         "cfg3M", "cfg3Ma"])
     ap.add_argument("--secondary", default="", help="comma-separated subset of the secondary configurations")
+    ap.add_argument("--labels", default="", choices=["", "cfg4", "ones"],
+                    help="--gpus N > 1: the workload of the sharded leg -- cfg4 (default: the multi-label segmentation of "
+                         "configs[3]) or ones (the single-label box of the --gpus 1 headline: an apples-to-apples series)")
+    ap.add_argument("--global-size", type=int, default=0,
+                    help="--gpus N > 1: STRONG scaling -- one volume of this edge length whatever N (0: weak scaling, "
+                         "--size^3 voxels per GPU)")
+    ap.add_argument("--selftest", action="store_true", help="run the sharded leg's self-test also at world size 1")
+    ap.add_argument("--no-selftest", action="store_true", help="skip the self-test of the sharded leg (default at N > 1: run it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline configuration only")
     ap.add_argument("--generic", action="store_true", help="force the size-agnostic fallback kernels")
@@ -705,7 +833,7 @@ def main():
         "metric": "Mvox/s edt3dsq 512^3 uint32", "value": summary["mvox_per_s"], "unit": "Mvox/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": summary["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 envelope / f32 storage / u32 labels", "data": "synthetic",
+        "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"{args.config}: {n}^3 uint32 labels, anisotropy {tuple(head_an)}, "
                                f"black_border={head_bb}, device-resident in/out",
                    "path": "generic" if args.generic else "default", "output_verified": ok},
@@ -724,8 +852,11 @@ def main():
             res, _ = time_reference(lib, kind, lab, tuple(head_an), head_bb, threads)
             top = max(res, key=lambda k: res[k])
             result["cpu_baseline"] = {
-                "value": round(res[top], 2), "unit": "Mvox/s", "cores": int(top), "kind": kind,
-                "cpu": cpu_model(), "host_threads": cores,
+                # cores: the physical cores the fastest figure ran on (all of them when every hardware thread was used);
+                # host_threads: the threads of that run
+                "value": round(res[top], 2), "unit": "Mvox/s",
+                "cores": (physical_cores() if int(top) >= physical_cores() else int(top)), "kind": kind,
+                "cpu": cpu_model(), "host_threads": int(top), "hardware_threads": cores,
                 "sample": f"whole {m}^3 uint32 headline volume ({args.config}), anisotropy {tuple(head_an)}, "
                           "1 warm-up + best of 3; "
                           + ", ".join(f"{p} thread(s): {v:.1f} Mvox/s" for p, v in res.items()),

@@ -10,7 +10,7 @@
 // C ABI of include/edt_hip.h (link with -ledt_hip); the label type becomes a dtype code.
 //
 // Behaviour kept from the reference:
-//   * `workspace/output == NULL` -> the result is allocated with new float[]() and owned by
+//   * `workspace/output == NULL` -> the result is allocated with new float[] (freed again if the call throws) and owned by
 //     the caller (delete[]), otherwise the return value aliases the caller's buffer
 //     (src/edt.hpp:424-426);
 //   * `parallel` is accepted and ignored (the GPU grid replaces the thread pool);
@@ -22,6 +22,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -38,6 +39,23 @@ constexpr int dtype_code() {
   // signed integers are reinterpreted as unsigned, like src/edt.pyx:670-705
   return sizeof(T) == 1 ? EDT_U8 : sizeof(T) == 2 ? EDT_U16 : sizeof(T) == 4 ? EDT_U32 : EDT_U64;
 }
+
+// The result buffer of a call: the caller's, or a fresh `new float[]` the caller will own -- released again if the call
+// throws, and NOT zero-filled first (the reference's `new float[n]()` is: every entry point here writes every element).
+struct Result {
+  float* p;
+  std::unique_ptr<float[]> own;
+  Result(float* given, size_t count) : p(given) {
+    if (p == NULL) {
+      own.reset(new float[count]);
+      p = own.get();
+    }
+  }
+  float* release() {
+    own.release();
+    return p;
+  }
+};
 
 inline void check(int rc) {
   if (rc != EDT_OK) throw std::runtime_error(std::string("edt_hip: ") + edt_hip_last_error());
@@ -57,10 +75,10 @@ template <typename T>
 float* _edt3dsq(T* labels, const int64_t sx, const int64_t sy, const int64_t sz, const float wx,
                 const float wy, const float wz, const bool black_border = false,
                 const int parallel = 1, float* workspace = NULL) {
-  if (workspace == NULL) workspace = new float[sx * sy * sz]();
+  Result out(workspace, (size_t)(sx * sy * sz));
   check(edt_hip_edt3dsq(labels, dtype_code<T>(), sx, sy, sz, wx, wy, wz, black_border, parallel,
-                        workspace));
-  return workspace;
+                        out.p));
+  return out.release();
 }
 
 // src/edt.hpp:591-604
@@ -68,10 +86,10 @@ template <typename T>
 float* _edt3d(T* labels, const int64_t sx, const int64_t sy, const int64_t sz, const float wx,
               const float wy, const float wz, const bool black_border = false,
               const int parallel = 1, float* workspace = NULL) {
-  if (workspace == NULL) workspace = new float[sx * sy * sz]();
+  Result out(workspace, (size_t)(sx * sy * sz));
   check(edt_hip_edt3d(labels, dtype_code<T>(), sx, sy, sz, wx, wy, wz, black_border, parallel,
-                      workspace));
-  return workspace;
+                      out.p));
+  return out.release();
 }
 
 // src/edt.hpp:632-678 (bool: :758-772)
@@ -79,18 +97,18 @@ template <typename T>
 float* _edt2dsq(T* labels, const int64_t sx, const int64_t sy, const float wx, const float wy,
                 const bool black_border = false, const int parallel = 1,
                 float* workspace = NULL) {
-  if (workspace == NULL) workspace = new float[sx * sy]();
-  check(edt_hip_edt2dsq(labels, dtype_code<T>(), sx, sy, wx, wy, black_border, parallel, workspace));
-  return workspace;
+  Result out(workspace, (size_t)(sx * sy));
+  check(edt_hip_edt2dsq(labels, dtype_code<T>(), sx, sy, wx, wy, black_border, parallel, out.p));
+  return out.release();
 }
 
 // src/edt.hpp:776-797
 template <typename T>
 float* _edt2d(T* labels, const int64_t sx, const int64_t sy, const float wx, const float wy,
               const bool black_border = false, const int parallel = 1, float* output = NULL) {
-  if (output == NULL) output = new float[sx * sy]();
-  check(edt_hip_edt2d(labels, dtype_code<T>(), sx, sy, wx, wy, black_border, parallel, output));
-  return output;
+  Result out(output, (size_t)(sx * sy));
+  check(edt_hip_edt2d(labels, dtype_code<T>(), sx, sy, wx, wy, black_border, parallel, out.p));
+  return out.release();
 }
 
 // The binary route (src/edt.hpp:487-576, :607-629, :681-755): pass X splits runs at label changes, passes Y and Z
@@ -102,35 +120,35 @@ float* _binary_edt3dsq(T* img, const int64_t sx, const int64_t sy, const int64_t
                        const float wy, const float wz, const bool black_border = false,
                        const int parallel = 1, float* workspace = NULL) {
   (void)parallel;
-  if (workspace == NULL) workspace = new float[sx * sy * sz]();
-  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 0, workspace));
-  return workspace;
+  Result out(workspace, (size_t)(sx * sy * sz));
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 0, out.p));
+  return out.release();
 }
 template <typename T>
 float* _binary_edt3d(T* img, const int64_t sx, const int64_t sy, const int64_t sz, const float wx,
                      const float wy, const float wz, const bool black_border = false,
                      const int parallel = 1, float* workspace = NULL) {
   (void)parallel;
-  if (workspace == NULL) workspace = new float[sx * sy * sz]();
-  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 1, workspace));
-  return workspace;
+  Result out(workspace, (size_t)(sx * sy * sz));
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 1, out.p));
+  return out.release();
 }
 template <typename T>
 float* _binary_edt2dsq(T* img, const int64_t sx, const int64_t sy, const float wx, const float wy,
                        const bool black_border = false, const int parallel = 1,
                        float* workspace = NULL) {
   (void)parallel;
-  if (workspace == NULL) workspace = new float[sx * sy]();
-  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 0, workspace));
-  return workspace;
+  Result out(workspace, (size_t)(sx * sy));
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 0, out.p));
+  return out.release();
 }
 template <typename T>
 float* _binary_edt2d(T* img, const int64_t sx, const int64_t sy, const float wx, const float wy,
                      const bool black_border = false, const int parallel = 1, float* output = NULL) {
   (void)parallel;
-  if (output == NULL) output = new float[sx * sy]();
-  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 1, output));
-  return output;
+  Result out(output, (size_t)(sx * sy));
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 1, out.p));
+  return out.release();
 }
 
 // src/edt_voxel_graph.hpp:54-117, :120-214, :216-236 (GRAPH_TYPE is always uint8_t upstream)
@@ -139,20 +157,20 @@ float* _edt2dsq_voxel_graph(T* labels, GRAPH_TYPE* graph, const int64_t sx, cons
                             const float wx, const float wy, const bool black_border = false,
                             float* workspace = NULL) {
   static_assert(sizeof(GRAPH_TYPE) == 1, "voxel graph must be one byte per voxel");
-  if (workspace == NULL) workspace = new float[sx * sy]();
+  Result out(workspace, (size_t)(sx * sy));
   check(edt_hip_edt2dsq_voxel_graph(labels, dtype_code<T>(), reinterpret_cast<const uint8_t*>(graph),
-                                    sx, sy, wx, wy, black_border, workspace));
-  return workspace;
+                                    sx, sy, wx, wy, black_border, out.p));
+  return out.release();
 }
 template <typename T, typename GRAPH_TYPE = uint8_t>
 float* _edt3dsq_voxel_graph(T* labels, GRAPH_TYPE* graph, const int64_t sx, const int64_t sy,
                             const int64_t sz, const float wx, const float wy, const float wz,
                             const bool black_border = false, float* workspace = NULL) {
   static_assert(sizeof(GRAPH_TYPE) == 1, "voxel graph must be one byte per voxel");
-  if (workspace == NULL) workspace = new float[sx * sy * sz]();
+  Result out(workspace, (size_t)(sx * sy * sz));
   check(edt_hip_edt3dsq_voxel_graph(labels, dtype_code<T>(), reinterpret_cast<const uint8_t*>(graph),
-                                    sx, sy, sz, wx, wy, wz, black_border, workspace));
-  return workspace;
+                                    sx, sy, sz, wx, wy, wz, black_border, out.p));
+  return out.release();
 }
 template <typename T, typename GRAPH_TYPE = uint8_t>
 float* _edt3d_voxel_graph(T* labels, GRAPH_TYPE* graph, const int64_t sx, const int64_t sy,
@@ -171,17 +189,18 @@ namespace edt {
 // 1-D (src/edt.hpp:807-821, :884-893)
 template <typename T>
 float* edt(T* labels, const int sx, const float wx, const bool black_border = false) {
-  float* d = new float[sx]();
+  pyedt::Result out(NULL, (size_t)sx);
+  float* d = out.p;
   pyedt::squared_edt_1d_multi_seg(labels, d, sx, 1, wx);  // sic: black_border not forwarded upstream
   for (int i = 0; i < sx; i++) d[i] = std::sqrt(d[i]);
   (void)black_border;
-  return d;
+  return out.release();
 }
 template <typename T>
 float* edtsq(T* labels, const int sx, const float wx, const bool black_border = false) {
-  float* d = new float[sx]();
-  pyedt::squared_edt_1d_multi_seg(labels, d, sx, 1, wx, black_border);
-  return d;
+  pyedt::Result out(NULL, (size_t)sx);
+  pyedt::squared_edt_1d_multi_seg(labels, out.p, sx, 1, wx, black_border);
+  return out.release();
 }
 
 // 2-D (src/edt.hpp:823-833, :895-905)

@@ -117,7 +117,7 @@ struct Plan {
   float *bufB = nullptr;
   int32_t *stack = nullptr;
   uint32_t *nz_y = nullptr, *rs_y = nullptr, *zs_y = nullptr, *nz_z = nullptr, *rs_z = nullptr;
-  unsigned char *line_ws = nullptr;  // scratch of the line pipeline when pass 1 runs over rows of more than 2048 voxels
+  unsigned char *line_ws = nullptr;  // scratch of the line pipeline when pass 1 runs over rows no row kernel takes (> 4096 voxels)
   uint16_t *codes = nullptr;  // 16-bit distance indices of pass 1 (index form), one slab of xy_slab slices
   int64_t xy_slab = 0;        // slices per slab of the slab-wise X/Y passes (0: no index form for this shape)
   // the tiles the 16-bit integer column kernel hands to the fp32 kernel (edt_colq16.hip): kQ16Slots counters, one per
@@ -203,8 +203,10 @@ static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, v
     p.q16_ids = c.take<uint32_t>((size_t)std::max(ty, tz));
   }
   if (ndim == 1) (void)c.take<unsigned char>(line_workspace_bytes(sx));  // block scan + table of the 1-D pipeline
-  // rows too long for the row kernels (sx > 2048): pass 1 runs as the line pipeline over the stack of rows
-  if (ndim >= 2 && !row_pass_tiled_supported(sx) && !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic())
+  // rows too long for the row kernels (more than 4096 voxels; more than 2048 where the wave kernel does not apply): pass 1
+  // runs as the line pipeline over the stack of rows and needs its scratch
+  if (ndim >= 2 && !row_pass_tiled_supported(sx) && !row_pass_wave_supported(dtype, sx, sy, sz) &&
+      !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic())
     p.line_ws = c.take<unsigned char>(rows_line_workspace_bytes(sx, sy * sz));
   p.bytes = align_up(c.off, 256) + 256;
   return p;
@@ -228,8 +230,9 @@ static int launch_column_inplace(float *F, const uint32_t *nz, const uint32_t *r
   return launch_column_pass_tiled(F, nz, rs, g, w, bb, epi, stream);
 }
 
-// Pass 1 with the bit planes of the column passes as a by-product: the register-resident kernel
-// for rows up to 512 voxels, the LDS-staged one for longer rows.  (debug bit 32 forces the latter.)
+// Pass 1 with the bit planes of the column passes as a by-product: the register-resident wave kernel for rows of up
+// to 4096 voxels (one, two or four waves per row), the LDS-staged workgroup kernel (rows of up to 2048 voxels) where
+// that one does not apply.  (debug bit 32 forces the latter.)
 static int launch_row_bits(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                            uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
                            int to_finite, hipStream_t stream) {
@@ -330,7 +333,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     q16 = q16_quantum(ws3, (ndim == 3 && !(flags & EDT_FLAG_BATCH_2D)) ? 3 : 2, &q16_q, q16_a);
     if (q16) EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, (kQ16Slots + (size_t)(ceil_div(sx, 32) * p.q16_map_words)) * sizeof(uint32_t), stream));
   }
-  constexpr int kQ16Off = 16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x400000;
+  constexpr int kQ16Off = 16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000;
   // F in place (codes == nullptr) or from the 16-bit indices of pass X; returns the list for the fp32 launch that follows
   auto q16_pass = [&](float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, int axis, int epi,
                       TileList &list, uint16_t *plane = nullptr) -> int {
@@ -618,6 +621,24 @@ static std::vector<int> g_devices = [] {
 
 constexpr int EDT_FLAG_SINGLE_DEVICE = 0x4000;  // internal: do not take the multi-GPU route
 
+// The first device of the list (edt_hip_set_devices / EDT_HIP_DEVICES) for the duration of one host-buffer call that
+// is not sharded; no list: the caller's current device stays.
+struct ListedDevice {
+  int prev = -1;
+  bool switched = false;
+  ListedDevice() {
+    int first = -1;
+    {
+      std::lock_guard<std::mutex> lock(g_devices_mutex);
+      if (!g_devices.empty()) first = g_devices[0];
+    }
+    if (first >= 0 && hipGetDevice(&prev) == hipSuccess && prev != first && hipSetDevice(first) == hipSuccess) switched = true;
+  }
+  ~ListedDevice() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz,
                     float wx, float wy, float wz, int flags, float *output) {
   int rc = check_shape(dtype, ndim, sx, sy, sz);
@@ -628,20 +649,24 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
   rc = require_device();
   if (rc != EDT_OK) return rc;
   if (env_force_generic()) flags |= EDT_FLAG_FORCE_GENERIC;
-  if (ndim == 3 && !(flags & (EDT_FLAG_FORCE_GENERIC | EDT_FLAG_BATCH_2D | EDT_FLAG_SINGLE_DEVICE | EDT_FLAG_BINARY_YZ))) {
+  // The device list (edt_hip_set_devices / EDT_HIP_DEVICES) is honoured by EVERY host-buffer call: a 3-D volume the
+  // slab-record form can cut is Z-sharded over the listed devices, everything else (1-D, 2-D, stacks of images, the binary
+  // route, the forced generic kernels, volumes that cannot be cut) runs on the FIRST listed device.
+  if (!(flags & EDT_FLAG_SINGLE_DEVICE)) {
     std::vector<int> devs;
     {
       std::lock_guard<std::mutex> lock(g_devices_mutex);
       devs = g_devices;
     }
-    if (devs.size() >= 2 && multi_supported(dtype, sx, sy, sz, (int)devs.size())) {
+    const bool shardable = ndim == 3 && !(flags & (EDT_FLAG_FORCE_GENERIC | EDT_FLAG_BATCH_2D | EDT_FLAG_BINARY_YZ));
+    if (shardable && devs.size() >= 2 && multi_supported(dtype, sx, sy, sz, (int)devs.size())) {
       Prefault touch(output, (size_t)voxels * sizeof(float));
       touch.join();
       return run_multi(labels, dtype, sx, sy, sz, wx, wy, wz, flags, output, devs.data(), (int)devs.size());
     }
     if (!devs.empty()) {
-      // a one-entry list, or a volume the slab-record form does not cover: the FIRST listed device does it alone
-      if (devs.size() >= 2) {
+      // a one-entry list, or a call the slab-record form does not cover: the FIRST listed device does it alone
+      if (shardable && devs.size() >= 2) {
         static std::atomic<bool> said{false};
         if (!said.exchange(true))
           fprintf(stderr, "[edt_hip] note: a %lld x %lld x %lld volume cannot be Z-sharded over %zu devices (slab records: "
@@ -692,6 +717,7 @@ static int sdf_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
   if (voxels == 0) return EDT_OK;
   if (!labels || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
   if ((rc = require_device()) != EDT_OK) return rc;
+  ListedDevice on_listed_device;
   if (env_force_generic()) flags |= EDT_FLAG_FORCE_GENERIC;
   const size_t lbytes = (size_t)voxels * dtype_size(dtype), obytes = (size_t)voxels * sizeof(float);
   const size_t wbytes = std::max(edt_hip_workspace_bytes_flags(dtype, ndim, sx, sy, sz, flags),
@@ -730,6 +756,7 @@ static int voxel_graph_host(const void *labels, int dtype, const uint8_t *graph,
   if (voxels == 0) return EDT_OK;
   if (!labels || !graph || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
   if ((rc = require_device()) != EDT_OK) return rc;
+  ListedDevice on_listed_device;
   const size_t lbytes = (size_t)voxels * dtype_size(dtype);
   const size_t wbytes = edt_hip_voxel_graph_workspace_bytes(ndim, sx, sy, sz);
   const bool pooled = pool_enabled();
@@ -1189,7 +1216,7 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
     const float w2[2] = {wx, wy};
     float q = 1.0f;
     uint32_t a[3];
-    if (!(g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x400000)) && q16_quantum(w2, 2, &q, a) &&
+    if (!(g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000)) && q16_quantum(w2, 2, &q, a) &&
         column_pass_q16_supported(gy) && column_pass_wave_supported(gy) && aligned) {
       EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, 4 * sizeof(uint32_t), stream));
       rc = launch_column_pass_q16(p.F, codes, p.ys_y, gy, q, a[1], a[0], bb, 0, p.q16_counts, p.q16_ids, stream, p.table);
@@ -1260,7 +1287,7 @@ static int shard_z_records(float *d_records, int64_t sx, int64_t sy_local, int64
   if (w3 != nullptr) {
     float q = 1.0f;
     uint32_t a[3];
-    if (!(g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x400000)) && q16_quantum(w3, 3, &q, a) &&
+    if (!(g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000)) && q16_quantum(w3, 3, &q, a) &&
         column_pass_q16_supported(gz) && column_pass_wave_supported(gz) && (reinterpret_cast<uintptr_t>(d_records) % 16) == 0) {
       EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, 4 * sizeof(uint32_t), stream));
       rc = launch_column_pass_q16(d_records, nullptr, p.rs_z, gz, q, a[2], a[0], bb, epi, p.q16_counts, p.q16_ids, stream);

@@ -35,17 +35,6 @@ int window_limit() {
   return v;
 }
 
-// Where the bracket path takes over from the windowed path (edt_colwave_lane.h: mono_band): tiles that would need
-// windows of more than this many rows.  EDT_HIP_MONO_FROM overrides the default (experiments).
-int mono_from() {
-  static const int v = [] {
-    const char *e = getenv("EDT_HIP_MONO_FROM");
-    const int t = e ? atoi(e) : 56;
-    return t < 0 ? 0 : (t > 4096 ? 4096 : t);
-  }();
-  return v;
-}
-
 bool column_pass_wave_supported(const AxisGeom &g) {
   // rows in VGPRs: one band per lane, at most 64 bands per column (n <= 2048)
   return g.nbands >= 1 && g.nbands <= 64;

@@ -63,16 +63,11 @@ struct BruteArgs {
   float *compact;
   int64_t c_outer, c_row2;
   int c_al;             // its rows are whole 16-byte granules
-  // the bracket path (edt_colwave_lane.h: mono_band): tiles whose largest field value v satisfies
-  // mono_lo_bits < bits(v) <= mono_hi_bits (mono_hi_bits = 0: never; mono_force: every tile up to mono_hi_bits)
-  uint32_t mono_lo_bits, mono_hi_bits;
-  int mono_force;
   // list mode (nullptr: every tile of the grid): the launch serves the tiles the 16-bit integer kernel handed over
   // (edt_colq16.hip) -- workgroup b takes tile list_ids[b] (already in the XCD-aware order) if b < *list_count
   const uint32_t *list_count, *list_ids;
 };
 int window_limit();  // edt_colwave.hip: largest window (rows) the windowed path is used for
-int mono_from();     // edt_colwave.hip: tiles with windows beyond this many rows take the bracket path (where it applies)
 
 namespace {
 
@@ -173,94 +168,7 @@ __device__ EDT_BRUTE_INLINE void brute_tile(float *tile, const uint32_t *alive, 
   else brute_band<CW, BB, X32, 1>(BL, epi & 0xA03, store);
 }
 
-#ifdef EDT_CONTIG
-// Experiment: the 64 blocks a wave works on at a time are CONTIGUOUS -- lane = column x block, 64 / NBLK
-// columns x the NBLK blocks of ONE band -- and the wave's (band, column) pairs are walked in NBLK groups.  `dst_of(col,
-// band)`: row 0 of the column the lane writes (see the caller).
-template <int CW, bool BB, bool X32, class DstOf>
-__device__ EDT_BRUTE_INLINE void brute_tile_contig(float *tile, const uint32_t *alive, const uint32_t *rsp,
-                                                   const uint32_t *lohi, const uint32_t *bscan, int n, int NB,
-                                                   int cols_left, int wave, int lane, float w, int epi,
-                                                   DstOf &&dst_of, int64_t dstride) {
-  using namespace edt_lane;
-  constexpr int TC = TileGeom<CW>::kCols;
-  const bool s2 = (epi & 0x100) != 0;          // blocks of 16 rows (even rows evaluated): two per band
-  const int nblk = s2 ? 2 : 4, per = 64 / nblk;  // blocks per band, (band, column) pairs per group
-  const int k0 = (lane / per) * (32 / nblk);
-  const bool compact = (epi & 0x400) != 0;
-#pragma unroll 1
-  for (int g = 0; g < nblk; ++g) {
-    const int q = g * per + lane % per;          // this lane's (band, column) pair among the wave's 64
-    const int band = wave * (64 / TC) + q / TC, col = q % TC;
-    BruteLane BL;
-    BL.tile = tile;
-    BL.col = col;
-    BL.band = band;
-    BL.row0 = band * 32;
-    BL.n = n;
-    BL.rsw = rsp[addr_word<CW>(col, band)];
-    BL.brk = alive[addr_word<CW>(col, band)];
-    const uint32_t bs = bscan[addr_word<CW>(col, band)];
-    BL.blo_in = (int)(bs & 0xFFFFu) - 1;
-    BL.bhi_out = (int)(bs >> 16);
-    const uint32_t lh = lohi[addr_word<CW>(col, band)];
-    BL.lo_in = (int)(lh & 0xFFFFu) - 1;
-    BL.hi_out = (int)(lh >> 16) - 1;
-    BL.w2 = (double)(w * w);
-    BL.w2f = w * w;
-    BL.live = col < cols_left && band < NB;
-    const bool colok = col < cols_left;
-    auto *gdst = (__attribute__((address_space(1))) float *)dst_of(col, band);
-    auto store = [&](int row, float v) {
-      if (row < n && colok) gdst[(int64_t)(compact ? row >> 1 : row) * dstride] = v;
-    };
-    if (s2) brute_block<CW, BB, X32, 2>(BL, k0, epi & 0xA03, store);
-    else brute_block<CW, BB, X32, 1>(BL, k0, epi & 0xA03, store);
-  }
-}
-#endif
 
-// The bracket path of one lane (edt_colwave_lane.h: mono_anchor / mono_band) -- EXPERIMENT, compiled into the kernel
-// only with -DEDT_MONO (make VARIANT=mono EXTRA=-DEDT_MONO): bit-exact (GPU parity suite + fuzz under debug bit 0x400000,
-// host emulation in the CPU tier) but not faster than the better of the two shipped forms at any cell size
-// (profiles/r03_mono_v1_*.txt), so the shipped kernels do not carry its code.  The anchors' argmins cross bands
-// through one plane of LDS words (`anchors`: the break-scan plane of the windowed path, unused here) and one
-// workgroup barrier -- every thread of the workgroup takes this path together (the choice is per tile).
-#ifdef EDT_MONO
-template <int CW, bool BB>
-__device__ __forceinline__ void mono_tile(float *tile, const uint32_t *rsp, const uint32_t *lohi, uint32_t *anchors,
-                                          int n, int NB, int cols_left, int band, int col, float w, int epi,
-                                          float *dst0, int64_t dstride) {
-  using namespace edt_lane;
-  MonoLane ML;
-  ML.tile = tile;
-  ML.col = col;
-  ML.band = band;
-  ML.row0 = band * 32;
-  ML.n = n;
-  ML.rsw = rsp[addr_word<CW>(col, band)];
-  const uint32_t lh = lohi[addr_word<CW>(col, band)];
-  ML.lo_in = (int)(lh & 0xFFFFu) - 1;
-  ML.hi_out = (int)(lh >> 16) - 1;
-  ML.w2f = w * w;
-  ML.live = col < cols_left && band < NB;
-  if (!ML.live) ML.rsw = 0;
-  const float Fa = tile[addr_tile<CW>(col, ML.row0)];
-  const float Ba = mono_bound<CW, BB>(ML, 0, Fa);
-  float best0;
-  int A0;
-  mono_anchor<CW>(ML, Ba, Fa, best0, A0);
-  anchors[addr_word<CW>(col, band)] = (uint32_t)A0;
-  __syncthreads();
-  const int A32 = (ML.row0 + 32 < n) ? (int)anchors[addr_word<CW>(col, band + 1)] : n - 1;
-  auto *gdst = (__attribute__((address_space(1))) float *)dst0;
-  const bool colok = col < cols_left;
-  auto store = [&](int row, float v) {
-    if (row < n && colok) gdst[(int64_t)row * dstride] = v;
-  };
-  mono_band<CW, BB>(ML, best0, Ba, A0, A32, epi & 3, store);
-}
-#endif  // EDT_MONO
 
 // The hull path of one lane (phases 1-3 of edt_colwave_lane.h), inlined into the kernel (as a callee it would save
 // and restore 48 callee-saved registers per tile: cfg2 0.69 -> 1.04 ms, measured).  It RE-READS the lane's 32 rows
@@ -551,14 +459,8 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
       bscan[addr_word<CW>(L.colc, L.band)] = (uint32_t)(blo_in + 1) | ((uint32_t)bhi_out << 16);
       __syncthreads();
       const uint32_t tile_max = tmax[0], tile_brk = tmax[1];
-      // three forms: short windows (small fields), brackets (larger fields, exact arithmetic), hulls (the rest)
-#ifdef EDT_MONO
-      const bool mono = ba.mono_hi_bits != 0u && tile_max <= ba.mono_hi_bits &&
-                        (ba.mono_force || (tile_brk != 0u && tile_max > ba.mono_lo_bits));
-#else
-      constexpr bool mono = false;
-#endif
-      if (mono || (tile_max <= ba.limit_bits && (tile_brk != 0u || ba.force))) {
+      // two forms: windows (fields that are small everywhere) or hulls (the rest)
+      if (tile_max <= ba.limit_bits && (tile_brk != 0u || ba.force)) {
         __syncthreads();  // (every thread has read tmax: the padding band it sits in may be filled now)
         // +inf around the columns: the padding bands and the rows that complete the last band
         for (int i = (int)threadIdx.x; i < 32 * TC; i += (int)blockDim.x)
@@ -583,31 +485,8 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
           }
         }
         // (bit 9, diagnostics: debug bit 0x80000 = no window at all, i.e. the fixed cost of the path; wrong results)
-#ifdef EDT_MONO
-        if (mono) {
-          mono_tile<CW, BB>(tile, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi, dst0, dstep);
-          return;
-        }
-#endif
         const int epi_s = epi | (ba.stride == 2 ? 0x100 : 0) | (EDT_DIAG_BITS(dbg, 0x80000) ? 0x200 : 0) | (compact ? 0x400 : 0) |
                           (ba.x32 == 2 ? 0x800 : 0);
-#ifdef EDT_CONTIG
-        {
-          // (the same destinations as dst0 above, as a function of the (column, band) pair a lane works on)
-          auto dst_of = [&](int c, int b) -> float * {
-            if constexpr (SC) {
-              const int bb2 = b < BandScatter::kBands ? b : 0;
-              return scatter->rows[bb2] + o * scatter->ostride[bb2] + x0 + c - (int64_t)b * 32 * st;
-            } else {
-              if (ba.compact != nullptr) return ba.compact + x0 + c + o * ba.c_outer;
-              return Ftile + c;
-            }
-          };
-          if (ba.x32) brute_tile_contig<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, wave, lane, w, epi_s, dst_of, dstep);
-          else brute_tile_contig<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, wave, lane, w, epi_s, dst_of, dstep);
-          return;
-        }
-#endif
         if (ba.x32) brute_tile<CW, BB, true>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
         else brute_tile<CW, BB, false>(tile, alive, rsp, lohi, bscan, n, NB, cols_left, band2, col2, w, epi_s, dst0, dstep);
         return;
@@ -723,19 +602,8 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
     ba.force = force ? 1 : 0;
     if (T < 1) ba.limit_bits = 0u;
   }
-  // The bracket path (edt_colwave_lane.h: mono_limits has the conditions).  (debug bits: 0x800000 never, 0x400000
-  // every tile the exactness conditions allow, whatever its windows.)
-  ba.mono_lo_bits = ba.mono_hi_bits = 0u;
-  ba.mono_force = 0;
   ba.list_count = list.count;
   ba.list_ids = list.ids;
-#ifdef EDT_MONO
-  if (!(debug_mode() & 0x800000) && ba.stride == 1 && ba.compact == nullptr &&
-      edt_lane::mono_limits(w, (int)g.n, mono_from(), ba.mono_lo_bits, ba.mono_hi_bits)) {
-    ba.mono_force = (debug_mode() & 0x400000) ? 1 : 0;
-    if (ba.mono_hi_bits <= ba.mono_lo_bits && !ba.mono_force) ba.mono_hi_bits = 0u;
-  }
-#endif
   static std::atomic<uint64_t> attr_done{0};  // per instantiation, one bit per device
   EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_wave<CW, BB, XF, SC>)));
   const int64_t tiles_x = ceil_div(g.sx, TC);

@@ -788,28 +788,10 @@ struct BruteSteps {
       const double c1 = w2 * (double)(D * D), c2 = w2 * (double)((D + 1) * (D + 1));
       if (X32 ? !EDT_ANY(c1f < bmaxf) : !EDT_ANY(c1 < bmax64)) return;
       // the rows that enter the window in these two steps
-#ifdef EDT_CONTIG
-      // k0 differs from lane to lane (brute_block): the window leaves the lane's band at a step that does too -- but only
-      // at d = k0 + 1 below and d = 33 - NR - k0 above, both congruent to 1 (mod 8): four static steps where the pointer of
-      // either side moves to the neighbouring band by a per-lane select (PL0 / PH0 hold the CURRENT pointers)
-      if constexpr (D % 8 == 1) {
-        // (the neighbouring bands' addresses are rebuilt here rather than kept alive across the block: the kernel has
-        // no registers to spare)
-        const float *below = L.tile + addr_tile<CW>(L.col, L.row0 - 32) + (k0 + 32 - K) * TC;
-        const float *above = L.tile + addr_tile<CW>(L.col, L.row0 + 32) + (k0 + NR - 1 - 32) * TC;
-        PL0 = (k0 == D - 1) ? below : PL0;
-        PH0 = (k0 == 33 - NR - D) ? above : PH0;
-      }
-      w[K - D] = PL0[(K - D) * TC];
-      w[K + NR - 1 + D] = PH0[D * TC];
-      w[K - D - 1] = PL0[(K - D - 1) * TC];
-      w[K + NR + D] = PH0[(D + 1) * TC];
-#else
       w[K - D] = (D <= k0 ? PL0 : PL1)[(K - D) * TC];
       w[K + NR - 1 + D] = (D <= 32 - NR - k0 ? PH0 : PH1)[D * TC];
       w[K - D - 1] = (D + 1 <= k0 ? PL0 : PL1)[(K - D - 1) * TC];
       w[K + NR + D] = (D + 1 <= 32 - NR - k0 ? PH0 : PH1)[(D + 1) * TC];
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -1075,317 +1057,6 @@ EDT_LANE void brute_band(const BruteLane &L, int epi, Store &&store) {
   }
 }
 
-#ifdef EDT_CONTIG
-// One block of a lane, the block's position k0 inside the band being the LANE's own (experiment, DESIGN.md 7.1: a wave
-// then works on 64 CONTIGUOUS blocks -- 16 columns x the four blocks of one band -- whose windows are alike, instead of
-// block k of bands 32 rows apart).  Same arithmetic as brute_band's loop body; what was carried from block to block (the
-// distance of the row before the block to its run start) is computed from the run-start word, and the window's band
-// crossings are per-lane selects (BruteSteps, EDT_CONTIG).
-template <int CW, bool BB, bool X32, int S, class Store>
-EDT_LANE void brute_block(const BruteLane &L, int k0, int epi, Store &&store) {
-  constexpr int K = kBruteK, B = kBruteB, TC = TileGeom<CW>::kCols, NR = S * B;
-  const int row0 = L.row0, n = L.n;
-  const uint32_t rsw = L.rsw;
-  const float *A0 = L.tile + addr_tile<CW>(L.col, row0);
-  const float *Am = L.tile + addr_tile<CW>(L.col, row0 - 32);
-  const float *Ap = L.tile + addr_tile<CW>(L.col, row0 + 32);
-  const int nb32 = ((n + 31) >> 5) << 5;
-  // distance of the row before the block to the row before ITS run (+inf: that run has no border below)
-  float dl;
-  {
-    const uint32_t lowm = k0 > 0 ? rsw & (0xFFFFFFFFu >> (32 - k0)) : 0u;  // run starts at rows < k0 of this band
-    const int s = lowm ? row0 + 31 - clz32(lowm) : L.lo_in;                 // first row of the run of row p0 - 1
-    dl = (BB || s > 0) ? (float)(row0 + k0 - s) : INFINITY;
-  }
-  float w[NR + 2 * K];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-  for (int j = 0; j < NR; ++j) w[K + j] = A0[(k0 + j) * TC];
-  const float *PL0 = A0 + (k0 - K) * TC, *PL1 = Am + (k0 + 32 - K) * TC;
-  const float *PH0 = A0 + (k0 + NR - 1) * TC, *PH1 = Ap + (k0 + NR - 1 - 32) * TC;
-  const uint32_t s8 = rsw >> k0;
-  float dlv[B];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-  for (int j = 0; j < NR; ++j) {
-    const float first = (BB || j > 0) ? 1.0f : (row0 + k0 > 0 ? 1.0f : INFINITY);
-    dl = ((s8 >> j) & 1u) ? first : dl + 1.0f;
-    if (j % S == 0) dlv[j / S] = dl;
-  }
-  float dr;
-  {
-    const uint32_t m = k0 + NR < 32 ? rsw & (0xFFFFFFFFu << (k0 + NR)) : 0u;
-    const int e = m ? row0 + ctz32(m) : L.hi_out + 1;
-    dr = (BB || e < n) ? (float)(e - (row0 + k0 + NR)) : INFINITY;
-  }
-  float best[B];
-  double best64[B];
-  uint32_t bmax = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-  for (int j = NR - 1; j >= 0; --j) {
-    dr += 1.0f;
-    if (j % S == 0) {
-      const int i = j / S;
-      const float dm = minpos(dlv[i], dr);
-      const float bord = L.w2f * (dm * dm);
-      float b = minpos(w[K + j], bord);
-      if (f2u(w[K + j]) == 0x7f800000u || !L.live) b = 0.0f;
-      best[i] = b;
-      if (!X32) best64[i] = (double)b;
-      const uint32_t ub = f2u(b);
-      bmax = ub > bmax ? ub : bmax;
-    }
-    if ((s8 >> j) & 1u) dr = 0.0f;
-  }
-  const float bmaxf = u2f(bmax);
-  const double bmax64 = (double)bmaxf;
-  bool open = true;
-  {
-    const int D = brute_flat_reach(L, k0, NR);
-    const double cD = L.w2 * (double)((D + 1) * (D + 1));
-    if (!EDT_ANY(cD < bmax64)) open = false;
-  }
-  if (open) {
-    float w2f = L.w2f;
-    double w2 = L.w2;
-    EDT_OPAQUE(w2f);
-    EDT_OPAQUE(w2);
-    BruteSteps<CW, X32, S> steps{L, w, best, best64, PL0, PL1, PH0, PH1, k0, bmaxf, bmax64, nb32, w2f, w2,
-                                  (epi & 0x800) ? 1u : 0u};
-    steps.template run<1>();
-  }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-  for (int i = 0; i < B; ++i) {
-    float r = X32 ? best[i] : (float)best64[i];
-    if ((epi & kLaneEpiToInf) && r >= 3.402823466e+38f) r = INFINITY;
-    best[i] = r;
-  }
-  if (epi & kLaneEpiSqrt) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int i = 0; i < B; ++i) best[i] = sqrtf(best[i]);
-  }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-  for (int i = 0; i < B; ++i) store(row0 + k0 + S * i, best[i]);
-}
-#endif  // EDT_CONTIG
-
-// ---------------------------------------------------------------------------------------
-// The bracket path ("mono"): tiles whose field is too large for short windows but whose arithmetic is exact.
-//
-// As in the windowed path, result[p] = min(B_p, G[p]) with B_p = min(F[p], border parabolas) and
-//     G[p] = min over ALL rows j of the column of  M[p][j] = c_|p-j| + F[j]
-// (rows outside p's run and the +inf rows around the column are harmless candidates, see above).  The matrix M is
-// strictly Monge -- M[q][j2] - M[q][j1] = M[p][j2] - M[p][j1] - 2*w2*(q-p)*(j2-j1) for q > p, j2 > j1 -- so every
-// minimiser of a row p lies at or after every minimiser of an earlier row and at or before every minimiser of a later
-// one: once rows a < b are done, a row between them only needs the candidates A(a) .. A(b) between their argmins
-// (ANY argmin serves as either end).  The cost of a row is then the length of its bracket, not the window: the
-// brackets of the rows of one level tile the column.  Levels, lane = (column, band of 32 rows):
-//   0  the band's first row ("anchor"): the window search of the windowed path for ONE row, with its argmin
-//      (mono_anchor); the anchors' argmins travel through one plane of LDS words,
-//   1  row 16 between this band's anchor and the next one's,   2  rows 8 and 24,
-//   3  the four gaps of seven rows between those, all seven rows of a gap against the gap's bracket at once.
-// Rows whose envelope value cannot beat B_p are the only ones a truncated search may get "wrong" (an anchor's window
-// ends once c_d >= min(B_a, best): candidates beyond it lie beyond a border site of every row that could want them),
-// and their result is B_p either way -- the argument is spelled out in DESIGN.md.
-//
-// Exactness: the path is only taken where every candidate value is computed without rounding that could reorder
-// candidates: c_d exactly representable in fp32 for every d it can meet (brute_exact_prefix), and field values below
-// 2^23 * w2 (one ulp of any candidate is then at most w2 < 2*w2 = the least amount by which the order of two
-// candidates changes from one row to the next).  The host (launcher) turns both into the bit pattern of the largest
-// tile maximum the path accepts.  c_d and its first differences are updated by exact fp32 additions.
-// ---------------------------------------------------------------------------------------
-struct MonoLane {
-  const float *tile;  // LDS tile, row 0 (one band of +inf rows on either side; rows >= n are +inf)
-  int col, band, row0, n;
-  uint32_t rsw;       // run-start bits of the band
-  int lo_in, hi_out;  // as in Lane
-  bool live;          // the lane has a column and the band has rows
-  float w2f;
-};
-
-// B_p of row r (relative) of the band: the row's own value and the parabolas of height 0 just outside its run
-template <int CW, bool BB>
-EDT_LANE float mono_bound(const MonoLane &L, int r, float Fp) {
-  const int p = L.row0 + r;
-  const uint32_t lowm = L.rsw & (0xFFFFFFFFu >> (31 - r));
-  const int s = lowm ? L.row0 + 31 - clz32(lowm) : L.lo_in;             // first row of p's run
-  const uint32_t him = r < 31 ? (L.rsw & (0xFFFFFFFEu << r)) : 0u;
-  const int e = him ? L.row0 + ctz32(him) - 1 : L.hi_out;                // last row of p's run
-  float dm = INFINITY;
-  if (BB || s > 0) dm = (float)(p - s + 1);
-  if (BB || e < L.n - 1) dm = fminf(dm, (float)(e + 1 - p));
-  return minpos(Fp, L.w2f * (dm * dm));  // (+inf * +inf = +inf: no border at all)
-}
-
-// Level 0: the band's first row a.  Returns G-or-bound information in `best` (the least candidate met, the row's own
-// value included) and its row in `arg`.  The loop runs for the whole wave until c_d >= min(B_a, best) for every lane.
-template <int CW>
-EDT_LANE void mono_anchor(const MonoLane &L, float Ba, float Fa, float &best, int &arg) {
-  constexpr int TC = TileGeom<CW>::kCols;
-  const int a = L.row0;
-  const int nb32 = ((L.n + 31) >> 5) << 5;
-  best = Fa;
-  int off = 0;
-  float bnd = L.live ? minpos(Ba, Fa) : 0.0f;
-#if defined(EDT_MONO_SKIP) && (EDT_MONO_SKIP & 1)
-  bnd = 0.0f;  // (cost measurement: no anchor search; wrong results)
-#endif
-  // (rows a - d, a + d for d <= 32 exist in the LDS image whatever a is: one band of +inf rows on either side)
-  const float *P = L.tile + addr_tile<CW>(L.col, a);
-  const float *Pm = L.tile + addr_tile<CW>(L.col, a - 32);  // the band below (its own column rotation)
-  float c = L.w2f, g = 3.0f * L.w2f;  // c_1 and c_2 - c_1 (exact)
-  const float g2 = L.w2f + L.w2f;
-  int d = 1;
-  for (; d <= 32; ++d) {
-    if (!EDT_ANY(c < bnd)) break;
-    const float flo = Pm[(32 - d) * TC], fhi = d < 32 ? P[d * TC] : L.tile[addr_tile<CW>(L.col, a + 32)];
-    const float m = minpos(flo, fhi);
-    const float cand = m + c;
-    const bool win = f2u(cand) < f2u(best);
-    const int side = f2u(flo) <= f2u(fhi) ? -d : d;
-    best = minpos(best, cand);
-    bnd = minpos(bnd, cand);
-    off = win ? side : off;
-    c += g;
-    g += g2;
-  }
-  if (d > 32) {
-    for (;; ++d) {
-      if (!EDT_ANY(c < bnd)) break;
-      int rl = a - d, rh = a + d;
-      rl = rl < -1 ? -1 : rl;        // rows -1 and nb32 are +inf rows
-      rh = rh > nb32 ? nb32 : rh;
-      const float flo = L.tile[addr_tile<CW>(L.col, rl)], fhi = L.tile[addr_tile<CW>(L.col, rh)];
-      const float m = minpos(flo, fhi);
-      const float cand = m + c;
-      const bool win = f2u(cand) < f2u(best);
-      const int side = f2u(flo) <= f2u(fhi) ? -d : d;
-      best = minpos(best, cand);
-      bnd = minpos(bnd, cand);
-      off = win ? side : off;
-      c += g;
-      g += g2;
-    }
-  }
-  arg = a + off;
-  // (a clamped far row is a +inf row: it never wins, so arg is a real row or a itself)
-}
-
-// One row p against the candidates lo .. hi (rows of the column, lo <= hi): least value (the incoming best included)
-// and its row.  Per-lane trip counts: the loop is an ordinary divergent one.
-template <int CW>
-EDT_LANE void mono_row(const MonoLane &L, int p, int lo, int hi, float &best, int &arg) {
-  // c = w2 * (p - j)^2 and its difference to the next candidate, stepped exactly: g = c_(j+1) - c_j = w2 * (1 - 2*(p - j))
-  const float dj = (float)(p - lo);
-  float c = L.w2f * (dj * dj);
-  float g = L.w2f * (1.0f - (dj + dj));
-  const float g2 = L.w2f + L.w2f;
-  for (int j = lo; j <= hi; ++j) {
-    const float F = L.tile[addr_tile<CW>(L.col, j)];
-    const float cand = F + c;
-    const bool win = f2u(cand) < f2u(best);
-    best = minpos(best, cand);
-    arg = win ? j : arg;
-    c += g;
-    g += g2;
-  }
-}
-
-// Seven rows p0+1 .. p0+7 (best[0..6]) against the candidates lo .. hi, no argmin.
-template <int CW>
-EDT_LANE void mono_gap(const MonoLane &L, int p0, int lo, int hi, float *best) {
-  float d[8];  // d[i] = (p0 + 1 + i) - j as a float (|d| < 2^12), stepped by -1 per candidate
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-  for (int i = 0; i < 8; ++i) d[i] = (float)(p0 + 1 + i - lo);
-  for (int j = lo; j <= hi; ++j) {
-    const float F = L.tile[addr_tile<CW>(L.col, j)];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int i = 0; i < 7; ++i) {
-      // fl32(w2 * d^2 + F): the product is exact (c_d is representable), one rounding -- the same value as c_d + F
-      const float cand = fmaf(L.w2f, d[i] * d[i], F);
-      best[i] = minpos(best[i], cand);
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int i = 0; i < 8; ++i) d[i] -= 1.0f;
-  }
-}
-
-// Levels 1-3 of one lane's band.  A0 / A32: argmins of this band's anchor and of the next band's (n - 1 where there
-// is none); best0 = the anchor's least candidate.  store(row, value) takes the finished rows.
-template <int CW, bool BB, class Store>
-EDT_LANE void mono_band(const MonoLane &L, float best0, float B0, int A0, int A32, int epi, Store &&store) {
-  constexpr int TC = TileGeom<CW>::kCols;
-  const int row0 = L.row0, n = L.n;
-  const float *own = L.tile + addr_tile<CW>(L.col, row0);
-  auto done = [&](int r, float v, float B) {
-    v = minpos(v, B);
-    store(row0 + r, finish_f(v, epi));
-  };
-  if (!L.live) return;
-  done(0, best0, B0);
-  // (rows beyond the column do not exist: nothing is computed for them and their "argmin" is the last row)
-  auto level_row = [&](int r, int lo, int hi) -> int {
-    if (row0 + r >= n) return n - 1;
-#if defined(EDT_MONO_SKIP) && (EDT_MONO_SKIP & 2)
-    hi = lo;  // (cost measurement: one candidate per level row; wrong results)
-#endif
-    const float Fp = own[r * TC];
-    float best = Fp;
-    int arg = row0 + r;
-    mono_row<CW>(L, row0 + r, lo, hi, best, arg);
-    done(r, best, mono_bound<CW, BB>(L, r, Fp));
-    return arg;
-  };
-  // (an inverted bracket can only come from rows whose value is their bound anyway: order the ends)
-  auto lo_of = [](int x, int y) { return x < y ? x : y; };
-  auto hi_of = [](int x, int y) { return x < y ? y : x; };
-  const int A16 = level_row(16, lo_of(A0, A32), hi_of(A0, A32));
-  const int A8 = level_row(8, lo_of(A0, A16), hi_of(A0, A16));
-  const int A24 = level_row(24, lo_of(A16, A32), hi_of(A16, A32));
-  // (written out four times: the argmins stay in registers, no indexed array)
-  auto gap = [&](int q, int Alo, int Ahi) {
-    const int p0 = row0 + 8 * q;
-    if (p0 + 1 >= n) return;
-    float best[7], Fp[7];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int i = 0; i < 7; ++i) {
-      Fp[i] = own[(8 * q + 1 + i) * TC];
-      best[i] = Fp[i];
-    }
-#if defined(EDT_MONO_SKIP) && (EDT_MONO_SKIP & 4)
-    mono_gap<CW>(L, p0, lo_of(Alo, Ahi), lo_of(Alo, Ahi), best);  // (cost measurement: one candidate per gap)
-#else
-    mono_gap<CW>(L, p0, lo_of(Alo, Ahi), hi_of(Alo, Ahi), best);
-#endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int i = 0; i < 7; ++i)
-      if (p0 + 1 + i < n) done(8 * q + 1 + i, best[i], mono_bound<CW, BB>(L, 8 * q + 1 + i, Fp[i]));
-  };
-  gap(0, A0, A8);
-  gap(1, A8, A16);
-  gap(2, A16, A24);
-  gap(3, A24, A32);
-}
 
 // The largest D <= want such that c_d = w2 * d^2 is exactly representable in fp32 for every d <= D (then the
 // candidates of the windowed path may be fp32 sums up to windows of D rows).
@@ -1426,34 +1097,6 @@ inline int brute_f32e_prefix(float w, float fmin, int want) {
   int T = want > 4095 ? 4095 : want;                             // (d^2 as an exact float: d < 4096)
   while (T > 0 && !(2.0 * (double)w2f * (double)T * (double)T < cap)) --T;
   return T;
-}
-
-// Which tiles may take the bracket path (mono_band), as bit patterns of the tile's largest field value v:
-// lo_bits < bits(v) <= hi_bits.  A tile whose largest value is at most c_T never looks further than T + 32 rows (the
-// anchors' windows end by T, a bracket reaches at most one band beyond an anchor's argmin), so T = (largest d with
-// c_d exact in fp32) - 33; values below 2^23 * w2 keep one ulp of every candidate (field + c_(T+32)) at or below w2,
-// less than the 2 * w2 by which the order of two candidates moves from row to row.  `from`: tiles with windows of
-// up to that many rows stay on the windowed path.  Returns false (hi_bits = 0) where the path never applies.
-inline bool mono_limits(float w, int n, int from, uint32_t &lo_bits, uint32_t &hi_bits) {
-  lo_bits = hi_bits = 0u;
-  if (!(w * w >= 1.17549435e-38f) || !((double)w * (double)w < 1.0e30)) return false;
-  const int T = brute_exact_prefix(w, n + 64) - 33;
-  if (T < 48) return false;
-  const double w2 = (double)(w * w);
-  double hi = w2 * (double)T * (double)T;
-  const double mag = w2 * 8388608.0 - w2 * (double)(T + 32) * (double)(T + 32);
-  if (mag < hi) hi = mag;
-  auto bits_below = [](double v) -> uint32_t {
-    if (!(v > 0.0)) return 0u;
-    float f = v < 3.0e38 ? (float)v : 3.0e38f;
-    if ((double)f > v) f = nextafterf(f, 0.0f);
-    uint32_t b;
-    memcpy(&b, &f, 4);
-    return b;
-  };
-  hi_bits = bits_below(hi);
-  lo_bits = bits_below(w2 * (double)from * (double)from);
-  return hi_bits != 0u;
 }
 
 }  // namespace edt_lane

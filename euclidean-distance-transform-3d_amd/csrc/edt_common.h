@@ -33,8 +33,8 @@ void set_error(const std::string &msg);
 //   0x1000        name every pass on stderr                      0x2000    no tile takes the windowed path
 //   0x4000        every tile takes the windowed path             0x8000    fp64 candidates on the windowed path
 //   0x20000       voxel graph: up-sampled formulation            0x100000  fp32 form of pass X (no 16-bit indices)
-//   0x200000      voxel graph: separate gather pass              0x400000  every tile takes the bracket path (where exact)
-//   0x800000      no tile takes the bracket path                 0x1000000 short axes (<= 32 rows) stay on the wave kernel
+//   0x200000      voxel graph: separate gather pass              0x400000, 0x800000  (round 3's bracket-path experiment: no effect
+//                 now, experiments/colwave_r03)                  0x1000000 short axes (<= 32 rows) stay on the wave kernel
 //   0x2000000     inexact voxel sizes: fp64 candidates even where fp32 fma candidates are exact
 //   0x4000000     rows of 1025..2048 voxels: the workgroup-phased kernel of pass X, not the two-wave form
 //   0x8000000     no 16-bit integer column kernel (edt_colq16.hip): every tile on the fp32 kernels

@@ -25,53 +25,52 @@
 namespace edt_amd {
 
 // ------------------------------------------------------------------------------------
-// Pass 1, one thread per row (fallback for very long rows).  Same recurrences as the
-// reference's sweeps (src/edt.hpp:83-118) so that fp32 rounding is identical.
+// Pass 1, one thread per row, RUN BY RUN (size-agnostic fallback: EDT_FLAG_FORCE_GENERIC, 1-D calls without a
+// workspace).  A voxel's value is fl32(T[k]^2): T[k] the k-fold sequential fp32 sum of w (what the reference's two
+// sweeps accumulate, src/edt.hpp:83-114), k its distance in voxels to the nearer end of its run that has a border (a
+// label change, or the row's end with black_border); T is non-decreasing, so the minimum of the two sweeps is the value at
+// the smaller index.  The thread finds a maximal run [s, e] and fills it from its bordered end(s) inwards with ONE running
+// sum -- no forward / backward sweep over the row, no second visit of a voxel.
 // ------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_row_pass_serial(const T *__restrict__ labels, float *__restrict__ out,
-                                  int64_t sx, int64_t nrows, float w, int bb, int to_finite,
-                                  int take_sqrt) {
+__global__ void k_row_pass_runs(const T *__restrict__ labels, float *__restrict__ out,
+                                int64_t sx, int64_t nrows, float w, int bb, int to_finite,
+                                int take_sqrt) {
   const int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (row >= nrows) return;
   const T *seg = labels + row * sx;
   float *d = out + row * sx;
-
-  T current = seg[0];
-  T before = current;
-  float run = bb ? (float)(current != 0) * w : (current == 0 ? 0.0f : INFINITY);
-  d[0] = run;
-  for (int64_t i = 1; i < sx; ++i) {
-    const T here = seg[i];
-    if (here == 0) {
-      run = 0.0f;
-    } else if (here == current) {
-      run = run + w;
+  auto value = [&](float t) {
+    float v = t * t;                                   // `d[i] *= d[i]` (src/edt.hpp:116-118)
+    if (to_finite && isinf(v)) v = FLT_MAX;            // tofinite (src/edt.hpp:39-45)
+    return take_sqrt ? sqrtf(v) : v;
+  };
+  int64_t s = 0;
+  while (s < sx) {
+    const T lab = seg[s];
+    int64_t e = s;
+    while (e + 1 < sx && seg[e + 1] == lab) ++e;
+    const int64_t len = e - s + 1;
+    if (lab == 0) {
+      for (int64_t i = s; i <= e; ++i) d[i] = 0.0f;
     } else {
-      run = w;
-      d[i - 1] = (float)(before != 0) * w;
-      current = here;
+      const bool left = bb || s > 0, right = bb || e < sx - 1;
+      if (!left && !right) {
+        const float v = value(INFINITY);               // a row inside one label: no boundary at all
+        for (int64_t i = s; i <= e; ++i) d[i] = v;
+      } else {
+        // j-th voxel from a bordered end: T[j + 1]; with both borders the two fills meet in the middle
+        const int64_t count = (left && right) ? (len + 1) / 2 : len;
+        float t = 0.0f;
+        for (int64_t j = 0; j < count; ++j) {
+          t = t + w;
+          const float v = value(t);
+          if (left) d[s + j] = v;
+          if (right) d[e - j] = v;
+        }
+      }
     }
-    d[i] = run;
-    before = here;
-  }
-  int64_t lo = 0;
-  if (bb) {
-    d[sx - 1] = (float)(seg[sx - 1] != 0) * w;
-    lo = 1;
-  }
-  float next = d[sx - 1];
-  for (int64_t i = sx - 2; i >= lo; --i) {
-    const float v = fminf(d[i], next + w);
-    d[i] = v;
-    next = v;
-  }
-  for (int64_t i = 0; i < sx; ++i) {
-    float v = d[i];
-    v = v * v;
-    if (to_finite && isinf(v)) v = FLT_MAX;
-    if (take_sqrt) v = sqrtf(v);
-    d[i] = v;
+    s = e + 1;
   }
 }
 
@@ -80,7 +79,7 @@ static int launch_row_serial_t(const void *labels, float *out, int64_t sx, int64
                                int bb, int to_finite, int take_sqrt, hipStream_t stream) {
   const int threads = 64;
   const int64_t blocks = ceil_div(nrows, threads);
-  hipLaunchKernelGGL(k_row_pass_serial<T>, dim3((unsigned)blocks), dim3(threads), 0, stream,
+  hipLaunchKernelGGL(k_row_pass_runs<T>, dim3((unsigned)blocks), dim3(threads), 0, stream,
                      (const T *)labels, out, sx, nrows, w, bb, to_finite, take_sqrt);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;

@@ -22,6 +22,7 @@
 // tested on a one-GPU box.  Volumes the slab-record form does not cover (sx, sy or sz > 2048, fewer y words or
 // z slices than devices): edt_hip_edt3dsq_multi reports EDT_ERR_UNSUPPORTED (query: edt_hip_multi_supported); the
 // edt_hip_set_devices route runs them on the first listed device and says so once on stderr.
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
@@ -39,7 +40,7 @@ struct Barrier {  // (C++17: no std::barrier).  abort() releases every waiter, n
   std::mutex m;
   std::condition_variable cv;
   int count, waiting = 0, phase = 0;
-  bool broken = false;
+  std::atomic<bool> broken{false};  // (also read outside the mutex, by the launching thread after the join)
   explicit Barrier(int n) : count(n) {}
   bool wait() {
     std::unique_lock<std::mutex> lk(m);

@@ -29,6 +29,7 @@
 #endif
 
 EDT_HD float edt_seq_sum_at(float w, int64_t k) {
+  if (w < 0.0f) return -edt_seq_sum_at(-w, k);  // (round-to-nearest is symmetric: the sums of -w are the negated sums of w)
   float t = 0.0f;
   int64_t done = 0;
   while (done < k) {
@@ -36,6 +37,24 @@ EDT_HD float edt_seq_sum_at(float w, int64_t k) {
     t = t + w;
     ++done;
     if (done >= k) break;
+    // voxel sizes the jump conditions below can never serve -- NaN, +-inf, zero, negative, subnormal sums -- would walk the
+    // whole line one addition at a time (a thread per chunk, each k0 steps: 2^31-voxel lines would take hours).  Their
+    // sums are fixed points or settle at once: NaN and inf stay, a zero step adds nothing; negative and subnormal steps
+    // are walked only while the sum still moves in whole steps (the sequential loop below is exact for them).
+    if (!(t == t) || t - t != 0.0f) return t;        // NaN or +-inf: every further sum is the same value
+    if (w == 0.0f) return t;
+    if (t < 2.3509887e-38f && w < 2.3509887e-38f) {
+      // below 2^-125 every value is a multiple of the smallest subnormal and the additions are exact: jump to just
+      // below that bound in one go
+      const double room = (2.350988701644575e-38 - (double)t) / (double)w;
+      int64_t j = room > 4.0e18 ? (int64_t)4000000000000000000ll : (int64_t)room - 1;
+      if (j > k - done) j = k - done;
+      if (j > 0) {
+        t = (float)((double)t + (double)j * (double)w);  // exact
+        done += j;
+        continue;
+      }
+    }
     const float t1 = t + w;
     const float t2 = t1 + w;
     const float d1 = t1 - t, d2 = t2 - t1;
@@ -45,7 +64,7 @@ EDT_HD float edt_seq_sum_at(float w, int64_t k) {
     (void)frexpf(t, &e0);
     (void)frexpf(t2, &e2);
     // steady only if the two increments agree, all three values share a binade, and that binade has normal ulps
-    if (d1 != d2 || e0 != e2 || e0 < -100 || !(t > 0.0f)) continue;
+    if (d1 != d2 || e0 != e2 || e0 < -125 || !(t > 0.0f)) continue;  // (e0 >= -125: ulps of 2^-149 and up, exact in fp64)
     // values are multiples of u = 2^(e0-24); steps left strictly inside the binade [2^(e0-1), 2^e0):
     const double u = ldexp(1.0, e0 - 24);
     const int64_t A = (int64_t)((ldexp(1.0, e0) - (double)t) / u);   // exact: both are multiples of u, quotient < 2^24

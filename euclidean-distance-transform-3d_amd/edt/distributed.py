@@ -155,9 +155,14 @@ class ShardedEDT:
     with ``gather_back=True`` -- its original Z-slab of the result.
     """
 
-    def __init__(self, extents_xyz, code: int, group=None, ops=None, records=None, chunks=None):
+    def __init__(self, extents_xyz, code: int, group=None, ops=None, records=None, chunks=None, reuse_output=False):
         """records: None = use the slab-record form whenever it applies, False = never (the
-        byte-flag form).  chunks: z-chunks per slab in the record form (default 4 when world > 1)."""
+        byte-flag form).  chunks: z-chunks per slab in the record form (default 4 when world > 1).
+        reuse_output: the record form keeps ONE receive buffer between calls -- the view run() returns is then only valid
+        until the next run() of this plan (what a loop that consumes every result wants: no allocation per step)."""
+        self.reuse_output = bool(reuse_output)
+        self._dst = None
+        self._halo_buf = None
         self.sx, self.sy, self.sz = (int(e) for e in extents_xyz)
         self.code = code
         self.group = group
@@ -222,15 +227,22 @@ class ShardedEDT:
             ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(peer), self.group))
         return _Transfers(dist.batch_isend_irecv(ops) if ops else [], post)
 
-    def _halo(self, labels):
-        """One-slice label halo: receive the previous rank's last slice, send ours onward."""
+    def _halo_start(self, labels):
+        """One-slice label halo: receive the previous rank's last slice, send ours onward.  Enqueue only: returns
+        (halo buffer | None, transfers to wait for before the buffer is read)."""
         sends, recvs, halo = [], [], None
         if self.rank + 1 < self.world:
             sends.append((labels[-1], self.rank + 1))
         if self.rank > 0:
-            halo = torch.empty_like(labels[0])
+            halo = self._halo_buf
+            if halo is None or halo.shape != labels[0].shape or halo.dtype != labels.dtype or halo.device != labels.device:
+                halo = self._halo_buf = torch.empty_like(labels[0])
             recvs.append((halo, self.rank - 1))
-        self._p2p(sends, recvs).wait()
+        return halo, self._p2p(sends, recvs)
+
+    def _halo(self, labels):
+        halo, req = self._halo_start(labels)
+        req.wait()
         return halo
 
     def _reshard(self, slab_list, to_y: bool):
@@ -281,13 +293,19 @@ class ShardedEDT:
         c0, c1 = balanced_partition(ze - zs, self.nchunks)[k]
         return zs + c0, zs + c1
 
-    def _run_records(self, labels, w, flags, sqrt, halo):
-        """Slab-record form: chunked XY phase with the exchange of chunk k under chunk k+1."""
+    def _run_records(self, labels, w, flags, sqrt, halo, halo_req=None):
+        """Slab-record form: chunked XY phase with the exchange of one chunk under the kernels of the next.  The chunks are
+        taken TOP-DOWN: only the slab's first chunk needs the neighbour's slice (halo, in flight: halo_req), and it runs
+        last -- the halo exchange is off the critical path whenever there is more than one chunk."""
         zs, ze = self.local_z()
         ys, ye = self.local_y()
         rec = [self.ops.record_floats(self.sx, b - a) for a, b in self.yparts]
         y_splits = [a for a, _ in self.yparts] + [self.sy]
-        dst = torch.empty((self.sz, rec[self.rank]), dtype=torch.float32, device=labels.device)
+        dst = self._dst if self.reuse_output else None
+        if dst is None or tuple(dst.shape) != (self.sz, rec[self.rank]) or dst.device != labels.device:
+            dst = torch.empty((self.sz, rec[self.rank]), dtype=torch.float32, device=labels.device)
+            if self.reuse_output:
+                self._dst = dst
         pending = []
         # On the GPU consecutive chunks alternate between two side streams (each with its own scratch):
         # pass 1 of chunk k+1 fills the tail of chunk k's Y pass, and every exchange is ordered after
@@ -300,13 +318,19 @@ class ShardedEDT:
             side = self._streams
             for st in side:
                 st.wait_stream(main)
-        for k in range(self.nchunks):
+        for i, k in enumerate(reversed(range(self.nchunks))):
+            # (a later chunk continues this slab: the slice below it; the first one: the neighbour's slice, which has had
+            # the other chunks' kernels to arrive -- waited for on the stream that reads it)
+            h = halo if k == 0 else labels[self._chunk(self.rank, k)[0] - zs - 1]
             if side is not None:
-                with torch.cuda.stream(side[k % len(side)]):
-                    self._records_chunk(k, labels, halo, w, flags, rec, y_splits, dst, pending, k % len(side))
+                with torch.cuda.stream(side[i % len(side)]):
+                    if k == 0 and halo_req is not None:
+                        halo_req.wait()
+                    self._records_chunk(k, labels, h, w, flags, rec, y_splits, dst, pending, i % len(side))
             else:
-                self._records_chunk(k, labels, halo, w, flags, rec, y_splits, dst, pending, None)
-            halo = labels[self._chunk(self.rank, k)[1] - zs - 1]  # the next chunk continues this slab
+                if k == 0 and halo_req is not None:
+                    halo_req.wait()
+                self._records_chunk(k, labels, h, w, flags, rec, y_splits, dst, pending, None)
         if side is not None:
             for st in side:
                 main.wait_stream(st)
@@ -372,12 +396,13 @@ class ShardedEDT:
             raise ValueError(f"rank {self.rank}: expected a contiguous ({ze - zs}, {self.sy}, {self.sx}) slab")
         w = tuple(float(np.float32(v)) for v in weights_xyz)
         flags = (_lib.FLAG_BLACK_BORDER if black_border else 0)
-        halo = self._halo(labels)
         if self.records:
-            out = self._run_records(labels, w, flags, sqrt, halo)
+            halo, halo_req = self._halo_start(labels)
+            out = self._run_records(labels, w, flags, sqrt, halo, halo_req)
             if gather_back:
                 out = self._reshard([out], to_y=False)[0]
             return out
+        halo = self._halo(labels)
         partial, zflags = self.ops.xy(labels, halo, self.code, w, flags)
         partial_y, zflags_y = self._reshard([partial, zflags], to_y=True)
         out = self.ops.z(partial_y, zflags_y, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0), wxy=(w[0], w[1]))

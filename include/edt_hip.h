@@ -136,9 +136,11 @@ int edt_hip_binary_edtsq(const void *labels, int dtype, int ndim, int64_t sx, in
  * sz > 2048, fewer z-slices or 32-row words of y than devices) is EDT_ERR_UNSUPPORTED too; n_devices = 1 runs on
  * that device.
  * edt_hip_set_devices makes the ordinary host-buffer 3-D entry points (edt_hip_edt3dsq / edt_hip_edt3d, and with
- * them edt::edt<T>() and the Python / Cython front ends) take this route; volumes that cannot be cut that way (and
- * every 1-D / 2-D call) run on the FIRST listed device, with one note on stderr; n_devices = 0 restores the
- * current-device behaviour.  The environment variable EDT_HIP_DEVICES="0,1,2,..." presets the list. */
+ * them edt::edt<T>() and the Python / Cython front ends) take this route; every OTHER host-buffer call -- volumes that
+ * cannot be cut that way (one note on stderr), 1-D and 2-D transforms, stacks of images, the binary route, the forced
+ * generic kernels, sdf and the voxel-graph transforms -- runs on the FIRST listed device (the caller's current device is
+ * restored afterwards); the *_device entry points are never redirected (their buffers live where the caller put them);
+ * n_devices = 0 restores the current-device behaviour.  The environment variable EDT_HIP_DEVICES="0,1,2,..." presets the list. */
 int edt_hip_edt3dsq_multi(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
                           float wz, int black_border, int take_sqrt, float *output, const int *devices,
                           int n_devices);

@@ -28,8 +28,6 @@ static int g_lane_base = 0;
 
 using namespace edt_lane;
 
-static long g_mono_tiles = 0;  // tiles that took the bracket path (tests make sure the path is really exercised)
-extern "C" long lane_emul_mono_tiles() { return g_mono_tiles; }
 // mode 7: fp32 fma candidates for voxel sizes whose c_d are not exact (brute_f32e_prefix), the launcher's conditions:
 // the caller vouches for a lower bound of the non-zero field values (AxisGeom::fmin), a tile takes the window when its
 // largest value is at most c_T.  g_f32e_tiles counts the tiles that did.
@@ -132,58 +130,6 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
   // mode 0: hulls only; 1 / 2: every tile takes the windowed path (fp32 candidates when exact / fp64
   // candidates); 3: the kernel's per-tile choice (field small everywhere -> windowed path); 4 / 5: as 1 / 2 with
   // output stride 2 (only the even rows are evaluated and written)
-  // mode 6: every tile the exactness conditions allow takes the bracket path (edt_colwave_lane.h: mono_band), the
-  // others fall through to the hulls -- the kernel under debug bit 0x400000
-  if (mode == 6) {
-    uint32_t lo_bits, hi_bits;
-    float fmaxv = 0.0f;
-    for (auto &P : lanes)
-      if (P.L.colc < cols_left && P.L.band < NB)
-        for (int r = 0; r < 32; ++r) fmaxv = std::max(fmaxv, P.f[r]);
-    if (mono_limits(w, n, 0, lo_bits, hi_bits) && f2u(fmaxv) <= hi_bits) {
-      ++g_mono_tiles;
-      for (int row = -32; row < (NB + 1) * 32; ++row)
-        if (row < 0 || row >= n)
-          for (int c = 0; c < TC; ++c) tile[addr_tile<CW>(c, row)] = INFINITY;
-      auto lane_at = [&](int colc, int band) -> PerLane * {
-        for (auto &Q : lanes)
-          if (Q.L.colc == colc && Q.L.band == band) return &Q;
-        return nullptr;
-      };
-      std::vector<float> res((size_t)NBP * 32 * TC, 0.0f);
-      std::vector<int> anchor((size_t)NBP * TC, 0);
-      std::vector<float> best0((size_t)NBP * TC, 0.0f), bound0((size_t)NBP * TC, 0.0f);
-      std::vector<MonoLane> ml((size_t)NBP * TC);
-      for (int band = 0; band < NBP; ++band)
-        for (int col = 0; col < TC; ++col) {
-          PerLane *P = lane_at(col, band);
-          MonoLane &ML = ml[(size_t)band * TC + col];
-          ML.tile = tile; ML.col = col; ML.band = band; ML.row0 = band * 32; ML.n = n;
-          ML.rsw = P->L.rsw; ML.lo_in = P->L.lo_in; ML.hi_out = P->L.hi_out;
-          ML.w2f = w * w;
-          ML.live = col < cols_left && band < NB;
-          if (!ML.live) ML.rsw = 0;
-          const float Fa = tile[addr_tile<CW>(col, ML.row0)];
-          const float Ba = mono_bound<CW, BB>(ML, 0, Fa);
-          // (the kernel runs the anchor search wave-wide: a lane keeps going while any lane of its wave does; the
-          // extra candidates are valid ones, so a lane-by-lane search may only see fewer -- both are exact)
-          mono_anchor<CW>(ML, Ba, Fa, best0[(size_t)band * TC + col], anchor[(size_t)band * TC + col]);
-          bound0[(size_t)band * TC + col] = Ba;
-        }
-      for (int band = 0; band < NBP; ++band)
-        for (int col = 0; col < TC; ++col) {
-          const MonoLane &ML = ml[(size_t)band * TC + col];
-          const int A32 = (ML.row0 + 32 < n) ? anchor[(size_t)(band + 1) * TC + col] : n - 1;
-          auto store = [&](int row, float v) { res[(size_t)row * TC + col] = v; };
-          mono_band<CW, BB>(ML, best0[(size_t)band * TC + col], bound0[(size_t)band * TC + col],
-                            anchor[(size_t)band * TC + col], A32, epi, store);
-        }
-      for (int row = 0; row < n; ++row)
-        for (int c = 0; c < TC && c < cols_left; ++c) F[x0 + (int64_t)row * rstride + c] = res[(size_t)row * TC + c];
-      return;
-    }
-    mode = 0;
-  }
   const int stride = (mode == 4 || mode == 5) ? 2 : 1;
   if (mode == 4) mode = 1;
   if (mode == 5) mode = 2;
@@ -246,18 +192,6 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
           BL.live = col < cols_left && band < NB;
           BL.w2 = (double)(w * w); BL.w2f = w * w;
           auto store = [&](int row, float v) { res[(size_t)row * TC + col] = v; };
-#ifdef EDT_CONTIG
-          // the experiment's form: one call per block, the block's position handed in (lane = column x block)
-          for (int k0 = 0; k0 < 32; k0 += 8 * stride) {
-            if (stride == 2) {
-              if (x32) brute_block<CW, BB, true, 2>(BL, k0, epi, store);
-              else brute_block<CW, BB, false, 2>(BL, k0, epi, store);
-            } else {
-              if (x32) brute_block<CW, BB, true, 1>(BL, k0, epi, store);
-              else brute_block<CW, BB, false, 1>(BL, k0, epi, store);
-            }
-          }
-#else
           if (stride == 2) {
             if (x32) brute_band<CW, BB, true, 2>(BL, epi, store);
             else brute_band<CW, BB, false, 2>(BL, epi, store);
@@ -265,7 +199,6 @@ void tile_pass(float *F, const uint32_t *nzbits, const uint32_t *rsbits, int64_t
             if (x32) brute_band<CW, BB, true, 1>(BL, epi, store);
             else brute_band<CW, BB, false, 1>(BL, epi, store);
           }
-#endif
         }
       for (int row = 0; row < n; row += stride)
         for (int c = 0; c < TC && c < cols_left; ++c) F[x0 + (int64_t)row * rstride + c] = res[(size_t)row * TC + c];

@@ -95,7 +95,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q, records=None, chunks=None):
+def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q, records=None, chunks=None, reuse=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -107,11 +107,20 @@ def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q, records=None
         vol = blocky_labels(shape, nlabels=5, zero_frac=0.15, block=5, rng=rng).astype(np.uint32)
         vol = np.asfortranarray(vol)                      # (sx, sy, sz), x fastest
         zyx = np.ascontiguousarray(vol.T)                  # (sz, sy, sx)
-        plan = edist.ShardedEDT(shape, 2, ops=OracleOps(), records=records, chunks=chunks)
+        plan = edist.ShardedEDT(shape, 2, ops=OracleOps(), records=records, chunks=chunks, reuse_output=reuse)
         assert records is None or plan.records == records
         zs, ze = plan.local_z()
         slab = torch.from_numpy(zyx[zs:ze].copy().view(np.int32))
-        out = plan.run(slab, an, black_border=bb, sqrt=sqrt, gather_back=gather_back).numpy()
+        if reuse:
+            # a plan that keeps its receive buffer (and its halo buffer): a first transform of OTHER labels must leave
+            # nothing behind that the second one could pick up
+            other = torch.from_numpy(np.ascontiguousarray(zyx[zs:ze][:, ::-1, :]).view(np.int32))
+            first = plan.run(other, an, black_border=bb, sqrt=sqrt)
+            ptr = first.data_ptr()
+        out = plan.run(slab, an, black_border=bb, sqrt=sqrt, gather_back=gather_back)
+        if reuse and not gather_back:
+            assert out.data_ptr() == ptr, "reuse_output: the receive buffer was allocated again"
+        out = out.numpy()
 
         want = harness.port().edtsq(vol, an, bb)
         if sqrt:
@@ -161,6 +170,24 @@ def test_slab_record_form_equals_single_process(world, shape, an, bb, sqrt, gath
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, shape, an, bb, sqrt, gather_back, q, True, chunks))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, "worker crashed"
+    results = dict(q.get(timeout=5) for _ in range(world))
+    assert results == {r: True for r in range(world)}
+
+
+@pytest.mark.parametrize("world,shape,chunks", [(2, (12, 70, 9), 4), (3, (8, 100, 10), 3), (2, (10, 64, 6), 1)])
+def test_slab_record_form_with_reused_buffers(world, shape, chunks):
+    """reuse_output: one receive buffer and one halo buffer per plan; the chunks are taken top-down with the halo exchange
+    in flight (waited for before the slab's first chunk only) -- two transforms in a row, the second one checked."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, (1.0, 1.0, 2.0), False, False, False, q, True, chunks, True))
              for r in range(world)]
     for p in procs:
         p.start()

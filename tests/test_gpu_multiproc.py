@@ -105,6 +105,41 @@ def test_bench_sharded_leg_on_one_gpu():
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libedt_ref.so")):
         assert out["config"]["output_verified"] is True, out["config"]
         assert out["cpu_baseline"]["kind"] == "reference"
+    # what makes the line readable against N = 1: the kind of scaling, the same workload on one GPU, the efficiency
+    assert out["scaling"] == "weak" and "configs[3]" in out["reading"] and out["config"]["labels"] == "cfg4"
+    same = out["single_gpu_same_workload"]
+    assert same["mvox_per_s"] > 0
+    assert out["scaling_efficiency"] == pytest.approx(out["value"] / (2 * same["mvox_per_s"]), rel=1e-3)
+    # the self-test ran before the timed steps and says what a failure on a multi-GPU box would be diagnosed from
+    st = [ln for ln in res.stdout.splitlines() if ln.startswith("[selftest]")]
+    assert any("RCCL/NCCL" in ln for ln in st) and any("peer access" in ln for ln in st)
+    assert any("all_to_all of rank 0" in ln for ln in st)
+    assert any("output_verified=True" in ln for ln in st), st
+    assert res.stdout.strip().splitlines()[-1].startswith("{"), "the JSON line must be the last line of stdout"
+
+
+@pytest.mark.parametrize("extra,scaling,labels", [(["--labels", "ones"], "weak", "ones"),
+                                                  (["--global-size", "128"], "strong", "cfg4"),
+                                                  (["--global-size", "128", "--labels", "ones"], "strong", "ones")])
+def test_bench_sharded_leg_other_readings(extra, scaling, labels):
+    """--labels ones: the series that continues the N = 1 headline (closed-form check); --global-size: strong scaling."""
+    import json
+    import subprocess
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, EDT_BENCH_BACKEND="gloo", EDT_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128", "--no-selftest"] + extra
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["scaling"] == scaling and out["config"]["labels"] == labels
+    assert out["config"]["global_extents"] == ([128, 128, 128] if scaling == "strong" else [128, 128, 256])
+    assert out["scaling_efficiency"] == pytest.approx(out["value"] / (2 * out["single_gpu_same_workload"]["mvox_per_s"]), rel=1e-3)
+    if labels == "ones" or os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libedt_ref.so")):
+        assert out["config"]["output_verified"] is True, out["config"]
 
 
 def _nccl_worker(rank, world, port, shape, an, bb, chunks, q):
@@ -137,18 +172,19 @@ def _nccl_worker(rank, world, port, shape, an, bb, chunks, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 @pytest.mark.parametrize("shape,an,bb,chunks", [
-    ((128, 192, 96), (1.0, 1.0, 1.0), False, 3),      # slab records, chunked: the exchange of chunk k under chunk k+1
-    ((96, 130, 70), (6.0, 6.0, 30.0), True, 1),       # uneven cuts (sy, sz not multiples of the world size)
+    ((128, 320, 96), (1.0, 1.0, 1.0), False, 3),      # slab records, chunked: the exchange of one chunk under the next one's kernels
+    ((96, 290, 70), (6.0, 6.0, 30.0), True, 1),       # uneven cuts (sy, sz not multiples of the world size), one chunk
+    ((256, 250, 254), (1.0, 1.0, 1.0), False, 4),     # a 1024 x 1000 x 1016-style volume at a quarter of the size: uneven everywhere
 ])
-def test_rccl_exchange_between_real_devices(shape, an, bb, chunks):
+def test_rccl_exchange_between_real_devices(world, shape, an, bb, chunks):
     """The one path no 1-GPU box can run: RCCL `all_to_all` of slab records between DIFFERENT devices (non-empty
-    peers), the one-slice label halo over send/recv and the chunked overlap, checked bit for bit against the compiled
-    reference.  min(device_count, 2) ranks... i.e. 2; skipped below 2 devices (gpurun boxes have one) -- the driver's
-    first multi-GPU lease runs it."""
-    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
-        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
-    world = 2
+    peers), the one-slice label halo over send/recv (in flight while the upper chunks run) and the chunked overlap, checked
+    bit for bit against the compiled reference, at every world size the box offers up to 8 -- skipped where the box has
+    fewer devices (gpurun boxes have one); the driver's first multi-GPU lease runs it."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < world:
+        pytest.skip(f"needs >= {world} GPUs (RCCL refuses two ranks on one device)")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -56,3 +56,24 @@ def test_long_walks_and_stagnation(lib):
     assert lib.seqsum_jump(ctypes.c_float(0.1), 1 << 40) == lib.seqsum_jump(ctypes.c_float(0.1), 1 << 27)
     # a huge index costs no more than a small one
     assert np.isfinite(lib.seqsum_jump(ctypes.c_float(1.3), (1 << 62)))
+
+
+def test_degenerate_voxel_sizes_need_no_long_walk(lib):
+    """NaN, infinities, zero, negative and subnormal voxel sizes: the jump conditions cannot serve them; every thread of
+    the table kernel would otherwise walk its whole prefix one addition at a time.  Values: the plain loop's."""
+    import time
+    for w in (-0.1, -1.3, -6.0, 0.0, 2.0 ** -149, 2.0 ** -149 * 5, 2.0 ** -140, 1.0e-39, -1.0e-39, 2.0 ** -127):
+        ks = np.concatenate([np.arange(0, 200), [1 << 12, (1 << 15) + 3, 1 << 18]])
+        assert _check(lib, w, ks) == 0, w
+    t0 = time.perf_counter()
+    for w in (float("nan"), float("inf"), float("-inf"), 0.0, -0.1, 2.0 ** -149, 1.0e-39, -2.0 ** -140, 3.0e38):
+        v = lib.seqsum_jump(ctypes.c_float(w), 1 << 40)
+        if w != w:
+            assert v != v
+        elif w == 0.0:
+            assert v == 0.0
+        elif abs(w) == float("inf") or abs(w) > 1e38:
+            assert v == (float("inf") if w > 0 else float("-inf"))
+    assert time.perf_counter() - t0 < 2.0, "a degenerate voxel size walked a 2^40-step line"
+    # the subnormal sums: exact multiples until they reach the normal range
+    assert lib.seqsum_jump(ctypes.c_float(2.0 ** -149), 1000) == np.float32(1000 * 2.0 ** -149)

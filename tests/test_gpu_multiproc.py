@@ -109,7 +109,7 @@ def test_bench_sharded_leg_on_one_gpu():
     assert out["scaling"] == "weak" and "configs[3]" in out["reading"] and out["config"]["labels"] == "cfg4"
     same = out["single_gpu_same_workload"]
     assert same["mvox_per_s"] > 0
-    assert out["scaling_efficiency"] == pytest.approx(out["value"] / (2 * same["mvox_per_s"]), rel=1e-3)
+    assert out["scaling_efficiency"] == pytest.approx(out["value"] / (2 * same["mvox_per_s"]), abs=1e-4)
     # the self-test ran before the timed steps and says what a failure on a multi-GPU box would be diagnosed from
     st = [ln for ln in res.stdout.splitlines() if ln.startswith("[selftest]")]
     assert any("RCCL/NCCL" in ln for ln in st) and any("peer access" in ln for ln in st)
@@ -137,7 +137,7 @@ def test_bench_sharded_leg_other_readings(extra, scaling, labels):
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["scaling"] == scaling and out["config"]["labels"] == labels
     assert out["config"]["global_extents"] == ([128, 128, 128] if scaling == "strong" else [128, 128, 256])
-    assert out["scaling_efficiency"] == pytest.approx(out["value"] / (2 * out["single_gpu_same_workload"]["mvox_per_s"]), rel=1e-3)
+    assert out["scaling_efficiency"] == pytest.approx(out["value"] / (2 * out["single_gpu_same_workload"]["mvox_per_s"]), abs=1e-4)
     if labels == "ones" or os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libedt_ref.so")):
         assert out["config"]["output_verified"] is True, out["config"]
 

@@ -40,7 +40,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r03"    # profiles/<tag>_traffic.json holds the PMC-derived HBM bytes per launch
+PROFILE_TAG = "r04"    # profiles/<tag>_traffic.json holds the PMC-derived HBM bytes per launch
 HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming kernel reaches on this part (MI355X_MICROARCH.md)
 
 
@@ -57,7 +57,7 @@ def measured_traffic(kernel=None, config="cfg2"):
     runs, corrected as MI355X_MICROARCH.md prescribes for gfx950); tools/profile_r03.sh collects them,
     profiles/<tag>_traffic.json holds the per-kernel result.  NOT measured in this run: the returned dict names the
     file it was read from (`source`).  kernel=None: every kernel of the configuration."""
-    for tag in (PROFILE_TAG, "r02", "r01"):
+    for tag in (PROFILE_TAG,):  # (older rounds profiled other kernels: their tables do not describe this build)
         rel = os.path.join("profiles", f"{tag}_traffic.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:
@@ -282,6 +282,8 @@ def voxel_graph_secondary(n, dev, steps, warmup, ref=None):
     entry = {"config": "cfg5", "workload": f"{n}^3 uint8 blobs + voxel graph (1 % of the +x links cut), anisotropy (6, 6, 30), "
                                            "black_border=True, device-resident in/out, 1 GPU",
              "ms_per_step": round(ms, 4), "mvox_per_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1), "output_verified": None}
+    if n == 512:
+        entry.update(real_traffic_fields(ms, {}, None, "cfg5"))
     if ref is not None and os.environ.get("EDT_BENCH_VERIFY", "1") != "0":
         # the timed output against the compiled reference's own voxel-graph transform (single-threaded upstream:
         # about a minute at 512^3 -- src/edt_voxel_graph.hpp:120-214)
@@ -803,7 +805,7 @@ def main():
                 entry = {"config": name,
                          "workload": f"{size}^3 uint32 multi-label: {what[name]}, anisotropy {tuple(run.an)}, "
                                      f"black_border={run.bb}, device-resident in/out, 1 GPU", **s}
-                entry.update(real_traffic_fields(s["ms_per_step"], kern, None, name) if size == n else {})
+                entry.update(real_traffic_fields(s["ms_per_step"], kern, None, name))
                 entry["output_verified"] = None
                 if lib is not None and verify:
                     # the timed output, bit for bit against the CPU reference on the same volume (all threads), timed as well

@@ -45,7 +45,7 @@ except Exception as e:
 PY
       done ;;
     prof)
-      rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$1_$2 -o p -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --config $2 > gpurun_out/prof_$1_$2.log 2>&1
+      rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$1_$2 -o p -- python bench.py --steps ${BENCH_STEPS:-20} --warmup 3 --size ${BENCH_SIZE:-512} --no-cpu-baseline --no-secondary --config $2 > gpurun_out/prof_$1_$2.log 2>&1
       echo "prof $1 $2 rc=$?"
       f=$(find gpurun_out/prof_$1_$2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" ;;
     pmc)
@@ -55,11 +55,30 @@ PY
                   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAIT_INST_LDS"; do
         i=$((i+1))
         if [ -n "$PMC_PASSES" ] && [ $i -gt $PMC_PASSES ]; then break; fi
-        rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/pmc_$1$2_$i -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --config $2 > gpurun_out/pmc_$1$2_$i.log 2>&1
+        rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/pmc_$1$2_$i -o p -- python bench.py --steps 3 --warmup 1 --size ${BENCH_SIZE:-512} --no-cpu-baseline --no-secondary --config $2 > gpurun_out/pmc_$1$2_$i.log 2>&1
         echo "pmc $1 $2 pass $i rc=$?"
       done
       python tools/pmc_summary.py $1$2 > gpurun_out/pmc_$1$2_summary.txt
       grep -A20 "k_column_pass_wave" gpurun_out/pmc_$1$2_summary.txt | grep -E "k_column|FETCH|WRITE|INSTS_VALU|WAVE_CYCLES|WAIT_INST_ANY" | head -16 ;;
+    profshard)  # profshard <tag>: kernel stats of the N > 1 leg as a 1-rank RCCL dry run (4 chunks) -> gpurun_out/prof_<tag>_shard
+      EDT_SHARD_CHUNKS=4 EDT_BENCH_FORCE_SHARDED=1 EDT_BENCH_VERIFY=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 \
+        rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$1_shard -o p -- python bench.py --steps 20 --warmup 3 --no-selftest > gpurun_out/prof_$1_shard.log 2>&1
+      echo "profshard $1 rc=$?"
+      f=$(find gpurun_out/prof_$1_shard -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -9 "$f" ;;
+    cmd)  # cmd <tag> <name> -- <command...>: kernel stats of any command -> gpurun_out/prof_<tag>_<name>
+      local tag=$1 name=$2; shift 2
+      rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_${name} -o p -- "$@" > gpurun_out/prof_${tag}_${name}.log 2>&1
+      echo "cmd $tag $name rc=$?"
+      f=$(find gpurun_out/prof_${tag}_${name} -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" ;;
+    pmccmd)  # pmccmd <tag> <name> <command...>: FETCH_SIZE / WRITE_SIZE passes of any command -> gpurun_out/pmc_<tag><name>_{1,2}
+      local tag=$1 name=$2; shift 2
+      local i=0
+      for ctrs in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS"; do
+        i=$((i+1))
+        rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/pmc_${tag}${name}_$i -o p -- "$@" > gpurun_out/pmc_${tag}${name}_$i.log 2>&1
+        echo "pmccmd $tag $name pass $i rc=$?"
+      done
+      python tools/pmc_summary.py ${tag}${name} > gpurun_out/pmc_${tag}${name}_summary.txt ;;
     final)
       python -m pytest tests -m gpu -x -q 2>&1 | tail -3
       python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

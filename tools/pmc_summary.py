@@ -6,7 +6,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sorted(glob.glob(f"gpurun_out/pmc_{tag}_*/p_counter_collection.csv")):
     with open(path) as f:
         for row in csv.DictReader(f):
-            name = row["Kernel_Name"].split("(")[0].replace("void edt_amd::", "")[:40]
+            name = row["Kernel_Name"].split("(")[0].replace("void edt_amd::", "")[:64]
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, ctrs in acc.items():
     print(k)

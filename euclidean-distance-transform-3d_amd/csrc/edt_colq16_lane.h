@@ -45,6 +45,10 @@ constexpr int kK = EDT_Q16_K;     // register-resident radius of the window (com
 constexpr int kPad = kK;          // rows of +inf (0xFFFF) before row 0 and after the last band of the image
 constexpr int kRowWords = 16;     // 32-bit words per image row (32 columns x 16 bit)
 constexpr int kB = 8;             // rows per block
+#ifndef EDT_Q16_REFRESH
+#define EDT_Q16_REFRESH 8  // (measured: 2 -> +2.9 %, 8 -> -1.3 % of a cfg3 step against 4)
+#endif
+constexpr int kRefresh = EDT_Q16_REFRESH;  // the exit bound is refreshed from the current minima every so many steps (2 or 4)
 constexpr uint32_t kInf = 0xFFFFu;
 constexpr uint32_t kFar = 0x4000u;  // "no border on this side" distance (stays below 2^15 after n <= 2048 increments)
 
@@ -246,7 +250,7 @@ struct Steps {
   template <int D>
   EDT_LANE_MEMBER void run() {
     if constexpr (D < K) {
-      if constexpr (D > 1 && (D - 1) % 4 == 0) refresh_bound();
+      if constexpr (D > 1 && (D - 1) % kRefresh == 0) refresh_bound();
       const pk c1 = cpk(D), c2 = cpk(D + 1);
       // a candidate at distance d is at least c_d: once c_d >= every current minimum of the wave nothing further away
       // can lower any of them
@@ -283,7 +287,7 @@ struct Steps {
         EDT_Q16_UNROLL
         for (int e = 0; e < R; e += 2) {  // steps d, d + 1 with d = d0 + e;  d mod R == (1 + e) mod R
           const int d = d0 + e;
-          if (e % 4 == 0) refresh_bound();
+          if (e % kRefresh == 0) refresh_bound();
           const pk c1 = cpk(d), c2 = cpk(d + 1);
           if (!EDT_Q16_ANY(pk_subs(bmax, c1) != 0u)) { done = true; break; }
           if (e % 8 == 0) {

@@ -35,6 +35,25 @@ def dtype_code(dtype: torch.dtype) -> int:
         raise TypeError(f"Unsupported label dtype {dtype}") from None
 
 
+def as_device_tensor(obj) -> torch.Tensor:
+    """A zero-copy torch view of any device array: a torch tensor itself, an object that speaks DLPack (``__dlpack__``:
+    CuPy, JAX, recent Numba ...) or the CUDA array interface (``__cuda_array_interface__``: Numba device arrays, CuPy --
+    also what those libraries expose on ROCm).  Every entry point of this module takes its array arguments through here
+    (the boundary of src/edt.pyx:639-734, for callers whose data never was a numpy array); results are torch tensors,
+    which speak both protocols in the other direction."""
+    if isinstance(obj, torch.Tensor):
+        t = obj
+    elif hasattr(obj, "__dlpack__"):
+        t = torch.from_dlpack(obj)
+    elif hasattr(obj, "__cuda_array_interface__"):
+        t = torch.as_tensor(obj, device=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        raise TypeError(f"expected a device array (torch tensor, __dlpack__ or __cuda_array_interface__), got {type(obj).__name__}")
+    if not t.is_cuda:
+        raise TypeError("edt.device takes device-resident arrays; host arrays go through edt.edtsq / edt.edt / edt.sdf")
+    return t
+
+
 def _stream_ptr() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -107,7 +126,8 @@ def _plan_for(ext, code, device) -> Plan:
     return _plans[key]
 
 
-def _transform(labels: torch.Tensor, anisotropy, black_border, sqrt, force_generic=False, binary=False):
+def _transform(labels, anisotropy, black_border, sqrt, force_generic=False, binary=False):
+    labels = as_device_tensor(labels)
     if labels.numel() == 0:
         return torch.zeros(labels.shape, dtype=torch.float32, device=labels.device)
     if labels.dim() < 1 or labels.dim() > 3:
@@ -126,6 +146,7 @@ def _transform(labels: torch.Tensor, anisotropy, black_border, sqrt, force_gener
 def binary_edtsq(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
     """``edt::binary_edtsq`` on a 2-D / 3-D device tensor of ANY label type (reference: src/edt.hpp:487-576, :681-755):
     labels split runs along x only; along y and z every non-zero voxel is one foreground."""
+    labels = as_device_tensor(labels)
     if labels.dim() not in (2, 3):
         raise TypeError("binary_edtsq: 2-D or 3-D tensors")
     return _transform(labels, anisotropy, black_border, sqrt=False, binary=True)
@@ -140,7 +161,8 @@ def edt(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tens
     return _transform(labels, anisotropy, black_border, sqrt=True)
 
 
-def _stack2d(images: torch.Tensor, anisotropy, black_border, sqrt):
+def _stack2d(images, anisotropy, black_border, sqrt):
+    images = as_device_tensor(images)
     if images.dim() != 3:
         raise TypeError("a stack of 2-D images is a 3-D tensor (count, height, width)")
     if images.numel() == 0:
@@ -168,7 +190,7 @@ def edt_stack(images: torch.Tensor, anisotropy=None, black_border=False) -> torc
 def sdf(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
     """``edt(x) - edt(x == 0)`` without leaving the device (reference: src/edt.pyx:148-158)."""
     lib = _lib.load()
-    labels = labels.contiguous()
+    labels = as_device_tensor(labels).contiguous()
     dt = _transform(labels, anisotropy, black_border, sqrt=True)
     mask = torch.empty(labels.shape, dtype=torch.bool, device=labels.device)
     _lib.check(lib.edt_hip_is_background_device(
@@ -186,6 +208,7 @@ def edtsq_voxel_graph(labels: torch.Tensor, voxel_graph: torch.Tensor, anisotrop
     """Squared EDT with a voxel connectivity graph (reference: edt.edtsq(..., voxel_graph=g),
     src/edt.pyx:736-845) on device tensors: a 2-D or 3-D labels tensor and a uint8 graph of the same shape
     (C order; bit layout of the reference).  Everything stays in HBM (edt_hip_edtsq_voxel_graph_device)."""
+    labels, voxel_graph = as_device_tensor(labels), as_device_tensor(voxel_graph)
     if labels.dim() not in (2, 3) or voxel_graph.shape != labels.shape or voxel_graph.dtype != torch.uint8:
         raise TypeError("voxel_graph needs a 2-D or 3-D volume and a uint8 graph of the same shape")
     lib = _lib.load()
@@ -212,6 +235,7 @@ _NP_OF_CODE = {_lib.U8: np.uint8, _lib.BOOL: np.uint8, _lib.U16: np.uint16, _lib
 def select_label(labels: torch.Tensor, dt: torch.Tensor, key, out: torch.Tensor = None) -> torch.Tensor:
     """``dt`` where ``labels == key``, 0 elsewhere -- the image :func:`edt.each` yields for one label,
     as one streaming kernel (edt_hip_select_label_device)."""
+    labels, dt = as_device_tensor(labels), as_device_tensor(dt)
     if labels.shape != dt.shape or dt.dtype != torch.float32:
         raise ValueError("dt must be a float32 tensor of the labels' shape")
     labels, dt = labels.contiguous(), dt.contiguous()
@@ -236,7 +260,7 @@ def runs(labels: torch.Tensor):
     (run k covers ``[starts[k], ends[k])`` and holds ``values[k]``).  Two enqueue-only kernels sweeps
     (edt_hip_extract_runs_device); the only host synchronisation is reading the run count."""
     lib = _lib.load()
-    labels = labels.contiguous()
+    labels = as_device_tensor(labels).contiguous()
     n = labels.numel()
     dev = labels.device
     if n == 0:
@@ -263,6 +287,7 @@ class _DeviceLabelImages:
     (first run start .. last run end) instead of the whole volume."""
 
     def __init__(self, labels, dt, reuse):
+        labels, dt = as_device_tensor(labels), as_device_tensor(dt)
         if labels.shape != dt.shape or dt.dtype != torch.float32:
             raise ValueError("dt must be a float32 tensor of the labels' shape")
         self.labels, self.dt, self.reuse = labels.contiguous(), dt.contiguous(), reuse

@@ -205,3 +205,49 @@ def test_inexact_voxel_sizes_both_candidate_forms(edt_gpu, oracle_port, anisotro
                     assert np.array_equal(got, want), (anisotropy, bb, hex(mode), int((got != want).sum()))
             finally:
                 lib.edt_hip_set_debug_mode(0)
+
+
+class _CudaArrayInterfaceOnly:
+    """a device array that speaks ONLY the CUDA array interface (what a Numba device array or a CuPy array offers)"""
+
+    def __init__(self, t, typestr):
+        self._keep = t
+        self.__cuda_array_interface__ = {"shape": tuple(t.shape), "typestr": typestr, "data": (t.data_ptr(), False),
+                                         "version": 3, "strides": None}
+
+
+class _DLPackOnly:
+    """a device array that speaks ONLY DLPack"""
+
+    def __init__(self, t):
+        self._t = t
+
+    def __dlpack__(self, *a, **k):
+        return self._t.__dlpack__(*a, **k)
+
+    def __dlpack_device__(self):
+        return self._t.__dlpack_device__()
+
+
+def test_device_entry_points_take_dlpack_and_cuda_array_interface(edt_gpu, oracle_port):
+    """callers whose arrays are not torch tensors (CuPy, Numba, JAX) reach the device entry points zero-copy
+    through __dlpack__ / __cuda_array_interface__ (boundary: src/edt.pyx:639-734)."""
+    import torch
+    from edt import device
+    lab = voronoi_labels((96, 80, 72), nseeds=40, seed=3, upsample=4, membrane=0.03)
+    want = oracle_port.edtsq(lab, (6.0, 6.0, 30.0), True)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).cuda()       # (z, y, x), x fastest
+    ref = device.edtsq(t, anisotropy=(30.0, 6.0, 6.0), black_border=True)
+    assert np.array_equal(ref.cpu().numpy().T, want)
+    for wrapped in (_DLPackOnly(t), _CudaArrayInterfaceOnly(t, "<i4"), _CudaArrayInterfaceOnly(t.view(torch.uint8).view(torch.int32), "<u4")):
+        got = device.edtsq(wrapped, anisotropy=(30.0, 6.0, 6.0), black_border=True)
+        assert torch.equal(got, ref), type(wrapped).__name__
+    assert torch.equal(device.as_device_tensor(_DLPackOnly(t)), t)
+    assert device.as_device_tensor(_CudaArrayInterfaceOnly(t, "<i4")).data_ptr() == t.data_ptr()      # zero-copy
+    assert torch.equal(device.sdf(_DLPackOnly(t), anisotropy=(30.0, 6.0, 6.0)), device.sdf(t, anisotropy=(30.0, 6.0, 6.0)))
+    # the result speaks both protocols in the other direction
+    assert hasattr(ref, "__dlpack__") and ref.__cuda_array_interface__["data"][0] == ref.data_ptr()
+    with pytest.raises(TypeError):
+        device.edtsq(np.zeros((4, 4), np.uint8))      # a host array: not this module's business
+    with pytest.raises(TypeError):
+        device.edtsq([[1, 2], [3, 4]])

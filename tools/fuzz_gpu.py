@@ -28,17 +28,27 @@ for i in range(ncases):
             s = max(4, s // 4 * 4)
         shape.append(s)
     shape = tuple(shape)
-    if np.prod(shape) > 6e6:
+    q16 = os.environ.get("FUZZ_Q16") == "1"
+    if q16:
+        # shapes and voxel sizes of the 16-bit integer column kernel (csrc/edt_colq16.hip): rows of whole 16-byte granules,
+        # both column axes of at least four bands (some beyond 512 rows), voxel sizes that share a quantum
+        dims = 3
+        shape = (4 * int(rng.integers(1, 70)), int(rng.integers(97, 700)), int(rng.integers(97, 400)))
+        if rng.random() < 0.3:
+            shape = (shape[0], shape[2], shape[1])
+        if rng.random() < 0.15:
+            shape = (4 * int(rng.integers(1, 12)), int(rng.integers(513, 1100)), int(rng.integers(97, 200)))
+    if np.prod(shape) > (3e7 if q16 else 6e6):
         continue
     kind = rng.integers(0, 3)
     if kind == 0:
         lab = np.ones(shape, dtype=np.uint32)
     else:
-        lab = blocky_labels(shape, nlabels=int(rng.integers(1, 6)), zero_frac=float(rng.random() * 0.3),
-                            block=int(rng.integers(1, 50)), rng=rng)
+        lab = blocky_labels(shape, nlabels=int(rng.integers(1, 6)) if not q16 or rng.random() < 0.5 else int(rng.integers(20, 400)),
+                            zero_frac=float(rng.random() * 0.3), block=int(rng.integers(1, 50 if not q16 else 120)), rng=rng)
     dt = dtypes[i % len(dtypes)]
     lab = np.asfortranarray(lab.astype(dt)) if rng.random() < 0.7 else np.ascontiguousarray(lab.astype(dt))
-    an = tuple(float(a) for a in rng.choice([1, 2, 6, 30, 0.5, 1.3, 7.25], size=dims))
+    an = tuple(float(a) for a in rng.choice([1, 2, 6, 30, 0.5, 4, 40, 3] if q16 else [1, 2, 6, 30, 0.5, 1.3, 7.25], size=dims))
     bb = bool(rng.integers(0, 2))
     want = o.edtsq(lab, an, bb)
     got = edt.edtsq(lab, anisotropy=an, black_border=bb)

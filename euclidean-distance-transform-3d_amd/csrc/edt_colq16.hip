@@ -47,6 +47,10 @@ struct Q16Args {
   uint16_t *plane;
   uint32_t *map;
   int map_words;          // words per x-tile
+  // output stride 2 (S = 2: the doubled grids of the voxel-graph transform) only: nullptr = the even rows go to their places
+  // in F; else row r of column (x, outer o) goes to compact[x + o * c_outer + (r / 2) * c_row2]   (edt_kernels.h: ColumnOut)
+  float *compact;
+  int64_t c_outer, c_row2;
 };
 enum : int { kQ16InF32 = 0, kQ16InCodes = 1, kQ16InMixed = 2 };
 
@@ -64,7 +68,8 @@ __host__ __device__ constexpr int q16_lds_words(int NB) {
 // O16: the results go to the 16-bit plane (in place over the indices) instead of F; SC: ... to the slab records
 // T: threads of the workgroup -- 256 (four waves) up to 512 rows, 512 beyond (a 1024-row image leaves room for two
 // workgroups per CU: eight waves each keep the SIMDs as busy as the four workgroups of four waves of the shorter axes)
-template <bool BB, int IN, bool O16, bool SC, int T>
+// S: output stride -- 1 = every row; 2 = blocks of 16 rows whose even rows are evaluated and written (IN = fp32 only)
+template <bool BB, int IN, bool O16, bool SC, int T, int S = 1>
 __global__ void __launch_bounds__(T, 4)
 k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, AxisGeom g, int tiles_x, int epi, int dbg,
                   Q16Args qa, const BandScatter *__restrict__ scatter) {
@@ -259,11 +264,16 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   const bool store_ok = 2 * cp < cols_left;
   typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll 1
-  for (int s = wave; s < NB; s += T / 64) {
+  for (int sb = wave; sb * 32 * S < nb32; sb += T / 64) {
     Block L;
     L.img = img;
     L.cp = cp;
-    L.p0 = 32 * s + 8 * bq;
+    L.p0 = 32 * S * sb + 8 * S * bq;
+    // (S = 2 and an odd number of bands: the last two blocks of the last iteration do not exist -- their lanes repeat the
+    // column's last block and store nothing, so that the wave-wide exit tests stay what they are)
+    const bool lane_on = L.p0 < nb32;
+    if (!lane_on) L.p0 = nb32 - 8 * S;
+    const int s = L.p0 >> 5;  // the block's band
     L.n = n;
     L.nb32 = nb32;
     {
@@ -279,8 +289,8 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     L.a = qa.a;
     L.dmax = qa.dmax;
     {
-      // the break bits of blocks gi - 32 .. gi + 31 (gi = 4 s + bq): bits gi .. gi + 63 of the padded mask
-      const int wi = s >> 3, sh = (4 * s + bq) & 31;
+      // the break bits of blocks gi - 32 .. gi + 31 (gi = p0 / 8): bits gi .. gi + 63 of the padded mask
+      const int gi = L.p0 >> 3, wi = gi >> 5, sh = gi & 31;
       const uint32_t *m = bm + cp * 6 + wi;
       const uint32_t e0 = m[0], e1 = m[1], e2 = m[2];
       const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
@@ -288,21 +298,26 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       L.win = ((uint64_t)hi << 32) | lo;
     }
     pk best[kB];
-    block_eval<BB>(L, best);
+    block_eval<BB, S>(L, best);
     // ---- results: (float)N * q is exact; sqrt of the last pass (src/edt.hpp:599-601) ----
     float *dst;
+    int64_t dstep = st;  // between consecutive EVALUATED rows: S rows of the column, or one row of a compact destination
     if constexpr (SC) {
       const int b = s < BandScatter::kBands ? s : 0;
       dst = scatter->rows[b] + o * scatter->ostride[b] + x0 + 2 * cp - (int64_t)s * 32 * st;
+    } else if (S == 2 && qa.compact != nullptr) {  // (wave-uniform: kernel argument)
+      dst = qa.compact + x0 + 2 * cp + o * qa.c_outer;
+      dstep = qa.c_row2;
     } else {
       dst = F + x0 + o * g.outer_stride + 2 * cp;
+      dstep = st * S;
     }
     if constexpr (O16) {
       auto *ndst = (__attribute__((address_space(1))) uint32_t *)(qa.plane + x0 + o * g.outer_stride + 2 * cp);
 #pragma unroll
       for (int j = 0; j < kB; ++j) {
         const int row = L.p0 + j;
-        if (row < n && store_ok) ndst[((int64_t)row * st) >> 1] = best[j];  // (st % 4 == 0: the pair is a whole word)
+        if (row < n && store_ok && lane_on) ndst[((int64_t)row * st) >> 1] = best[j];  // (st % 4 == 0: the pair is a whole word)
       }
       continue;
     }
@@ -317,9 +332,9 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     }
 #pragma unroll
     for (int j = 0; j < kB; ++j) {
-      const int row = L.p0 + j;
-      if (row < n && store_ok)
-        *reinterpret_cast<__attribute__((address_space(1))) v2f *>(gdst + (int64_t)row * st) = out[j];
+      const int row = L.p0 + S * j;
+      if (row < n && store_ok && lane_on)
+        *reinterpret_cast<__attribute__((address_space(1))) v2f *>(gdst + (int64_t)(row / S) * dstep) = out[j];
     }
   }
 }
@@ -334,7 +349,7 @@ bool column_pass_q16_supported(const AxisGeom &g) {
          !(debug_mode() & 0x8000000);
 }
 
-template <bool BB, int IN, bool O16, bool SC, int T>
+template <bool BB, int IN, bool O16, bool SC, int T, int S = 1>
 static int launch_q16_kt(float *F, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa, int epi, hipStream_t stream,
                          const BandScatter *scatter) {
   const int NB = (int)g.nbands;
@@ -347,8 +362,8 @@ static int launch_q16_kt(float *F, const uint32_t *rs, const AxisGeom &g, const 
   if (!(debug_mode() & 0x800)) tiles = tiles_x * (ceil_div(g.nouter, 8) * 8);
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
   static std::atomic<uint64_t> attr_done{0};
-  EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_q16<BB, IN, O16, SC, T>)));
-  hipLaunchKernelGGL((k_column_pass_q16<BB, IN, O16, SC, T>), dim3((unsigned)tiles), dim3(T), lds, stream, F, rs, g,
+  EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_column_pass_q16<BB, IN, O16, SC, T, S>)));
+  hipLaunchKernelGGL((k_column_pass_q16<BB, IN, O16, SC, T, S>), dim3((unsigned)tiles), dim3(T), lds, stream, F, rs, g,
                      (int)tiles_x, epi, debug_mode(), qa, scatter);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
@@ -363,7 +378,12 @@ static int launch_q16_k(float *F, const uint32_t *rs, const AxisGeom &g, const Q
 
 template <bool BB>
 static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa, int in, bool o16, int epi,
-                        hipStream_t stream, const BandScatter *scatter) {
+                        hipStream_t stream, const BandScatter *scatter, int out_stride) {
+  if (out_stride == 2) {
+    if (scatter != nullptr || o16 || in != kQ16InF32) { set_error("internal: output stride 2 takes fp32 in and out"); return EDT_ERR_BAD_ARG; }
+    if (g.nbands > 16) return launch_q16_kt<BB, kQ16InF32, false, false, 512, 2>(F, rs, g, qa, epi, stream, nullptr);
+    return launch_q16_kt<BB, kQ16InF32, false, false, 256, 2>(F, rs, g, qa, epi, stream, nullptr);
+  }
   if (scatter != nullptr) {
     if (o16 || in == kQ16InMixed) { set_error("internal: 16-bit plane with slab records"); return EDT_ERR_BAD_ARG; }
     return in == kQ16InCodes ? launch_q16_k<BB, kQ16InCodes, false, true>(F, rs, g, qa, epi, stream, scatter)
@@ -382,7 +402,7 @@ static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q
 // map; without -- the rows are taken from the plane wherever map says so (the pass after such a pass).
 int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
                            uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
-                           const BandScatter *scatter, uint16_t *plane, uint32_t *map, int map_words) {
+                           const BandScatter *scatter, uint16_t *plane, uint32_t *map, int map_words, const ColumnOut *out) {
   Q16Args qa;
   qa.codes = codes;
   qa.q = q;
@@ -400,10 +420,18 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
   qa.plane = plane;
   qa.map = map;
   qa.map_words = map_words;
+  qa.compact = out ? out->compact : nullptr;
+  qa.c_outer = out ? out->outer : 0;
+  qa.c_row2 = out ? out->row2 : 0;
+  const int ostride = (out && (out->stride == 2 || out->compact != nullptr)) ? 2 : 1;
+  if (qa.compact != nullptr && ((reinterpret_cast<uintptr_t>(qa.compact) % 8) != 0 || (qa.c_outer % 2) != 0 || (qa.c_row2 % 2) != 0)) {
+    set_error("internal: compact destination of the integer kernel must take 8-byte stores");
+    return EDT_ERR_BAD_ARG;
+  }
   const int in = codes ? kQ16InCodes : (plane ? kQ16InMixed : kQ16InF32);
   const bool o16 = codes != nullptr && plane != nullptr;
-  return bb ? launch_q16_b<true>(F, rs, g, qa, in, o16, epi, stream, scatter)
-            : launch_q16_b<false>(F, rs, g, qa, in, o16, epi, stream, scatter);
+  return bb ? launch_q16_b<true>(F, rs, g, qa, in, o16, epi, stream, scatter, ostride)
+            : launch_q16_b<false>(F, rs, g, qa, in, o16, epi, stream, scatter, ostride);
 }
 
 // the quantum of a call (edt_colq16_lane.h: quantum_of), host side

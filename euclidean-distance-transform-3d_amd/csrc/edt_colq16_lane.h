@@ -199,9 +199,11 @@ EDT_LANE uint32_t band_breaks(const uint32_t *band0, pk apk, bool top, int valid
 
 // Flat reach of block gi of a column pair (in rows): no break lies within this distance of the block's rows.
 // bm: the break bits of the pair's blocks gi-32 .. gi+31 (bit 32 = the block itself).
+// S = 2: the block is 16 rows, i.e. the blocks gi and gi + 1 of the break bits.
+template <int S = 1>
 EDT_LANE int flat_reach(uint64_t win) {
-  if ((win >> 32) & 1u) return 0;
-  const uint32_t below = (uint32_t)win, above = (uint32_t)(win >> 33);
+  if ((win >> 32) & (S == 2 ? 3u : 1u)) return 0;
+  const uint32_t below = (uint32_t)win, above = (uint32_t)(win >> (32 + S));
   // nearest break block below: gi - 32 + hb  ->  its last row is at least 8 * (32 - hb) - 7 rows below the block
   const int dlo = below ? 8 * (q16_clz(below) + 1) - 7 : 8 * 33 - 7;
   const int dhi = above ? 8 * q16_ctz(above) : 8 * 31;
@@ -225,11 +227,13 @@ struct Block {
   uint64_t win;          // break bits around the block (flat_reach)
 };
 
-template <bool BB>
+// S = output stride: 1 = every row of the block is evaluated; 2 = a block is 16 rows of which the even ones are evaluated (the
+// doubled grids of the voxel-graph transform, whose odd rows are never read again) -- every row is a candidate either way.
+template <bool BB, int S = 1>
 struct Steps {
-  static constexpr int K = kK, B = kB, RW = kRowWords;
+  static constexpr int K = kK, B = kB, RW = kRowWords, NR = S * B;  // NR rows per block
   const Block &L;
-  pk (&w)[B + 2 * K];
+  pk (&w)[NR + 2 * K];
   pk (&best)[B];
   const uint32_t *PB;  // word of (row p0 - K, pair cp)
   pk bmax;             // upper bound of the current minima of the block (both halves)
@@ -256,18 +260,57 @@ struct Steps {
       // can lower any of them
       if (!EDT_Q16_ANY(pk_subs(bmax, c1) != 0u)) return;
       w[K - D] = PB[(K - D) * RW];
-      w[K + B - 1 + D] = PB[(K + B - 1 + D) * RW];
+      w[K + NR - 1 + D] = PB[(K + NR - 1 + D) * RW];
       w[K - D - 1] = PB[(K - D - 1) * RW];
-      w[K + B + D] = PB[(K + B + D) * RW];
+      w[K + NR + D] = PB[(K + NR + D) * RW];
       EDT_Q16_UNROLL
       for (int ii = 0; ii < B; ++ii) {
         // (the first and the last row of the block need the rows just requested: they come last)
         const int i = ii < B - 2 ? ii + 1 : (ii == B - 2 ? 0 : B - 1);
-        const pk m1 = pk_min(w[K + i - D], w[K + i + D]);
-        const pk m2 = pk_min(w[K + i - D - 1], w[K + i + D + 1]);
+        const pk m1 = pk_min(w[K + S * i - D], w[K + S * i + D]);
+        const pk m2 = pk_min(w[K + S * i - D - 1], w[K + S * i + D + 1]);
         best[i] = pk_min(pk_min(best[i], pk_adds(m1, c1)), pk_adds(m2, c2));
       }
       run<D + 2>();
+    } else if constexpr (S == 2) {
+      // Windows beyond the register-resident part, blocks of 16 rows with the even ones evaluated: at step d output i looks
+      // at the rows p0+2i-d (entered at step d-2i) and p0+2i+d (entered at step d-15+2i) -- the last 16 entries of either
+      // side: rings of 16 registers indexed by d mod 16, one step per exit test.
+      constexpr int R = 16;
+      static_assert((K % R) == 0 && NR == R, "ring phase / size");
+      pk rlo[R], rhi[R];
+      EDT_Q16_UNROLL
+      for (int s = K - R + 2; s <= K; ++s) {  // the last 15 rows of the register-resident window on either side
+        rlo[s % R] = w[K - s];
+        rhi[s % R] = w[K + NR - 1 + s];
+      }
+      const uint32_t *slo = L.img, *shi = L.img;
+      for (int d0 = K + 1; d0 < 4096; d0 += R) {
+        bool done = false;
+        EDT_Q16_UNROLL
+        for (int e = 0; e < R; ++e) {  // step d = d0 + e;  d mod R == (1 + e) mod R
+          const int d = d0 + e;
+          if (e % kRefresh == 0) refresh_bound();
+          const pk c1 = cpk(d);
+          if (!EDT_Q16_ANY(pk_subs(bmax, c1) != 0u)) { done = true; break; }
+          if (e % 8 == 0) {
+            int rl = L.p0 - d - 7, rh = L.p0 + NR - 1 + d;  // the rows of the next eight steps: rl .. rl+7, rh .. rh+7
+            rl = rl < -kPad ? -kPad : rl;
+            rh = rh > L.nb32 + kPad - 8 ? L.nb32 + kPad - 8 : rh;
+            slo = L.img + (rl + kPad) * RW + L.cp;
+            shi = L.img + (rh + kPad) * RW + L.cp;
+          }
+          const int sl = (1 + e) % R;
+          rlo[sl] = slo[(7 - e % 8) * RW];
+          rhi[sl] = shi[(e % 8) * RW];
+          EDT_Q16_UNROLL
+          for (int i = 0; i < B; ++i) {
+            const pk m = pk_min(rlo[(sl - 2 * i + 2 * R) % R], rhi[(sl - (NR - 1) + 2 * i + 2 * R) % R]);
+            best[i] = pk_min(best[i], pk_adds(m, c1));
+          }
+        }
+        if (done) break;
+      }
     } else {
       // Windows beyond the register-resident part: the same step as a rolled loop.  At step d row i looks at the rows
       // p0+i-d and p0+i+d, i.e. at the B rows that entered the window most recently on either side: rings of 16 registers
@@ -325,68 +368,76 @@ EDT_LANE uint32_t dist_below(uint32_t rsw, int lo_in, int row0, int k0) {
 }
 // distance of the row after the block to the first row of the next run (kFar: no border above), one column
 template <bool BB>
-EDT_LANE uint32_t dist_above(uint32_t rsw, int hi_out, int row0, int k0, int n) {
-  const uint32_t m = k0 + kB < 32 ? rsw & (0xFFFFFFFFu << (k0 + kB)) : 0u;
+EDT_LANE uint32_t dist_above(uint32_t rsw, int hi_out, int row0, int k0, int n, int nr = kB) {
+  const uint32_t m = k0 + nr < 32 ? rsw & (0xFFFFFFFFu << (k0 + nr)) : 0u;
   const int e = m ? row0 + q16_ctz(m) : hi_out + 1;
-  return (BB || e < n) ? (uint32_t)(e - (row0 + k0 + kB)) : kFar;
+  return (BB || e < n) ? (uint32_t)(e - (row0 + k0 + nr)) : kFar;
 }
 
-// best[i] = result of row p0 + i (both columns), in quanta
-template <bool BB>
+// best[i] = result of row p0 + S * i (both columns), in quanta.  S = 2: the block is the 16 rows p0 .. p0 + 15 (p0 a multiple
+// of 16), its even rows are evaluated.
+template <bool BB, int S = 1>
 EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
-  constexpr int K = kK, B = kB, RW = kRowWords;
+  constexpr int K = kK, B = kB, RW = kRowWords, NR = S * B;
   const int row0 = L.p0 & ~31, k0 = L.p0 & 31;
   const uint32_t *PB = L.img + (L.p0 - K + kPad) * RW + L.cp;
-  pk w[B + 2 * K];
+  pk w[NR + 2 * K];
   EDT_Q16_UNROLL
-  for (int j = 0; j < B; ++j) w[K + j] = PB[(K + j) * RW];
+  for (int j = 0; j < NR; ++j) w[K + j] = PB[(K + j) * RW];
   // ---- B_p: border distances as packed counters from run start to run start ----
-  const pk starts = ((L.rswA >> k0) & 0xFFu) | (((L.rswB >> k0) & 0xFFu) << 16);  // bit j of a half: a run starts at row p0 + j
+  constexpr uint32_t kRowBits = S == 2 ? 0xFFFFu : 0xFFu;
+  const pk starts = ((L.rswA >> k0) & kRowBits) | (((L.rswB >> k0) & kRowBits) << 16);  // bit j of a half: a run starts at row p0 + j
   pk dl = dist_below<BB>(L.rswA, L.loA, row0, k0) | (dist_below<BB>(L.rswB, L.loB, row0, k0) << 16);
   // (a block that reaches beyond the column's last row has a "negative" distance above: the counters are 16-bit modular,
   // the rows of the column come out right and the others are not rows)
-  pk dr = (dist_above<BB>(L.rswA, L.hiA, row0, k0, L.n) & 0xFFFFu) | (dist_above<BB>(L.rswB, L.hiB, row0, k0, L.n) << 16);
+  pk dr = (dist_above<BB>(L.rswA, L.hiA, row0, k0, L.n, NR) & 0xFFFFu) | (dist_above<BB>(L.rswB, L.hiB, row0, k0, L.n, NR) << 16);
   const pk one = 0x00010001u;
   // a run that starts at row 0 of the column has a border below it only with black_border
   const pk first0 = (BB || L.p0 > 0) ? one : pk_both(kFar);
-  pk mask[B], dlv[B];
+  pk mask[NR], dlv[B];
   {
 #define EDT_Q16_ROW_UP(J)                                                   \
     mask[J] = pk_sar15(pk_shl<15 - J>(starts));                             \
     EDT_Q16_OPAQUE(mask[J]);                                                \
     dl = pk_sel(mask[J], J == 0 ? first0 : one, pk_add(dl, one));           \
-    dlv[J] = dl;
+    if ((J) % S == 0) dlv[(J) / S] = dl;
     EDT_Q16_ROW_UP(0) EDT_Q16_ROW_UP(1) EDT_Q16_ROW_UP(2) EDT_Q16_ROW_UP(3)
     EDT_Q16_ROW_UP(4) EDT_Q16_ROW_UP(5) EDT_Q16_ROW_UP(6) EDT_Q16_ROW_UP(7)
+    if constexpr (S == 2) {
+      EDT_Q16_ROW_UP(8) EDT_Q16_ROW_UP(9) EDT_Q16_ROW_UP(10) EDT_Q16_ROW_UP(11)
+      EDT_Q16_ROW_UP(12) EDT_Q16_ROW_UP(13) EDT_Q16_ROW_UP(14) EDT_Q16_ROW_UP(15)
+    }
 #undef EDT_Q16_ROW_UP
   }
   const pk dmaxpk = pk_both(L.dmax), apk = pk_both(L.a);
   pk bmax = 0;
   EDT_Q16_UNROLL
-  for (int j = B - 1; j >= 0; --j) {
+  for (int j = NR - 1; j >= 0; --j) {
     dr = pk_add(dr, one);
-    const pk dm = pk_min(pk_min(dlv[j], dr), dmaxpk);
-    // a * min(d, dmax)^2 fits 16 bits; a tile on this path holds no value above a * dmax^2, so the clamp changes no minimum
-    const pk bord = pk_mul(pk_mul(dm, dm), apk);
-    best[j] = pk_min(w[K + j], bord);
+    if (j % S == 0) {
+      const pk dm = pk_min(pk_min(dlv[j / S], dr), dmaxpk);
+      // a * min(d, dmax)^2 fits 16 bits; a tile on this path holds no value above a * dmax^2, so the clamp changes no minimum
+      const pk bord = pk_mul(pk_mul(dm, dm), apk);
+      best[j / S] = pk_min(w[K + j], bord);
+    }
     dr = dr & ~mask[j];  // (a set bit is a real row: the border site of the rows below it)
   }
   // rows that complete the last band are not rows of the column
-  if (L.p0 + B > L.n) {
+  if (L.p0 + NR > L.n) {
     EDT_Q16_UNROLL
-    for (int j = 0; j < B; ++j)
-      if (L.p0 + j >= L.n) best[j] = 0u;
+    for (int i = 0; i < B; ++i)
+      if (L.p0 + S * i >= L.n) best[i] = 0u;
   }
   EDT_Q16_UNROLL
-  for (int j = 0; j < B; ++j) bmax = pk_max(bmax, best[j]);
+  for (int i = 0; i < B; ++i) bmax = pk_max(bmax, best[i]);
   // ---- flat neighbourhood: nothing within reach can improve any row of the wave's blocks ----
   {
-    uint32_t D1 = (uint32_t)flat_reach(L.win) + 1u;
+    uint32_t D1 = (uint32_t)flat_reach<S>(L.win) + 1u;
     D1 = D1 < L.dmax + 1u ? D1 : L.dmax + 1u;
     const uint32_t cD = L.a * D1 * D1;
     if (!EDT_Q16_ANY(pk_subs(bmax, pk_both(cD < kInf ? cD : kInf)) != 0u)) return;
   }
-  Steps<BB> steps{L, w, best, PB, bmax, L.a};
+  Steps<BB, S> steps{L, w, best, PB, bmax, L.a};
   steps.template run<1>();
 }
 

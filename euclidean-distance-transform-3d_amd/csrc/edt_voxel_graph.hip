@@ -441,6 +441,9 @@ size_t vg_native_workspace_bytes(int ndim, int64_t sx, int64_t sy, int64_t sz) {
   b += 2 * align_up((size_t)(sx * ceil_div(Y2, kBandRows) * Z2) * sizeof(uint32_t), 256);
   if (ndim == 3) b += 2 * align_up((size_t)(sx * ceil_div(Z2, kBandRows) * sy) * sizeof(uint32_t), 256);
   b += align_up((size_t)(2 * sx + 4) * sizeof(float), 256);
+  // hand-over list of the integer column kernel (edt_colq16.hip): two counters + the tile ids of the larger pass
+  b += align_up(8 * sizeof(uint32_t), 256);
+  b += align_up((size_t)(ceil_div(sx, 16) * (ceil_div(std::max<int64_t>(Z2, sy), 8) * 8)) * sizeof(uint32_t), 256);
   return b + 256;
 }
 
@@ -463,6 +466,8 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
     rsZ = reinterpret_cast<uint32_t *>(take((size_t)(sx * nbZ * sy) * sizeof(uint32_t)));
   }
   float *ttab = reinterpret_cast<float *>(take((size_t)(2 * sx + 4) * sizeof(float)));
+  uint32_t *q16_counts = reinterpret_cast<uint32_t *>(take(8 * sizeof(uint32_t)));
+  uint32_t *q16_ids = reinterpret_cast<uint32_t *>(take((size_t)(ceil_div(sx, 16) * (ceil_div(std::max<int64_t>(Z2, sy), 8) * 8)) * sizeof(uint32_t)));
   const int idx_inf = (int)(2 * sx + 2);
   // half voxel size on the doubled grid (src/edt_voxel_graph.hpp:96-101, :189-193)
   const float hx = wx / 2, hy = wy / 2, hz = wz / 2;
@@ -497,7 +502,30 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
   last.outer = ndim == 3 ? sx : 0;          // 3-D: outer index of the z pass = y
   last.row2 = ndim == 3 ? sx * sy : sx;     // two doubled rows = one voxel slice / one voxel row
   if (g_vg_debug_gather()) last = even;     // (diagnostics: debug bit 0x200000 keeps the separate gather pass)
-  int rc = launch_column_pass_wave(F1, nzY, rsY, gy, hy, bb, ndim == 2 ? last_epi : 0, stream, nullptr, ndim == 2 ? last : even);
+  // The integer column kernel (edt_colq16.hip, output stride 2) where the half voxel sizes share a quantum and pass X left exact
+  // multiples; the tiles it refuses go to the fp32 kernel through the list, as everywhere.
+  float q16_q = 1.0f;
+  uint32_t q16_a[3] = {1u, 1u, 1u};
+  bool q16 = false;
+  {
+    const float h3[3] = {hx, hy, hz};
+    q16 = exact && !(debug_mode() & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x40000)) && q16_quantum(h3, ndim, &q16_q, q16_a) &&
+          (reinterpret_cast<uintptr_t>(out) % 8) == 0;
+    if (q16) EDT_HIP_TRY(hipMemsetAsync(q16_counts, 0, 8 * sizeof(uint32_t), stream));
+  }
+  auto column_pass = [&](const uint32_t *nzp, const uint32_t *rsp, const AxisGeom &g, float h, int axis, int epi, const ColumnOut &co,
+                         uint32_t *count) -> int {
+    TileList list;
+    if (q16 && column_pass_q16_supported(g) && column_pass_wave_supported(g)) {
+      const int r = launch_column_pass_q16(F1, nullptr, rsp, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, q16_ids, stream, nullptr,
+                                           nullptr, nullptr, 0, &co);
+      if (r != EDT_OK) return r;
+      list.count = count;
+      list.ids = q16_ids;
+    }
+    return launch_column_pass_wave(F1, nzp, rsp, g, h, bb, epi, stream, nullptr, co, list);
+  };
+  int rc = column_pass(nzY, rsY, gy, hy, 1, ndim == 2 ? last_epi : 0, ndim == 2 ? last : even, q16_counts);
   if (rc != EDT_OK) return rc;
   if (ndim == 3) {
     const int64_t total = sx * nbZ * sy;
@@ -508,7 +536,7 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
     EDT_HIP_TRY(hipGetLastError());
     AxisGeom gz;  // the even rows only: outer index = y, two doubled rows apart
     gz.sx = sx; gz.n = Z2; gz.stride = sx * Y2; gz.nouter = sy; gz.outer_stride = 2 * sx; gz.nbands = nbZ;
-    rc = launch_column_pass_wave(F1, nzZ, rsZ, gz, hz, bb, last_epi, stream, nullptr, last);
+    rc = column_pass(nzZ, rsZ, gz, hz, 2, last_epi, last, q16_counts + 1);
     if (rc != EDT_OK) return rc;
   }
   if (last.compact != nullptr) return EDT_OK;

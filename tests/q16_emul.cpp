@@ -21,7 +21,7 @@ using namespace edt_q16;
 namespace {
 
 // one tile: columns x0 .. x0+31.  Returns false if the tile does not qualify (nothing is written then).
-template <bool BB>
+template <bool BB, int S = 1>
 bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, float *out, int64_t sx, int n, int64_t x0,
                float q, uint32_t a, uint32_t ain, int epi, long *steps_taken, const uint16_t *plane_in = nullptr,
                const uint8_t *row_in_plane = nullptr, uint16_t *plane_out = nullptr) {
@@ -87,14 +87,16 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
     const uint32_t bits = band_breaks(img.data() + (size_t)(32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32);
     bm[cp * 6 + 1 + (band >> 3)] |= bits << (4 * (band & 7));
   }
-  // ---- blocks (phase 2) ----
-  for (int s = 0; s < NB; ++s)
+  // ---- blocks (phase 2): a wave works on 16 pairs x four consecutive blocks (of 8 rows, or -- S = 2 -- of 16) ----
+  for (int sb = 0; sb * 32 * S < nb32; ++sb)
     for (int lane = 0; lane < 64; ++lane) {
       const int cp = lane & 15, bq = lane >> 4;
       Block L;
       L.img = img.data();
       L.cp = cp;
-      L.p0 = 32 * s + 8 * bq;
+      L.p0 = 32 * S * sb + 8 * S * bq;
+      if (L.p0 >= nb32) continue;
+      const int s = L.p0 >> 5;  // the block's band
       L.n = n;
       L.nb32 = nb32;
       L.rswA = rsp[(size_t)s * 32 + 2 * cp];
@@ -107,7 +109,7 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
       L.a = a;
       L.dmax = dmax;
       {
-        const int wi = s >> 3, sh = (4 * s + bq) & 31;
+        const int gi = L.p0 >> 3, wi = gi >> 5, sh = gi & 31;
         const uint32_t *m = bm.data() + cp * 6 + wi;
         const uint32_t e0 = m[0], e1 = m[1], e2 = m[2];
         const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
@@ -115,10 +117,10 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
         L.win = ((uint64_t)hi << 32) | lo;
       }
       pk best[kB];
-      block_eval<BB>(L, best);
+      block_eval<BB, S>(L, best);
       (void)steps_taken;
       for (int j = 0; j < kB; ++j) {
-        const int row = L.p0 + j;
+        const int row = L.p0 + S * j;
         if (row >= n) continue;
         for (int h = 0; h < 2; ++h) {
           const int col = 2 * cp + h;
@@ -174,6 +176,27 @@ extern "C" int q16_emul_column_pass_plane(const uint32_t *labels, const float *F
   for (int64_t x0 = 0, i = 0; x0 < sx; x0 += 32, ++i) {
     const bool r = bb ? tile_pass<true>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr, plane_in, row_in_plane, plane_out)
                       : tile_pass<false>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr, plane_in, row_in_plane, plane_out);
+    tile_ok[i] = r ? 1 : 0;
+    ok += r ? 1 : 0;
+  }
+  return ok;
+}
+
+// output stride 2: only the even rows are evaluated and written (the doubled grids of the voxel-graph transform)
+extern "C" int q16_emul_column_pass_even(const uint32_t *labels, const float *Fin, float *out, int64_t sx, int64_t n, float q,
+                                         uint32_t a, int bb, int epi, uint8_t *tile_ok) {
+  const int NB = (int)((n + 31) / 32);
+  std::vector<uint32_t> rs((size_t)NB * sx, 0);
+  for (int64_t x = 0; x < sx; ++x)
+    for (int64_t y = 0; y < n; ++y) {
+      const uint32_t lab = labels[y * sx + x];
+      const bool start = (y == 0) || lab != labels[(y - 1) * sx + x];
+      if (start) rs[(size_t)(y / 32) * sx + x] |= 1u << (y % 32);
+    }
+  int ok = 0;
+  for (int64_t x0 = 0, i = 0; x0 < sx; x0 += 32, ++i) {
+    const bool r = bb ? tile_pass<true, 2>(Fin, nullptr, rs.data(), out, sx, (int)n, x0, q, a, 1u, epi, nullptr)
+                      : tile_pass<false, 2>(Fin, nullptr, rs.data(), out, sx, (int)n, x0, q, a, 1u, epi, nullptr);
     tile_ok[i] = r ? 1 : 0;
     ok += r ? 1 : 0;
   }

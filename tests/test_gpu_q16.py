@@ -77,3 +77,28 @@ def test_q16_binary_route_and_bool(edt_gpu, oracle_port):
     want = oracle_port.edtsq(lab, (1, 1, 2), True)
     for got, (_, name) in zip(run_modes(edt_gpu, lab, (1, 1, 2), True), MODES):
         assert np.array_equal(got, want), name
+
+
+@pytest.mark.parametrize("shape", [(64, 80, 72), (128, 200, 100), (36, 300, 70), (260, 260)])
+def test_q16_voxel_graph_output_stride_two(edt_gpu, oracle_port, shape):
+    """the doubled grids of the voxel-graph transform on the integer kernel (blocks of 16 rows, even rows evaluated, the last
+    pass writing the caller's array): against the oracle and against the fp32 kernels; band counts odd and even"""
+    from synth import blob_mask
+    from edt import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(sum(shape))
+    lab = (blob_mask(shape, rng=rng, p=0.8, block=7) * rng.integers(1, 4, size=shape)).astype(np.uint8)
+    g = np.full(shape, 0b00111111, dtype=np.uint8)
+    for bit in (0x01, 0x04, 0x10):
+        g[rng.random(shape) < 0.03] &= np.uint8(~bit & 0xFF)
+    for an, bb in (((6.0, 6.0, 30.0), True), ((1.0, 1.0, 1.0), False), ((1.0, 2.0, 1.5), True)):
+        an = an[:len(shape)]
+        want = oracle_port.edtsq(lab, an, bb, voxel_graph=g)
+        try:
+            for mode in (0, 0x8000000):
+                lib.edt_hip_set_debug_mode(mode)
+                got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb, voxel_graph=g)
+                assert np.array_equal(got, want, equal_nan=True), (shape, an, bb, hex(mode))
+        finally:
+            lib.edt_hip_set_debug_mode(0)
+        assert np.array_equal(edt_gpu.edt(lab, anisotropy=an, black_border=bb, voxel_graph=g), np.sqrt(want), equal_nan=True)

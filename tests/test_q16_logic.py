@@ -138,6 +138,37 @@ def test_q16_refuses_values_off_the_quantum_grid(q16, oracle_port):
     assert list(tiles) == [True, False]
 
 
+@pytest.mark.parametrize("n,sx,kind", [(1024, 32, "cells"), (512, 64, "blocky"), (500, 36, "membrane"), (300, 40, "cells"),
+                                       (130, 96, "noise"), (257, 40, "blocky"), (64, 32, "cells"), (33, 8, "ones"), (16, 8, "blocky")])
+def test_q16_output_stride_two(q16, oracle_port, n, sx, kind):
+    """blocks of 16 rows whose even rows are evaluated and written (every row a candidate): the doubled grids of the
+    voxel-graph transform.  The even rows must be the oracle's, the odd ones untouched."""
+    rng = np.random.default_rng(n + sx)
+    lab = make_labels(n, sx, kind, rng)
+    for (wx, wy) in ((1.0, 1.0), (3.0, 15.0), (0.5, 0.5)):
+        ok, q, a = quantum(q16, (wx, wy))
+        assert ok
+        for bb in (True, False):
+            f1, _ = x_pass(oracle_port, lab, wx, bb)
+            want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
+            for epi in (0, 2):
+                out = np.full((n, sx), -1.0, dtype=np.float32)
+                tiles = np.zeros((sx + 31) // 32, dtype=np.uint8)
+                labc, fc = np.ascontiguousarray(lab, dtype=np.uint32), np.ascontiguousarray(f1)
+                q16.q16_emul_column_pass_even(labc.ctypes.data_as(ctypes.c_void_p), fc.ctypes.data_as(ctypes.c_void_p),
+                                              out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(sx), ctypes.c_int64(n),
+                                              ctypes.c_float(q), ctypes.c_uint32(a[1]), ctypes.c_int(int(bb)), ctypes.c_int(epi),
+                                              tiles.ctypes.data_as(ctypes.c_void_p))
+                exp = np.sqrt(want) if epi else want
+                for i, t_ok in enumerate(tiles):
+                    sl = slice(32 * i, min(sx, 32 * i + 32))
+                    if t_ok:
+                        assert np.array_equal(out[0::2, sl], exp[0::2, sl]), (n, sx, kind, wx, wy, bb, epi, i)
+                    assert (out[1::2, sl] == -1.0).all()
+                if bb:
+                    assert tiles.any()
+
+
 def test_q16_plane_between_passes(q16, oracle_port):
     """the results of a pass stay 16-bit (plane out), the next pass takes every row from the plane or from fp32 values
     (mixed input); a refused tile of the mixed form leaves its plane rows as fp32 values for the fp32 kernel"""

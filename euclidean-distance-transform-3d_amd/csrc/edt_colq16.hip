@@ -5,20 +5,25 @@
 // every configuration of BASELINE.json; the mathematics, the exactness argument and the per-lane code are in
 // edt_colq16_lane.h.  This file is the workgroup around it:
 //
-//   workgroup = one tile of 32 adjacent columns x the whole scan axis (as in edt_colwave_kernel.h), 256 threads;
-//   LDS image = the tile as 16-bit integers N = F / q, row-major, 64 bytes per row, one 32-row band of +inf (0xFFFF)
-//               before and after it: 36 KiB for a 512-row axis (the fp32 kernel: 80 KiB), 68 KiB for 1024 rows -- three /
-//               two workgroups per CU with whole 128-byte lines per row where the fp32 kernel has two / needs 16-column tiles;
-//   fill      = through VGPRs: the 16-bit distance indices k of pass X (index form, edt_rowwave.hip C16: N = k^2 * ax) or
-//               fp32 values (N = F / q, checked to be exact); a tile that holds a value outside the 16-bit range or off the
-//               quantum grid (rows without any boundary, objects more than ~250 voxels deep) is NOT processed: its id goes
-//               to a list in device memory and the fp32 kernel (edt_colwave_kernel.h, list mode) takes it afterwards;
+//   workgroup = one tile of 32 adjacent columns x the whole scan axis (as in edt_colwave_kernel.h): 256 threads up to 512
+//               rows, 512 beyond;
+//   LDS image = the tile as 16-bit integers N = F / q, row-major, 64 bytes per row, kPad = 16 rows of +inf (0xFFFF) before
+//               and after it: 34 KiB for a 512-row axis, 39.3 KiB with the planes (the fp32 kernel: 80 KiB) -- FOUR
+//               workgroups per CU (measured: 2 / 3 / 4 per CU -> 0.88 / 0.77 / 0.74 ms per cfg3 step); 68 KiB for 1024 rows --
+//               two workgroups of eight waves with whole 128-byte lines per row (the fp32 kernel needs 16-column tiles there);
+//   fill      = through VGPRs: the 16-bit distance indices k of pass X (index form, edt_rowwave.hip C16: N = k^2 * ax), or
+//               fp32 values (N = F / q, checked to be exact), or -- behind a pass that left its results 16-bit -- per row the
+//               16-bit plane or fp32 values; a tile that holds a value outside the 16-bit range or off the quantum grid (rows
+//               without any boundary, objects more than ~250 voxels deep) is NOT processed: its id goes to a list in device
+//               memory and the fp32 kernel (edt_colwave_kernel.h, list mode) takes it afterwards;
 //   scans     = run extents across bands by one thread per column and direction over the band words (LDS), break bits per
 //               block of 8 rows and column pair;
 //   windows   = lane = (column pair, block of 8 rows): a wave works on 16 pairs x the four blocks of one band, a contiguous
-//               32 x 32 patch, and walks the bands wave, wave + 4, ...;
+//               32 x 32 patch, and walks the bands wave, wave + T/64, ...  (output stride 2 -- the voxel graph's doubled
+//               grids --: blocks of 16 rows whose even rows are evaluated, 16 pairs x four such blocks per wave);
 //   results   = converted once at the end, (float)N * q (exact), optional correctly rounded sqrt, 8-byte stores (16 lanes =
-//               one 128-byte line per row).
+//               one 128-byte line per row); or the 16-bit values themselves, over the tile's indices (the plane between
+//               passes Y and Z); or the rows of the slab records of the Z-sharded path.
 #include "edt_common.h"
 #include "edt_kernels.h"
 
@@ -57,7 +62,8 @@ enum : int { kQ16InF32 = 0, kQ16InCodes = 1, kQ16InMixed = 2 };
 namespace {
 
 __host__ __device__ constexpr int q16_lds_words(int NB) {
-  // image (NB + 2 bands of 32 rows x 16 words) + run-start plane + lo/hi plane + break masks (16 pairs x 6 words) + flags
+  // image (NB bands of 32 rows + 2 kPad rows, 16 words each) + run-start plane + lo/hi plane + break masks (16 pairs x 6
+  // words) + flags
   return (NB * 32 + 2 * edt_q16::kPad) * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 8;
 }
 
@@ -68,7 +74,8 @@ __host__ __device__ constexpr int q16_lds_words(int NB) {
 // O16: the results go to the 16-bit plane (in place over the indices) instead of F; SC: ... to the slab records
 // T: threads of the workgroup -- 256 (four waves) up to 512 rows, 512 beyond (a 1024-row image leaves room for two
 // workgroups per CU: eight waves each keep the SIMDs as busy as the four workgroups of four waves of the shorter axes)
-// S: output stride -- 1 = every row; 2 = blocks of 16 rows whose even rows are evaluated and written (IN = fp32 only)
+// S: output stride -- 1 = every row; 2 = blocks of 16 rows whose even rows are evaluated and written (fp32 values in, or
+// indices in and a compact destination out)
 template <bool BB, int IN, bool O16, bool SC, int T, int S = 1>
 __global__ void __launch_bounds__(T, 4)
 k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, AxisGeom g, int tiles_x, int epi, int dbg,
@@ -78,7 +85,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   const int n = (int)g.n;
   const int NB = (int)g.nbands;
   const int nb32 = NB * 32;
-  uint32_t *img = q16_smem;                                // [(nb32 + 64)][16]
+  uint32_t *img = q16_smem;                                // [nb32 + 2 kPad][16]
   uint32_t *rsp = img + (nb32 + 2 * kPad) * kRowWords;     // [NB][32]
   uint32_t *lohi = rsp + NB * 32;                          // [NB][32]: (lo_in + 1) | (hi_out + 1) << 16
   uint32_t *bm = lohi + NB * 32;                           // [16][6]: break bits of the pair's blocks, words 1..4 (0, 5: zero)
@@ -380,7 +387,14 @@ template <bool BB>
 static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q16Args &qa, int in, bool o16, int epi,
                         hipStream_t stream, const BandScatter *scatter, int out_stride) {
   if (out_stride == 2) {
-    if (scatter != nullptr || o16 || in != kQ16InF32) { set_error("internal: output stride 2 takes fp32 in and out"); return EDT_ERR_BAD_ARG; }
+    if (scatter != nullptr || o16 || in == kQ16InMixed || (in == kQ16InCodes && qa.compact == nullptr)) {
+      set_error("internal: output stride 2 takes fp32 values (in place or compact) or indices (compact)");
+      return EDT_ERR_BAD_ARG;
+    }
+    if (in == kQ16InCodes) {
+      if (g.nbands > 16) return launch_q16_kt<BB, kQ16InCodes, false, false, 512, 2>(F, rs, g, qa, epi, stream, nullptr);
+      return launch_q16_kt<BB, kQ16InCodes, false, false, 256, 2>(F, rs, g, qa, epi, stream, nullptr);
+    }
     if (g.nbands > 16) return launch_q16_kt<BB, kQ16InF32, false, false, 512, 2>(F, rs, g, qa, epi, stream, nullptr);
     return launch_q16_kt<BB, kQ16InF32, false, false, 256, 2>(F, rs, g, qa, epi, stream, nullptr);
   }

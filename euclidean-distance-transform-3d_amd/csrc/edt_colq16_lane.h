@@ -39,7 +39,8 @@ namespace edt_q16 {
 typedef uint32_t pk;  // two unsigned 16-bit values: low half = the even column of the pair, high half = the odd one
 
 #ifndef EDT_Q16_K
-#define EDT_Q16_K 16  // (16: the image of a 512-row axis with its planes is 39.3 KiB, four workgroups per CU; 32: 41.4 KiB, three)
+#define EDT_Q16_K 16  // (16: the image of a 512-row axis with its planes is 39.3 KiB, four workgroups per CU; 32: 41.4 KiB, three;
+                      //  8 with the rolled loop from step 9 on: cfg3 0.72 -> 0.76 ms)
 #endif
 constexpr int kK = EDT_Q16_K;     // register-resident radius of the window (compile-time steps); further steps: rolled loop
 constexpr int kPad = kK;          // rows of +inf (0xFFFF) before row 0 and after the last band of the image

@@ -137,7 +137,8 @@ int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, co
 // the same reading pass 1 as 16-bit distance indices (F is write-only): see XFuse
 int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_t *nz, const uint32_t *rs,
                                   const AxisGeom &g, float w, int bb, int epi, float wx, int to_finite,
-                                  hipStream_t stream, const BandScatter *scatter = nullptr, const TileList &list = TileList());
+                                  hipStream_t stream, const BandScatter *scatter = nullptr, const TileList &list = TileList(),
+                                  const ColumnOut &out = ColumnOut());
 // ---- 16-bit integer column pass: edt_colq16.hip ---------------------------------------------------
 // the quantum of a call: w_i^2 = a[i] * q (false: the voxel sizes share none, the fp32 kernels keep the call)
 bool q16_quantum(const float *w, int naxes, float *q, uint32_t *a);

@@ -168,16 +168,22 @@ __global__ void k_vg_ttab(float *__restrict__ ttab, float w, int count) {
 // links: a doubled row whose mask equals F in EVERY chunk (wave-uniform test) is the (1,1) row and is not computed
 // again.  black_border: the border site left of the row is cell -1, the trimmed odd cell 2sx-1 is the nearest
 // background on the right of every row (src/edt_voxel_graph.hpp:156-187), rows 2sy-1 / slices 2sz-1 are background.
-template <typename T>
+// C16: the index form (edt_colwave_lane.h: code_value) -- where every multiple of the half voxel size is exact the rows leave as
+// 16-bit distance indices (in half cells; 0 = background, 0xFFFF = no boundary) instead of fp32 values: half the bytes out of
+// this kernel and into the first column pass.
+template <typename T, bool C16>
 __global__ void __launch_bounds__(256)
 k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const float *__restrict__ ttab,
-          float *__restrict__ F1, int sx, int sy, int sz, int Y2, int Z2, int bb, int idx_inf, float exact_w) {
+          float *__restrict__ F1, uint16_t *__restrict__ codes, int sx, int sy, int sz, int Y2, int Z2, int bb, int idx_inf,
+          float exact_w) {
   extern __shared__ float Tl[];
   // (exact_w > 0: every multiple of the half voxel size is exact in fp32 -- row_codes_exact --, so the sequential sums
   // ARE the multiples and no table kernel ran)
-  for (int i = (int)threadIdx.x; i <= idx_inf; i += (int)blockDim.x)
-    Tl[i] = exact_w > 0.0f ? (i < idx_inf ? (float)i * exact_w : INFINITY) : ttab[i];
-  __syncthreads();
+  if constexpr (!C16) {
+    for (int i = (int)threadIdx.x; i <= idx_inf; i += (int)blockDim.x)
+      Tl[i] = exact_w > 0.0f ? (i < idx_inf ? (float)i * exact_w : INFINITY) : ttab[i];
+    __syncthreads();
+  }
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
   const int NC = (sx + 63) >> 6;  // <= 32 (launcher)
   const bool three = Z2 > 1;
@@ -185,14 +191,25 @@ k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const
   const uint64_t below = (1ull << lane) - 1ull;                         // lanes before this one
   const uint64_t above = lane < 63 ? ~((2ull << lane) - 1ull) : 0ull;   // lanes after it
   const uint64_t above_own = ~below;                                    // this lane and the lanes after it
+  // (the value of a cell: fp32, or -- C16 -- its index, carried through the same float variables as an exact small integer)
   auto eval = [&](int il, int ir) -> float {
     il = il < idx_inf ? il : idx_inf;
     ir = ir < idx_inf ? ir : idx_inf;
-    const float tl = Tl[il], tr = Tl[ir];
-    const float d = tl < tr ? tl : tr;
-    float f = d * d;                                    // `d[i] *= d[i]` (src/edt.hpp:116-118)
-    if (!bb && f >= INFINITY) f = 3.402823466e+38f;     // tofinite (src/edt.hpp:39-45)
-    return f;
+    if constexpr (C16) {
+      // the table is non-decreasing: the smaller of the two values is the value at the smaller index
+      const int k = il < ir ? il : ir;
+      return (float)(k < idx_inf ? k : 0xFFFF);
+    } else {
+      const float tl = Tl[il], tr = Tl[ir];
+      const float d = tl < tr ? tl : tr;
+      float f = d * d;                                    // `d[i] *= d[i]` (src/edt.hpp:116-118)
+      if (!bb && f >= INFINITY) f = 3.402823466e+38f;     // tofinite (src/edt.hpp:39-45)
+      return f;
+    }
+  };
+  auto put = [&](int64_t at, float v) {
+    if constexpr (C16) codes[at] = (uint16_t)(int)v;
+    else F1[at] = v;
   };
   for (int64_t vrow = (int64_t)blockIdx.x * 4 + wave; vrow < nvrows; vrow += (int64_t)gridDim.x * 4) {
     const int y = (int)(vrow % sy), z = (int)(vrow / sy);
@@ -276,12 +293,12 @@ k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const
       }
       if (valid) {
         const int64_t r00 = ((int64_t)(2 * z) * Y2 + 2 * y) * sx + x;
-        F1[r00] = ownF ? 0.0f : f0;
-        F1[r00 + sx] = (own1 || deadY) ? 0.0f : f1;
+        put(r00, ownF ? 0.0f : f0);
+        put(r00 + sx, (own1 || deadY) ? 0.0f : f1);
         if (three) {
           const int64_t r01 = r00 + (int64_t)Y2 * sx;
-          F1[r01] = (own2 || deadZ) ? 0.0f : f2;
-          F1[r01 + sx] = (ownF || deadY || deadZ) ? 0.0f : f3;
+          put(r01, (own2 || deadZ) ? 0.0f : f2);
+          put(r01 + sx, (ownF || deadY || deadZ) ? 0.0f : f3);
         }
       }
 #pragma unroll
@@ -473,14 +490,26 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
   const float hx = wx / 2, hy = wy / 2, hz = wz / 2;
   const bool exact = row_codes_exact(hx, idx_inf);  // k * hx exact for every index of the table
   if (!exact) hipLaunchKernelGGL(k_vg_ttab, dim3(1), dim3(64), 0, stream, ttab, hx, idx_inf);
+  // Index form (3-D, rows of whole granules, exact multiples): pass X writes 16-bit indices into the SECOND half of the F1
+  // allocation; the Y pass reads them and writes its even rows -- all the Z pass reads -- compactly into the FIRST half
+  // ([z2][y][x], one row per voxel row).  (debug bits 0x100000 / 0x200000: the fp32 form / the separate gather pass.)
+  const bool index_form = exact && ndim == 3 && sx % 4 == 0 && idx_inf < 0xFFFF && !g_vg_debug_gather() &&
+                          !(debug_mode() & (0x100000 | 64));
+  uint16_t *codes = index_form ? reinterpret_cast<uint16_t *>(F1 + sx * sy * Z2) : nullptr;
   {
     const int64_t nvrows = sy * (ndim == 3 ? sz : 1);  // one wave per voxel row (its 2 or 4 doubled rows)
     int64_t blocks = ceil_div(nvrows, 4);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    static std::atomic<uint64_t> attr_done{0};
-    EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_vg_rows<T>)));
-    hipLaunchKernelGGL(k_vg_rows<T>, dim3((unsigned)blocks), dim3(256), (size_t)(idx_inf + 1) * sizeof(float), stream,
-                       labels, graph, ttab, F1, (int)sx, (int)sy, (int)sz, (int)Y2, (int)Z2, bb, idx_inf, exact ? hx : 0.0f);
+    if (index_form) {
+      hipLaunchKernelGGL((k_vg_rows<T, true>), dim3((unsigned)blocks), dim3(256), 0, stream, labels, graph, ttab, F1, codes,
+                         (int)sx, (int)sy, (int)sz, (int)Y2, (int)Z2, bb, idx_inf, hx);
+    } else {
+      static std::atomic<uint64_t> attr_done{0};
+      EDT_HIP_TRY(EDT_LDS_ATTR_ONCE(attr_done, reinterpret_cast<const void *>(&k_vg_rows<T, false>)));
+      hipLaunchKernelGGL((k_vg_rows<T, false>), dim3((unsigned)blocks), dim3(256), (size_t)(idx_inf + 1) * sizeof(float), stream,
+                         labels, graph, ttab, F1, codes, (int)sx, (int)sy, (int)sz, (int)Y2, (int)Z2, bb, idx_inf,
+                         exact ? hx : 0.0f);
+    }
   }
   {
     const int64_t total = sx * nbY * (ndim == 3 ? sz : 1);  // one thread per word of slice 2z AND of slice 2z+1
@@ -513,19 +542,26 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
           (reinterpret_cast<uintptr_t>(out) % 8) == 0;
     if (q16) EDT_HIP_TRY(hipMemsetAsync(q16_counts, 0, 8 * sizeof(uint32_t), stream));
   }
-  auto column_pass = [&](const uint32_t *nzp, const uint32_t *rsp, const AxisGeom &g, float h, int axis, int epi, const ColumnOut &co,
-                         uint32_t *count) -> int {
+  // in16 != nullptr: the pass reads pass X as 16-bit indices (and writes compactly: co.compact)
+  auto column_pass = [&](const uint16_t *in16, const uint32_t *nzp, const uint32_t *rsp, const AxisGeom &g, float h, int axis, int epi,
+                         const ColumnOut &co, uint32_t *count) -> int {
     TileList list;
     if (q16 && column_pass_q16_supported(g) && column_pass_wave_supported(g)) {
-      const int r = launch_column_pass_q16(F1, nullptr, rsp, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, q16_ids, stream, nullptr,
+      const int r = launch_column_pass_q16(F1, in16, rsp, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, q16_ids, stream, nullptr,
                                            nullptr, nullptr, 0, &co);
       if (r != EDT_OK) return r;
       list.count = count;
       list.ids = q16_ids;
     }
+    if (in16 != nullptr)
+      return launch_column_pass_wave_codes(F1, in16, nzp, rsp, g, h, bb, epi, hx, bb ? 0 : 1, stream, nullptr, list, co);
     return launch_column_pass_wave(F1, nzp, rsp, g, h, bb, epi, stream, nullptr, co, list);
   };
-  int rc = column_pass(nzY, rsY, gy, hy, 1, ndim == 2 ? last_epi : 0, ndim == 2 ? last : even, q16_counts);
+  ColumnOut ycompact = even;  // index form: the even rows of the Y pass, one per voxel row, in the first half of F1
+  ycompact.compact = F1;
+  ycompact.outer = sx * sy;
+  ycompact.row2 = sx;
+  int rc = column_pass(codes, nzY, rsY, gy, hy, 1, ndim == 2 ? last_epi : 0, index_form ? ycompact : (ndim == 2 ? last : even), q16_counts);
   if (rc != EDT_OK) return rc;
   if (ndim == 3) {
     const int64_t total = sx * nbZ * sy;
@@ -534,9 +570,10 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
     hipLaunchKernelGGL((k_vg_bits_z<T>), dim3((unsigned)blocks), dim3(256), 0, stream, labels, graph, nzZ, rsZ,
                        (int)sx, (int)sy, (int)sz, (int)Z2, (int)nbZ, bb);
     EDT_HIP_TRY(hipGetLastError());
-    AxisGeom gz;  // the even rows only: outer index = y, two doubled rows apart
+    AxisGeom gz;  // the even rows only: outer index = y, two doubled rows apart (index form: the compact rows of the Y pass)
     gz.sx = sx; gz.n = Z2; gz.stride = sx * Y2; gz.nouter = sy; gz.outer_stride = 2 * sx; gz.nbands = nbZ;
-    rc = column_pass(nzZ, rsZ, gz, hz, 2, last_epi, last, q16_counts + 1);
+    if (index_form) { gz.stride = sx * sy; gz.outer_stride = sx; }
+    rc = column_pass(nullptr, nzZ, rsZ, gz, hz, 2, last_epi, last, q16_counts + 1);
     if (rc != EDT_OK) return rc;
   }
   if (last.compact != nullptr) return EDT_OK;

@@ -79,10 +79,12 @@ def test_q16_binary_route_and_bool(edt_gpu, oracle_port):
         assert np.array_equal(got, want), name
 
 
-@pytest.mark.parametrize("shape", [(64, 80, 72), (128, 200, 100), (36, 300, 70), (260, 260)])
+@pytest.mark.parametrize("shape", [(64, 80, 72), (128, 200, 100), (36, 300, 70), (66, 50, 40), (260, 260)])
 def test_q16_voxel_graph_output_stride_two(edt_gpu, oracle_port, shape):
     """the doubled grids of the voxel-graph transform on the integer kernel (blocks of 16 rows, even rows evaluated, the last
-    pass writing the caller's array): against the oracle and against the fp32 kernels; band counts odd and even"""
+    pass writing the caller's array): against the oracle and against the fp32 kernels; band counts odd and even.  Rows of
+    whole granules take the index form (16-bit indices out of pass X, compact even rows out of pass Y): debug bit 0x100000
+    keeps the fp32 form, 0x8000000 the fp32 kernels on either form."""
     from synth import blob_mask
     from edt import _lib
     lib = _lib.load()
@@ -95,7 +97,7 @@ def test_q16_voxel_graph_output_stride_two(edt_gpu, oracle_port, shape):
         an = an[:len(shape)]
         want = oracle_port.edtsq(lab, an, bb, voxel_graph=g)
         try:
-            for mode in (0, 0x8000000):
+            for mode in (0, 0x8000000, 0x100000, 0x100000 | 0x8000000):
                 lib.edt_hip_set_debug_mode(mode)
                 got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb, voxel_graph=g)
                 assert np.array_equal(got, want, equal_nan=True), (shape, an, bb, hex(mode))

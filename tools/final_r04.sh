@@ -14,9 +14,13 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a gpuru
   echo "the same shapes on the fp32 kernels (0x8000000), 80 cases:";     FUZZ_Q16=1 EDT_HIP_DEBUG_MODE=0x8000000 python tools/fuzz_gpu.py 80 85 2>&1 | tail -1
   echo "every tile windowed (0x4000), 150 cases:";             EDT_HIP_DEBUG_MODE=0x4000 python tools/fuzz_gpu.py 150 86 2>&1 | tail -1
   echo "hulls only (0x2000), 150 cases:";                      EDT_HIP_DEBUG_MODE=0x2000 python tools/fuzz_gpu.py 150 87 2>&1 | tail -1
+  echo "voxel-graph transform (FUZZ_VG=1), 300 cases:";        FUZZ_VG=1 python tools/fuzz_gpu.py 300 88 2>&1 | tail -1
+  echo "the same, fp32 form of its pass X (0x100000), 150 cases:";       FUZZ_VG=1 EDT_HIP_DEBUG_MODE=0x100000 python tools/fuzz_gpu.py 150 89 2>&1 | tail -1
+  echo "the same on the fp32 column kernels (0x8000000), 150 cases:";    FUZZ_VG=1 EDT_HIP_DEBUG_MODE=0x8000000 python tools/fuzz_gpu.py 150 90 2>&1 | tail -1
 } > gpurun_out/r04_fuzz.txt 2>&1
 cat gpurun_out/r04_fuzz.txt
-./tools/profile_r04.sh > gpurun_out/r04_profile.log 2>&1; tail -2 gpurun_out/r04_profile.log
+# (SKIP_PROFILE=1: a closing session after a change that left the profiled kernels alone)
+if [ -z "$SKIP_PROFILE" ]; then ./tools/profile_r04.sh > gpurun_out/r04_profile.log 2>&1; tail -2 gpurun_out/r04_profile.log; fi
 python tools/rank_shape_probe.py 2>&1 | tail -3 | tee gpurun_out/r04_rank_shape_probe.txt
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
 python - <<'PY'

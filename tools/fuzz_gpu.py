@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle fuzz over shapes / dtypes / label structures (diagnostics; the regular
-parity tests live in tests/).  usage: python tools/fuzz_gpu.py [ncases] [seed]"""
+parity tests live in tests/).  usage: [FUZZ_Q16=1 | FUZZ_VG=1] python tools/fuzz_gpu.py [ncases] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "euclidean-distance-transform-3d_amd"), os.path.join(ROOT, "tests")):
@@ -38,7 +38,15 @@ for i in range(ncases):
             shape = (shape[0], shape[2], shape[1])
         if rng.random() < 0.15:
             shape = (4 * int(rng.integers(1, 12)), int(rng.integers(513, 1100)), int(rng.integers(97, 200)))
-    if np.prod(shape) > (3e7 if q16 else 6e6):
+    vg = os.environ.get("FUZZ_VG") == "1"
+    if vg:
+        # the voxel-graph transform (csrc/edt_voxel_graph.hip): doubled column axes of 8..1200 rows, rows of whole granules
+        # (index form) and not, random cut links
+        dims = 3 if rng.random() < 0.8 else 2
+        shape = [int(rng.integers(1, 40)) * (4 if rng.random() < 0.6 else 1) + int(rng.integers(0, 2)) * int(rng.random() < 0.3)]
+        shape += [int(rng.integers(4, 600 if rng.random() < 0.2 else 120)) for _ in range(dims - 1)]
+        shape = tuple(shape)
+    if np.prod(shape) > (3e7 if q16 else 4e5 if vg else 6e6):
         continue
     kind = rng.integers(0, 3)
     if kind == 0:
@@ -46,13 +54,26 @@ for i in range(ncases):
     else:
         lab = blocky_labels(shape, nlabels=int(rng.integers(1, 6)) if not q16 or rng.random() < 0.5 else int(rng.integers(20, 400)),
                             zero_frac=float(rng.random() * 0.3), block=int(rng.integers(1, 50 if not q16 else 120)), rng=rng)
+    g = None
+    if vg:
+        g = np.full(shape, 0b00111111 if dims == 3 else 0b00001111, dtype=np.uint8)
+        for bit in (0x01, 0x02, 0x04, 0x08, 0x10, 0x20)[:2 * dims]:
+            g[rng.random(shape) < rng.choice([0.0, 0.01, 0.1])] &= np.uint8(~bit & 0xFF)
     dt = dtypes[i % len(dtypes)]
-    lab = np.asfortranarray(lab.astype(dt)) if rng.random() < 0.7 else np.ascontiguousarray(lab.astype(dt))
+    lab = np.asfortranarray(lab.astype(dt)) if vg or rng.random() < 0.7 else np.ascontiguousarray(lab.astype(dt))
+    if vg:
+        g = np.asfortranarray(g)
     an = tuple(float(a) for a in rng.choice([1, 2, 6, 30, 0.5, 4, 40, 3] if q16 else [1, 2, 6, 30, 0.5, 1.3, 7.25], size=dims))
     bb = bool(rng.integers(0, 2))
-    want = o.edtsq(lab, an, bb)
-    got = edt.edtsq(lab, anisotropy=an, black_border=bb)
-    if not np.array_equal(got, want):
+    if vg:
+        if rng.random() < 0.7:
+            an = tuple(float(a) for a in rng.choice([1, 2, 6, 30, 4], size=dims))  # (sizes that share a quantum: integer kernel)
+        want = o.edtsq(lab, an, bb, voxel_graph=g)
+        got = edt.edtsq(lab, anisotropy=an, black_border=bb, voxel_graph=g)
+    else:
+        want = o.edtsq(lab, an, bb)
+        got = edt.edtsq(lab, anisotropy=an, black_border=bb)
+    if not np.array_equal(got, want, equal_nan=True):
         bad += 1
         print("MISMATCH", shape, dt.__name__, an, bb, int((got != want).sum()))
 print(f"{ncases} cases, {bad} mismatches, {time.time() - t0:.1f} s")

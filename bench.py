@@ -441,7 +441,8 @@ def sharded_main(args, rank, world, dev):
     # what travels: this rank's slab records for every OTHER rank (4 B x record length x its slices), max over ranks
     sent = 0
     if plan.records:
-        rec = [plan.ops.record_floats(plan.sx, b - a) for a, b in plan.yparts]
+        # (16-bit rows where the integer kernel takes both column passes: 2.25 bytes per voxel instead of 4.25)
+        rec = [(plan.ops.record16_words if plan.last_records16 else plan.ops.record_floats)(plan.sx, b - a) for a, b in plan.yparts]
         sent = 4 * (ze - zs) * sum(rec[h] for h in range(world) if h != rank)
     else:
         sent = 5 * sum((ze - zs) * (b - a) * plan.sx for h, (a, b) in enumerate(plan.yparts) if h != rank)
@@ -536,7 +537,9 @@ def sharded_main(args, rank, world, dev):
                                    f"anisotropy {an}, black_border={bb}, Z-sharded over {world} GPUs, "
                                    "one all-to-all (Z-slabs -> Y-slabs) before the z pass",
                        "labels": kind, "global_extents": list(ext),
-                       "form": "slab records" if plan.records else "byte flags",
+                       "form": ("slab records, 16-bit rows" if plan.last_records16 else "slab records, fp32 rows") if plan.records
+                               else "byte flags",
+                       "records16_fallbacks": getattr(plan, "fallbacks16", 0),
                        "chunks": getattr(plan, "nchunks", 1),
                        "output_verified": verified, "verified_by": how,
                        "single_gpu_same_workload": same_n1},
@@ -544,7 +547,7 @@ def sharded_main(args, rank, world, dev):
             # how to read a SCALE curve: per-rank kernel time (rank 0, per step, chunks summed), the slowest rank's
             # kernel sum, the exposed part of the exchange (measured with events around the waits; ~0 when it hides
             # under the next chunk's kernels), and the bytes the busiest rank sends per step over xGMI
-            # (7 links x ~153 GB/s per GPU: bytes / (world - 1) per link)
+            # (7 links x 153.6 GB/s bidirectional = 76.8 GB/s per direction: bytes / (world - 1) per link)
             "per_rank": {"kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
                          "kernel_ms_note": "hipEvents per kernel, chunks summed; chunks run on two streams, so overlapping "
                                            "kernels are each timed at their stretched duration and the sum may exceed the step",
@@ -553,7 +556,7 @@ def sharded_main(args, rank, world, dev):
                          "exchange_ms_exposed_note": "events on the compute stream around the waits for the slab records: how long "
                                                      "the slowest rank sat between its last XY kernel and the last record's arrival",
                          "bytes_exchanged": int(sent_t.item()),
-                         "link_floor_ms": round(int(sent_t.item()) / max(1, world - 1) / 153e9 * 1e3, 4) if world > 1 else 0.0},
+                         "link_floor_ms": round(int(sent_t.item()) / max(1, world - 1) / 76.8e9 * 1e3, 4) if world > 1 else 0.0},
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu
@@ -601,7 +604,10 @@ def selftest(rank, world, dev, ext, kind):
         # message sizes of the real run (slab records): what rank r sends to rank h per chunk and per step
         plan = ShardedEDT(ext, _lib.U32)
         if plan.records:
-            rec = [plan.ops.record_floats(plan.sx, b - a) for a, b in plan.yparts]
+            an = (6.0, 6.0, 30.0) if kind == "ones" else (1.0, 1.0, 1.0)  # (the voxel sizes of the run to come: sharded_leg)
+            use16 = plan._use16(an)
+            say(f"slab records with {'16-bit rows (2.25 B/voxel; a step that meets a tile beyond 16 bits is repeated with fp32 rows)' if use16 else 'fp32 rows (4.25 B/voxel)'}")
+            rec = [(plan.ops.record16_words if use16 else plan.ops.record_floats)(plan.sx, b - a) for a, b in plan.yparts]
             for r in range(world):
                 per_chunk = [[4 * (plan._chunk(r, k)[1] - plan._chunk(r, k)[0]) * rec[h] if h != r else 0 for h in range(world)]
                              for k in range(plan.nchunks)]
@@ -625,6 +631,19 @@ def selftest(rank, world, dev, ext, kind):
         dist.barrier()
         if rank == 0 and ok is False:
             raise SystemExit("[selftest] the tiny sharded transform differs from the CPU checker")
+        # ... and one whose axes are long enough for the 16-bit records (97..1024 rows of y and z), at voxel sizes that share a quantum
+        small16 = (64, 32 * world + 72, 8 * world + 97)
+        tiny16 = ShardedEDT(small16, _lib.U32, chunks=2)
+        zs, ze = tiny16.local_z()
+        lab = slab_labels(small16, zs, ze, dev, "cfg4")
+        out = tiny16.run(lab, (6.0, 6.0, 30.0), black_border=True)
+        torch.cuda.synchronize()
+        ok, how, _ = _verify_against_reference(tiny16, lab, out, small16, (6.0, 6.0, 30.0), True, rank, world, dev, force=True)
+        say(f"tiny volume {small16} over {world} rank(s), 16-bit records used: {tiny16.last_records16} (fallbacks {tiny16.fallbacks16}): "
+            f"output_verified={ok} ({how})")
+        dist.barrier()
+        if rank == 0 and ok is False:
+            raise SystemExit("[selftest] the tiny sharded transform over 16-bit records differs from the CPU checker")
     except BaseException as e:
         print(f"[selftest] rank {rank} FAILED: {e!r}", flush=True)
         raise

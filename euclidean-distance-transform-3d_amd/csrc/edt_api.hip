@@ -808,6 +808,11 @@ static int64_t record_floats(int64_t sx, int64_t ylen) {
   return ylen * sx + 2 * ceil_div(ylen, kBandRows) * sx;
 }
 
+// (records of 16-bit values, where every pass runs on the integer column kernel: the rows as packed 16-bit pairs)
+static int64_t record16_words(int64_t sx, int64_t ylen) {
+  return ylen * sx / 2 + 2 * ceil_div(ylen, kBandRows) * sx;
+}
+
 struct RecordPlan {
   float *F = nullptr;                                      // pass 1 output of the slab (XY phase)
   uint32_t *nz_y = nullptr, *ys_y = nullptr, *zs_y = nullptr;  // y-packed planes of the slab
@@ -1297,6 +1302,153 @@ static int shard_z_records(float *d_records, int64_t sx, int64_t sy_local, int64
     }
   }
   return launch_column_pass_wave(d_records, p.nz_z, p.rs_z, gz, wz, bb, epi, stream, nullptr, ColumnOut(), list);
+}
+
+// ---- slab records of 16-bit values ---------------------------------------------------------------------------------------
+// Where the three voxel sizes share a quantum (edt_colq16.hip) and both column axes fit the integer kernel, the Y pass's
+// results are integers N < 2^16 (in quanta): a record then carries its rows as 16-bit values -- 2.25 bytes per voxel over
+// the links instead of 4.25 -- and the Z phase reads them as they are.  A tile the integer kernel cannot take (values beyond
+// 16 bits, rows without a boundary) has no 16-bit form: the XY phase COUNTS such tiles in *d_refused (a device counter the
+// caller zeroes and reads; it accumulates over calls) and leaves their rows unspecified -- a caller that finds it non-zero
+// repeats the step with the fp32 records above (edt/distributed.py does).
+static bool records16_common_ok(int64_t sx, float wx, float wy, float wz) {
+  if (sx % 4 != 0 || (g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x100000 | 0x8000000 | 0x10000000))) return false;
+  if (!row_codes_exact(wx, sx)) return false;
+  const float w3[3] = {wx, wy, wz};
+  float q = 1.0f;
+  uint32_t a[3];
+  return q16_quantum(w3, 3, &q, a);
+}
+// the XY phase of a slab of sz_local slices / the Z phase of a slab of sy_local rows: the scan axis on the integer kernel
+static bool records16_xy_ok(int dtype, int64_t sx, int64_t sy, int64_t sz_local, float wx, float wy, float wz) {
+  if (!edt_hip_shard_records_supported(dtype, sx, sy, sz_local) || !records16_common_ok(sx, wx, wy, wz)) return false;
+  const AxisGeom gy = make_geom_y(sx, sy, sz_local);
+  return column_pass_q16_supported(gy) && column_pass_wave_supported(gy);
+}
+static bool records16_z_ok(int64_t sx, int64_t sy_local, int64_t sz, float wx, float wy, float wz) {
+  if (!edt_hip_shard_records_supported(EDT_U8, sx, sy_local, sz) || !records16_common_ok(sx, wx, wy, wz)) return false;
+  const AxisGeom gz = make_geom_z(sx, sy_local, sz);
+  return column_pass_q16_supported(gz) && column_pass_wave_supported(gz);
+}
+
+int edt_hip_shard_records16_supported(int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz) {
+  if (dtype_size(dtype) == 0 || sx < 1 || sy < 1 || sz < 1) return 0;
+  // (whatever part of z or y a rank holds, its scan axis is whole: sy for the XY phase, sz for the Z phase)
+  return (records16_xy_ok(dtype, sx, sy, 1, wx, wy, wz) && records16_z_ok(sx, 32, sz, wx, wy, wz)) ? 1 : 0;
+}
+
+size_t edt_hip_shard_record16_words(int64_t sx, int64_t y_rows) {
+  if (sx < 0 || y_rows < 0 || sx % 2 != 0) return 0;
+  return (size_t)record16_words(sx, y_rows);
+}
+
+int edt_hip_shard_xy_records16_device(const void *d_labels, const void *d_halo, int dtype, int64_t sx, int64_t sy,
+                                      int64_t sz_local, float wx, float wy, float wz, int flags, int nparts,
+                                      const int64_t *y_splits, void *const *d_blocks, uint32_t *d_refused, void *d_workspace,
+                                      size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape(dtype, 3, sx, sy, sz_local);
+  if (rc != EDT_OK) return rc;
+  if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
+  if (!d_labels || !y_splits || !d_blocks || !d_refused || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
+  if (y_splits[0] != 0 || y_splits[nparts] != sy) { set_error("y_splits must run from 0 to sy"); return EDT_ERR_BAD_ARG; }
+  for (int h = 0; h < nparts; ++h) {
+    if (y_splits[h + 1] <= y_splits[h] || (y_splits[h] % kBandRows) != 0) {
+      set_error("y_splits must be increasing multiples of 32 (the last one is sy)");
+      return EDT_ERR_BAD_ARG;
+    }
+    if (!d_blocks[h] || (reinterpret_cast<uintptr_t>(d_blocks[h]) % 16) != 0) {
+      set_error("destination blocks must be non-null and 16-byte aligned");
+      return EDT_ERR_BAD_ARG;
+    }
+  }
+  const float w3[3] = {wx, wy, wz};
+  float q = 1.0f;
+  uint32_t a[3];
+  AxisGeom gy = make_geom_y(sx, sy, sz_local);
+  if (!records16_xy_ok(dtype, sx, sy, sz_local, wx, wy, wz) || !q16_quantum(w3, 3, &q, a)) {
+    set_error("16-bit slab records do not apply to these extents / voxel sizes (edt_hip_shard_records16_supported)");
+    return EDT_ERR_UNSUPPORTED;
+  }
+  RecordPlan p = make_record_plan(sx, sy, sz_local, d_workspace);
+  if (!d_workspace || workspace_bytes < p.bytes) {
+    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
+    return EDT_ERR_BAD_ARG;
+  }
+  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  // destination map in 4-byte words: a record = ylen * sx / 2 words of 16-bit pairs, then the two bit planes
+  BandScatter sc;
+  for (int b = 0, h = 0; b < BandScatter::kBands; ++b) {
+    if (b >= gy.nbands) { sc.rows[b] = nullptr; sc.bits[b] = nullptr; sc.ostride[b] = 0; sc.plane[b] = 0; continue; }
+    while ((int64_t)b * kBandRows >= y_splits[h + 1]) ++h;
+    const int64_t ys = y_splits[h], ylen = y_splits[h + 1] - ys, words = ceil_div(ylen, kBandRows);
+    float *blk = static_cast<float *>(d_blocks[h]);
+    sc.rows[b] = blk + (((int64_t)b * kBandRows - ys) * sx) / 2;
+    sc.bits[b] = reinterpret_cast<uint32_t *>(blk + ylen * sx / 2) + ((int64_t)b - ys / kBandRows) * sx;
+    sc.ostride[b] = record16_words(sx, ylen);
+    sc.plane[b] = words * sx;
+  }
+  uint16_t *codes = reinterpret_cast<uint16_t *>(p.F);
+  {
+    ScopedPass t("x_pass", stream);
+    rc = launch_row_pass_wave(dtype, d_labels, p.F, p.nz_y, p.ys_y, p.zs_y, sx, sy, sz_local, wx, bb, bb ? 0 : 1, stream,
+                              d_halo, codes);
+    if (rc != EDT_OK) return rc;
+  }
+  {
+    ScopedPass t("pack_bits", stream);
+    rc = launch_pack_record_bits(p.nz_y, p.zs_y, sc, p.table, sx, gy.nbands, sz_local, stream);
+    if (rc != EDT_OK) return rc;
+  }
+  ScopedPass t("y_pass", stream);
+  // (plane: any non-null value selects the 16-bit output; the destinations are the table's)
+  return launch_column_pass_q16(p.F, codes, p.ys_y, gy, q, a[1], a[0], bb, 0, d_refused, nullptr, stream, p.table, codes);
+}
+
+int edt_hip_shard_z_records16_device(const void *d_records, float *d_out, int64_t sx, int64_t sy_local, int64_t sz, float wx,
+                                     float wy, float wz, int flags, void *d_workspace, size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
+  if (rc != EDT_OK) return rc;
+  if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
+  if (!d_records || !d_out) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
+  const float w3[3] = {wx, wy, wz};
+  float q = 1.0f;
+  uint32_t a[3];
+  AxisGeom gz = make_geom_z(sx, sy_local, sz);  // the dense output: z-columns one (sy_local, sx) slice apart
+  gz.fmin = edt_hip_field_floor(wx, wy);
+  if (!records16_z_ok(sx, sy_local, sz, wx, wy, wz) || !q16_quantum(w3, 3, &q, a) ||
+      ((reinterpret_cast<uintptr_t>(d_records) | reinterpret_cast<uintptr_t>(d_out)) % 16) != 0) {
+    set_error("16-bit slab records do not apply to these extents / voxel sizes (edt_hip_shard_records16_supported)");
+    return EDT_ERR_UNSUPPORTED;
+  }
+  RecordPlan p = make_record_plan(sx, sy_local, sz, d_workspace);
+  if (!d_workspace || workspace_bytes < p.bytes) {
+    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
+    return EDT_ERR_BAD_ARG;
+  }
+  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
+  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
+  const int64_t rec = record16_words(sx, sy_local), words = ceil_div(sy_local, kBandRows);
+  const uint32_t *base = static_cast<const uint32_t *>(d_records);
+  const uint32_t *nz_y = base + sy_local * sx / 2;
+  {
+    ScopedPass t("z_bits", stream);
+    rc = launch_bits_transpose_yz(nz_y, nz_y + words * sx, p.nz_z, p.rs_z, sx, sy_local, sz, stream, rec);
+    if (rc != EDT_OK) return rc;
+  }
+  ScopedPass t("z_pass", stream);
+  // every row out of the records (16-bit elements: consecutive z are 2 * rec of them apart), results to the dense array; a
+  // tile beyond THIS pass's limits gets its rows written there as fp32 values and goes to the fp32 kernel, in place
+  EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, 4 * sizeof(uint32_t), stream));
+  uint16_t *plane = reinterpret_cast<uint16_t *>(const_cast<void *>(d_records));
+  rc = launch_column_pass_q16(d_out, nullptr, p.rs_z, gz, q, a[2], a[0], bb, epi, p.q16_counts, p.q16_ids, stream, nullptr, plane,
+                              nullptr, 0, nullptr, 2 * rec, sx);
+  if (rc != EDT_OK) return rc;
+  TileList list;
+  list.count = p.q16_counts;
+  list.ids = p.q16_ids;
+  return launch_column_pass_wave(d_out, p.nz_z, p.rs_z, gz, wz, bb, epi, stream, nullptr, ColumnOut(), list);
 }
 
 int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, int64_t count,

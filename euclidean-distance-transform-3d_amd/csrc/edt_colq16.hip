@@ -50,8 +50,9 @@ struct Q16Args {
   // results N over its indices (plane == codes, in place) instead of fp32 values to F and sets its bit in `map`
   // ([x-tile][outer index / 32], zeroed by the caller); pass Z takes every row from wherever pass Y left it.
   uint16_t *plane;
-  uint32_t *map;
+  uint32_t *map;          // (nullptr with a plane to read: every row is in the plane; with a plane to write: no map kept)
   int map_words;          // words per x-tile
+  int64_t pst, p_outer;   // the plane's own row / outer strides in 16-bit elements (slab records: edt_api.hip), else g's
   // output stride 2 (S = 2: the doubled grids of the voxel-graph transform) only: nullptr = the even rows go to their places
   // in F; else row r of column (x, outer o) goes to compact[x + o * c_outer + (r / 2) * c_row2]   (edt_kernels.h: ColumnOut)
   float *compact;
@@ -150,8 +151,10 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     }
   } else {
     const float *src = F + x0 + o * g.outer_stride + 4 * cg;
-    const uint16_t *src16 = qa.plane + x0 + o * g.outer_stride + 4 * cg;
+    const uint16_t *src16 = qa.plane + x0 + o * qa.p_outer + 4 * cg;
+    const int64_t pst = qa.pst;
     const uint32_t *mapw = qa.map + xt * qa.map_words;  // (IN == kQ16InMixed: bit z = row z of this x-tile is in the plane)
+    const bool all16 = qa.map == nullptr;                // (wave-uniform: kernel argument)
     const pk nlimpk = pk_both(qa.nlim);
     const float flim = (float)qa.nlim + 1.0f;
     // (eight loads per thread in flight; all sixteen of a 512-row tile at once measured no faster -- cfg2 Z 0.237 vs
@@ -169,13 +172,13 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
         bool p16 = false;
         if constexpr (IN == kQ16InMixed) {
           const int mrow = row < n ? row : 0;
-          const uint32_t mw = mapw[__builtin_amdgcn_readfirstlane(mrow >> 5)];
+          const uint32_t mw = all16 ? ~0u : mapw[__builtin_amdgcn_readfirstlane(mrow >> 5)];
           p16 = row < n && ((mw >> (row & 31)) & 1u) != 0u;
         }
         if (p16) {
           in16 |= 1u << j;
           if (col_ok) {
-            const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(src16 + (int64_t)row * st));
+            const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(src16 + (int64_t)row * pst));
             raw[j][0] = v[0];
             raw[j][1] = v[1];
           }
@@ -224,7 +227,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       const uint32_t *mapw = qa.map + xt * qa.map_words;
       float *dstF = F + x0 + o * g.outer_stride + 4 * cg;
       for (int row = r_in; row < n; row += RPS) {
-        if (((mapw[row >> 5] >> (row & 31)) & 1u) != 0u && col_ok) {
+        if ((qa.map == nullptr || ((mapw[row >> 5] >> (row & 31)) & 1u) != 0u) && col_ok) {
           const v2u v = *reinterpret_cast<const v2u *>(img + (row + kPad) * kRowWords + 2 * cg);
           *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) =
               (v4f){(float)(v[0] & 0xFFFFu) * qa.q, (float)(v[0] >> 16) * qa.q, (float)(v[1] & 0xFFFFu) * qa.q, (float)(v[1] >> 16) * qa.q};
@@ -232,7 +235,9 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       }
     }
     if (t == 0) {
-      if (qa.list_cols == 32) {
+      if (qa.ids == nullptr) {
+        atomicAdd(qa.count, 1u);  // (slab records of 16-bit values: the caller counts, nobody can serve the tile)
+      } else if (qa.list_cols == 32) {
         const uint32_t idx = atomicAdd(qa.count, 1u);
         qa.ids[idx] = (uint32_t)tile_id;
       } else {
@@ -245,7 +250,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     }
     return;
   }
-  if constexpr (O16) {
+  if constexpr (O16 && !SC) {
     if (t == 0) atomicOr(qa.map + xt * qa.map_words + (int)(o >> 5), 1u << (o & 31));
   }
 
@@ -320,7 +325,9 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       dstep = st * S;
     }
     if constexpr (O16) {
-      auto *ndst = (__attribute__((address_space(1))) uint32_t *)(qa.plane + x0 + o * g.outer_stride + 2 * cp);
+      // (SC: the record's rows are 16-bit here -- the table's pointers and strides count 4-byte words, a row is st / 2 of them)
+      auto *ndst = SC ? (__attribute__((address_space(1))) uint32_t *)dst - ((x0 + 2 * cp) >> 1) + (((int64_t)s * 32 * st) >> 1)
+                      : (__attribute__((address_space(1))) uint32_t *)(qa.plane + x0 + o * g.outer_stride + 2 * cp);
 #pragma unroll
       for (int j = 0; j < kB; ++j) {
         const int row = L.p0 + j;
@@ -399,7 +406,8 @@ static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q
     return launch_q16_kt<BB, kQ16InF32, false, false, 256, 2>(F, rs, g, qa, epi, stream, nullptr);
   }
   if (scatter != nullptr) {
-    if (o16 || in == kQ16InMixed) { set_error("internal: 16-bit plane with slab records"); return EDT_ERR_BAD_ARG; }
+    if (in == kQ16InMixed || (o16 && in != kQ16InCodes)) { set_error("internal: slab records take indices or fp32 rows"); return EDT_ERR_BAD_ARG; }
+    if (o16) return launch_q16_k<BB, kQ16InCodes, true, true>(F, rs, g, qa, epi, stream, scatter);  // 16-bit records
     return in == kQ16InCodes ? launch_q16_k<BB, kQ16InCodes, false, true>(F, rs, g, qa, epi, stream, scatter)
                              : launch_q16_k<BB, kQ16InF32, false, true>(F, rs, g, qa, epi, stream, scatter);
   }
@@ -414,9 +422,13 @@ static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q
 // a: c_d = a * d^2 quanta of this pass; ain: quanta per squared index of pass X (codes != nullptr).
 // plane / map != nullptr: with codes -- the results go to the 16-bit plane (= codes, in place) and the tile's bit is set in
 // map; without -- the rows are taken from the plane wherever map says so (the pass after such a pass).
+// Slab records of 16-bit values (edt_api.hip): with codes, a scatter table AND a plane (any non-null value) the results go to
+// the table's destinations as 16-bit rows, refused tiles are only counted (ids == nullptr); without codes, map == nullptr
+// and plane_stride > 0 every row is read from the plane at its own strides (16-bit elements) and F is only written.
 int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
                            uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
-                           const BandScatter *scatter, uint16_t *plane, uint32_t *map, int map_words, const ColumnOut *out) {
+                           const BandScatter *scatter, uint16_t *plane, uint32_t *map, int map_words, const ColumnOut *out,
+                           int64_t plane_stride, int64_t plane_outer) {
   Q16Args qa;
   qa.codes = codes;
   qa.q = q;
@@ -434,6 +446,8 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
   qa.plane = plane;
   qa.map = map;
   qa.map_words = map_words;
+  qa.pst = plane_stride > 0 ? plane_stride : g.stride;
+  qa.p_outer = plane_stride > 0 ? plane_outer : g.outer_stride;
   qa.compact = out ? out->compact : nullptr;
   qa.c_outer = out ? out->outer : 0;
   qa.c_row2 = out ? out->row2 : 0;

@@ -78,6 +78,10 @@ SIGNATURES = {
     "edt_hip_shard_z_device_ex": (_i, [_vp, _vp, _i64, _i64, _i64, _f, _f, _i, _vp, _sz, _vp]),
     "edt_hip_shard_z_records_device_ex": (_i, [_vp, _i64, _i64, _i64, _f, _f, _i, _vp, _sz, _vp]),
     "edt_hip_shard_z_records_device_w": (_i, [_vp, _i64, _i64, _i64, _f, _f, _f, _i, _vp, _sz, _vp]),
+    "edt_hip_shard_records16_supported": (_i, [_i, _i64, _i64, _i64, _f, _f, _f]),
+    "edt_hip_shard_record16_words": (_sz, [_i64, _i64]),
+    "edt_hip_shard_xy_records16_device": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "edt_hip_shard_z_records16_device": (_i, [_vp, _vp, _i64, _i64, _i64, _f, _f, _f, _i, _vp, _sz, _vp]),
     "edt_hip_field_floor": (_f, [_f, _f]),
     "edt_hip_subtract_device": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "edt_hip_voxel_graph_workspace_bytes": (_sz, [_i, _i64, _i64, _i64]),

@@ -123,6 +123,34 @@ class HipOps:
                 ctypes.c_void_p(records.data_ptr()), sx, syl, sz, wz, 0.0, flags, ctypes.c_void_p(ws.data_ptr()),
                 ws.numel(), self._stream()))
 
+    # -- slab records of 16-bit values (edt_hip.h): 2.25 bytes per voxel where the integer column kernel takes both passes --
+    def records16_supported(self, code, sx, sy, sz, weights):
+        return bool(self.lib.edt_hip_shard_records16_supported(code, sx, sy, sz, weights[0], weights[1], weights[2]))
+
+    def record16_words(self, sx, ylen):
+        return int(self.lib.edt_hip_shard_record16_words(sx, ylen))
+
+    def xy_records16(self, labels, halo, code, weights, flags, y_splits, blocks, refused, slot=0):
+        """X and Y passes of a z-chunk into records of 16-bit rows (int32 tensors of record16_words columns); `refused`
+        (int32[1], zeroed by the caller) counts the tiles that have no 16-bit form."""
+        szl, sy, sx = labels.shape
+        ws = self._workspace(self.lib.edt_hip_shard_records_workspace_bytes(code, sx, sy, szl), labels.device, slot)
+        splits = (ctypes.c_int64 * len(y_splits))(*y_splits)
+        ptrs = (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
+        _lib.check(self.lib.edt_hip_shard_xy_records16_device(
+            ctypes.c_void_p(labels.data_ptr()),
+            ctypes.c_void_p(halo.data_ptr()) if halo is not None else None, code, sx, sy, szl,
+            weights[0], weights[1], weights[2], flags, len(blocks), splits, ptrs, ctypes.c_void_p(refused.data_ptr()),
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
+
+    def z_records16(self, records, out, weights, flags):
+        """Z pass over the gathered (sz, record16_words) records into the dense (sz, syl, sx) fp32 tensor `out`."""
+        sz, syl, sx = out.shape
+        ws = self._workspace(self.lib.edt_hip_shard_records_workspace_bytes(_lib.U8, sx, syl, sz), records.device)
+        _lib.check(self.lib.edt_hip_shard_z_records16_device(
+            ctypes.c_void_p(records.data_ptr()), ctypes.c_void_p(out.data_ptr()), sx, syl, sz, weights[0], weights[1],
+            weights[2], flags, ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
+
     def z(self, partial, zflags, wz, flags, wxy=None):
         sz, syl, sx = partial.shape
         ws = self._workspace(self.lib.edt_hip_shard_workspace_bytes(_lib.U8, sx, syl, sz), partial.device)
@@ -155,11 +183,23 @@ class ShardedEDT:
     with ``gather_back=True`` -- its original Z-slab of the result.
     """
 
-    def __init__(self, extents_xyz, code: int, group=None, ops=None, records=None, chunks=None, reuse_output=False):
+    def __init__(self, extents_xyz, code: int, group=None, ops=None, records=None, chunks=None, reuse_output=False,
+                 records16=None):
         """records: None = use the slab-record form whenever it applies, False = never (the
         byte-flag form).  chunks: z-chunks per slab in the record form (default 4 when world > 1).
         reuse_output: the record form keeps ONE receive buffer between calls -- the view run() returns is then only valid
         until the next run() of this plan (what a loop that consumes every result wants: no allocation per step)."""
+        # records16: None = 16-bit records whenever the extents and the voxel sizes of a run() allow them (edt_hip.h; a run
+        # that meets a tile without a 16-bit form is repeated with fp32 records and the plan stays on those), False = never
+        # (EDT_SHARD_RECORDS16=0 likewise).  `last_records16` says what the last run() used.
+        import os as _os
+        self._allow16 = records16 is not False and _os.environ.get("EDT_SHARD_RECORDS16", "1") != "0"
+        self.last_records16 = False
+        self.fallbacks16 = 0
+        self._dst16 = None
+        self._out16 = None
+        self._refused = None
+        self._refused_host = None
         self.reuse_output = bool(reuse_output)
         self._dst = None
         self._halo_buf = None
@@ -293,19 +333,38 @@ class ShardedEDT:
         c0, c1 = balanced_partition(ze - zs, self.nchunks)[k]
         return zs + c0, zs + c1
 
-    def _run_records(self, labels, w, flags, sqrt, halo, halo_req=None):
+    def _use16(self, w):
+        return (self._allow16 and hasattr(self.ops, "xy_records16")
+                and self.ops.records16_supported(self.code, self.sx, self.sy, self.sz, w))
+
+    def _run_records(self, labels, w, flags, sqrt, halo, halo_req=None, use16=False):
         """Slab-record form: chunked XY phase with the exchange of one chunk under the kernels of the next.  The chunks are
         taken TOP-DOWN: only the slab's first chunk needs the neighbour's slice (halo, in flight: halo_req), and it runs
-        last -- the halo exchange is off the critical path whenever there is more than one chunk."""
+        last -- the halo exchange is off the critical path whenever there is more than one chunk.
+        use16: records of 16-bit rows (int32 words); the ranks agree afterwards whether every tile had that form."""
         zs, ze = self.local_z()
         ys, ye = self.local_y()
-        rec = [self.ops.record_floats(self.sx, b - a) for a, b in self.yparts]
+        if use16:
+            rec = [self.ops.record16_words(self.sx, b - a) for a, b in self.yparts]
+            rdtype = torch.int32
+        else:
+            rec = [self.ops.record_floats(self.sx, b - a) for a, b in self.yparts]
+            rdtype = torch.float32
         y_splits = [a for a, _ in self.yparts] + [self.sy]
-        dst = self._dst if self.reuse_output else None
+        dst = (self._dst16 if use16 else self._dst) if self.reuse_output else None
         if dst is None or tuple(dst.shape) != (self.sz, rec[self.rank]) or dst.device != labels.device:
-            dst = torch.empty((self.sz, rec[self.rank]), dtype=torch.float32, device=labels.device)
-            if self.reuse_output:
+            dst = torch.empty((self.sz, rec[self.rank]), dtype=rdtype, device=labels.device)
+            if self.reuse_output and use16:
+                self._dst16 = dst
+            elif self.reuse_output:
                 self._dst = dst
+        if use16:
+            if self._refused is None or self._refused.device != labels.device:
+                self._refused = torch.zeros(1, dtype=torch.int32, device=labels.device)
+                self._refused_host = torch.zeros(1, dtype=torch.int32)
+                if labels.is_cuda:
+                    self._refused_host = self._refused_host.pin_memory()
+            self._refused.zero_()
         pending = []
         # On the GPU consecutive chunks alternate between two side streams (each with its own scratch):
         # pass 1 of chunk k+1 fills the tail of chunk k's Y pass, and every exchange is ordered after
@@ -326,14 +385,19 @@ class ShardedEDT:
                 with torch.cuda.stream(side[i % len(side)]):
                     if k == 0 and halo_req is not None:
                         halo_req.wait()
-                    self._records_chunk(k, labels, h, w, flags, rec, y_splits, dst, pending, i % len(side))
+                    self._records_chunk(k, labels, h, w, flags, rec, y_splits, dst, pending, i % len(side), use16)
             else:
                 if k == 0 and halo_req is not None:
                     halo_req.wait()
-                self._records_chunk(k, labels, h, w, flags, rec, y_splits, dst, pending, None)
+                self._records_chunk(k, labels, h, w, flags, rec, y_splits, dst, pending, None, use16)
         if side is not None:
             for st in side:
                 main.wait_stream(st)
+        agreed = None
+        if use16:
+            # every rank learns whether ANY rank met a tile without a 16-bit form: one 4-byte all-reduce behind the last
+            # exchange, read back on a side stream while the Z phase runs -- waited for at the end of this call only
+            agreed = self._agree_start(labels)
         # (measure_exchange: two events on the compute stream bracket the waits for the exchanges -- the time this rank's
         # kernels are done and the Z pass cannot start yet = the EXPOSED part of the exchange; read with exposed_ms())
         timed = getattr(self, "measure_exchange", False) and labels.is_cuda
@@ -344,11 +408,48 @@ class ShardedEDT:
             req.wait()
         if timed:
             self._ev[1].record()
+        if use16:
+            out = self._out16 if self.reuse_output else None
+            if out is None or tuple(out.shape) != (self.sz, ye - ys, self.sx) or out.device != labels.device:
+                out = torch.empty((self.sz, ye - ys, self.sx), dtype=torch.float32, device=labels.device)
+                if self.reuse_output:
+                    self._out16 = out
+            self.ops.z_records16(dst, out, w, flags | (_lib.FLAG_SQRT if sqrt else 0))
+            if self._agree_finish(agreed) != 0:
+                return None  # (some tile somewhere had no 16-bit form: the caller repeats the step with fp32 records)
+            return out
         self.ops.z_records(dst, self.sx, ye - ys, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0), wxy=(w[0], w[1]))
         # the result is the float part of every record: a (sz, syl, sx) view with z-stride = record
         return dst[:, :(ye - ys) * self.sx].view(self.sz, ye - ys, self.sx)
 
-    def _records_chunk(self, k, labels, halo, w, flags, rec, y_splits, dst, pending, slot):
+    def _agree_start(self, labels):
+        """MAX over the ranks of the refused-tile counter, then its copy to the host -- enqueued, not waited for."""
+        flag = self._refused
+        if self._stage and flag.is_cuda:   # (gloo: collectives on host tensors; a synchronising copy -- tests only)
+            host = flag.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            self._refused_host.copy_(host)
+            return None
+        work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        if not flag.is_cuda:
+            work.wait()
+            self._refused_host.copy_(flag)
+            return None
+        if getattr(self, "_agree_stream", None) is None:
+            self._agree_stream = torch.cuda.Stream(labels.device)
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(self._agree_stream):
+            work.wait()                      # (this stream waits for the collective; the compute stream does not)
+            self._refused_host.copy_(flag, non_blocking=True)
+            ev.record()
+        return ev
+
+    def _agree_finish(self, ev):
+        if ev is not None:
+            ev.synchronize()
+        return int(self._refused_host.item())
+
+    def _records_chunk(self, k, labels, halo, w, flags, rec, y_splits, dst, pending, slot, use16=False):
         """XY phase of chunk k and the enqueue (not the wait) of its exchange, on the current stream."""
         zs = self.local_z()[0]
         c0, c1 = self._chunk(self.rank, k)
@@ -357,24 +458,30 @@ class ShardedEDT:
             if h == self.rank:
                 blocks.append(dst[c0:c1])  # own part: straight into the receive buffer
                 continue
-            key = (k, h)
+            key = (k, h, use16)
             buf = self._send.get(key)
             if buf is None or buf.shape != (c1 - c0, rec[h]) or buf.device != labels.device:
-                buf = self._send[key] = torch.empty((c1 - c0, rec[h]), dtype=torch.float32,
-                                                    device=labels.device)
+                buf = self._send[key] = torch.empty((c1 - c0, rec[h]), dtype=dst.dtype, device=labels.device)
             blocks.append(buf)
         kw = {} if slot is None else {"slot": slot}
-        self.ops.xy_records(labels[c0 - zs:c1 - zs], halo, self.code, w, flags, y_splits, blocks, **kw)
+        if use16:
+            self.ops.xy_records16(labels[c0 - zs:c1 - zs], halo, self.code, w, flags, y_splits, blocks, self._refused, **kw)
+        else:
+            self.ops.xy_records(labels[c0 - zs:c1 - zs], halo, self.code, w, flags, y_splits, blocks, **kw)
         recv = [dst[slice(*self._chunk(h, k))] for h in range(self.world)]
         if self._exchange == "alltoall":  # (also at world 1: a no-op that keeps the dry run honest)
             # one collective call per chunk (RCCL runs it as a group of sends / receives; every
             # peer pair has its own xGMI link); the own part is already in place -> empty entries
             # (the own entry is a one-element dummy rather than an empty tensor: every entry of the list is an
             # ordinary non-empty message, whatever the backend makes of zero-length ones)
-            if getattr(self, "_dummy", None) is None or self._dummy.device != dst.device:
-                self._dummy = torch.zeros(2, dtype=torch.float32, device=dst.device)
-            ins = [self._dummy[0:1] if h == self.rank else blocks[h] for h in range(self.world)]
-            outs = [self._dummy[1:2] if h == self.rank else recv[h] for h in range(self.world)]
+            dummies = getattr(self, "_dummies", None)
+            if dummies is None:
+                dummies = self._dummies = {}
+            dummy = dummies.get(dst.dtype)
+            if dummy is None or dummy.device != dst.device:
+                dummy = dummies[dst.dtype] = torch.zeros(2, dtype=dst.dtype, device=dst.device)
+            ins = [dummy[0:1] if h == self.rank else blocks[h] for h in range(self.world)]
+            outs = [dummy[1:2] if h == self.rank else recv[h] for h in range(self.world)]
             pending.append(dist.all_to_all(outs, ins, group=self.group, async_op=True))
         else:
             peers = [h for h in range(self.world) if h != self.rank]
@@ -398,7 +505,16 @@ class ShardedEDT:
         flags = (_lib.FLAG_BLACK_BORDER if black_border else 0)
         if self.records:
             halo, halo_req = self._halo_start(labels)
-            out = self._run_records(labels, w, flags, sqrt, halo, halo_req)
+            use16 = self._use16(w)
+            self.last_records16 = use16
+            out = self._run_records(labels, w, flags, sqrt, halo, halo_req, use16)
+            if out is None:
+                # a tile without a 16-bit form somewhere: the same step with fp32 records (the halo is here already), and the
+                # plan stays on those -- data that left the 16 bits once will again
+                self._allow16 = False
+                self.last_records16 = False
+                self.fallbacks16 += 1
+                out = self._run_records(labels, w, flags, sqrt, halo, None, False)
             if gather_back:
                 out = self._reshard([out], to_y=False)[0]
             return out

@@ -269,6 +269,26 @@ int edt_hip_shard_z_records_device_ex(float *d_records, int64_t sx, int64_t sy_l
 int edt_hip_shard_z_records_device_w(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wx, float wy,
                                      float wz, int flags, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Slab records of 16-BIT values (2.25 bytes per voxel over the links instead of 4.25).  Where the three voxel sizes share a
+ * quantum (csrc/edt_colq16.hip: w_i^2 = a_i q) and both column axes fit the integer kernel (97..1024 rows), the Y pass's
+ * results are integers N < 2^16 in quanta: the record of destination h and slice z is then
+ *     ylen_h * sx 16-bit values (row-major, as packed pairs)  |  the two bit planes as above
+ * = edt_hip_shard_record16_words(sx, ylen_h) 4-byte words.  edt_hip_shard_records16_supported: the extents of the WHOLE volume
+ * and its voxel sizes allow it.  A tile the integer kernel cannot take (values beyond 16 bits, rows without any boundary)
+ * has no 16-bit form: the XY phase adds the number of such tiles to *d_refused -- a device counter the caller zeroes and
+ * reads -- and leaves their rows unspecified; a caller that finds it non-zero repeats the step with the fp32 records
+ * (edt/distributed.py: the ranks agree on it with one all-reduce of the counter, off the critical path).  The Z phase reads
+ * the gathered records (sz x record16 words) and writes the dense (sz, sy_local, sx) fp32 result to d_out; the same bits as
+ * every other route.  No counterpart in the reference (src/edt.hpp:448-475 is what both phases replace). */
+int edt_hip_shard_records16_supported(int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz);
+size_t edt_hip_shard_record16_words(int64_t sx, int64_t y_rows);
+int edt_hip_shard_xy_records16_device(const void *d_labels, const void *d_halo, int dtype, int64_t sx, int64_t sy,
+                                      int64_t sz_local, float wx, float wy, float wz, int flags, int nparts,
+                                      const int64_t *y_splits, void *const *d_blocks, uint32_t *d_refused, void *d_workspace,
+                                      size_t workspace_bytes, void *stream);
+int edt_hip_shard_z_records16_device(const void *d_records, float *d_out, int64_t sx, int64_t sy_local, int64_t sz, float wx,
+                                     float wy, float wz, int flags, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- fused helpers on device-resident data ------------------------------------------ */
 /* out[i] = a[i] - b[i]  (src/edt.pyx:156-158, sdf = edt(x) - edt(x == 0)) */
 int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, int64_t count,

@@ -89,13 +89,70 @@ class OracleOps:
         raw[:, :syl * sx] = partial.reshape(sz, -1).view(np.uint32)
 
 
+    # -- slab records of 16-bit values: the same restatement, rows as integers in quanta (edt_hip.h) ------------------------
+    allow16 = True
+
+    @staticmethod
+    def _quantum(weights):
+        """q with w_i^2 = a_i q for integer a_i (integer voxel sizes only: all the tests need)"""
+        sq = [int(round(float(w) ** 2)) for w in weights]
+        if any(abs(float(w) ** 2 - v) > 0 or v <= 0 for w, v in zip(weights, sq)):
+            return None
+        return float(np.gcd.reduce(sq))
+
+    def records16_supported(self, code, sx, sy, sz, weights):
+        return self.allow16 and sx % 4 == 0 and self._quantum(weights) is not None
+
+    def record16_words(self, sx, ylen):
+        return ylen * sx // 2 + 2 * (-(-ylen // 32)) * sx
+
+    def xy_records16(self, labels, halo, code, weights, flags, y_splits, blocks, refused):
+        partial, zflags = self.xy(labels, halo, code, weights, flags)
+        q = self._quantum(weights)
+        p, f = partial.numpy(), zflags.numpy()
+        szl, sy, sx = p.shape
+        n = p / np.float32(q)
+        bad = ~np.isfinite(n) | (n != np.floor(n)) | (n > 65535)
+        # a 32-column tile of one slice with any such voxel has no 16-bit form: counted, its rows unspecified (here: garbage)
+        tiles = bad.reshape(szl, sy, -1, min(32, sx)).any(axis=(1, 3)) if sx % 32 == 0 else bad.any(axis=1, keepdims=True)
+        refused += int(tiles.sum())
+        n16 = np.where(bad, 0xDEAD, n).astype(np.uint16)
+        for h, blk in enumerate(blocks):
+            ys, ye = y_splits[h], y_splits[h + 1]
+            ylen, words = ye - ys, -(-(ye - ys) // 32)
+            assert ys % 32 == 0 and tuple(blk.shape) == (szl, self.record16_words(sx, ylen)) and blk.dtype == torch.int32
+            raw = blk.numpy().view(np.uint32)
+            raw[:, :ylen * sx // 2] = np.ascontiguousarray(n16[:, ys:ye, :]).reshape(szl, -1).view(np.uint32)
+            bits = np.zeros((szl, 2, words, sx), np.uint32)
+            for r in range(ylen):
+                row = f[:, ys + r, :].astype(np.uint32)
+                bits[:, 0, r // 32, :] |= (row & 1) << (r % 32)
+                bits[:, 1, r // 32, :] |= ((row >> 1) & 1) << (r % 32)
+            raw[:, ylen * sx // 2:] = bits.reshape(szl, -1)
+
+    def z_records16(self, records, out, weights, flags):
+        sz, syl, sx = out.shape
+        q = self._quantum(weights)
+        raw = records.numpy().view(np.uint32)
+        words = -(-syl // 32)
+        n16 = np.ascontiguousarray(raw[:, :syl * sx // 2]).view(np.uint16).reshape(sz, syl, sx)
+        partial = (n16.astype(np.float32) * np.float32(q)).copy()
+        bits = raw[:, syl * sx // 2:].reshape(sz, 2, words, sx)
+        zflags = np.zeros((sz, syl, sx), np.uint8)
+        for r in range(syl):
+            zflags[:, r, :] = ((bits[:, 0, r // 32, :] >> (r % 32)) & 1) | (((bits[:, 1, r // 32, :] >> (r % 32)) & 1) << 1)
+        self.z(torch.from_numpy(partial), torch.from_numpy(zflags), weights[2], flags)
+        out.copy_(torch.from_numpy(partial))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q, records=None, chunks=None, reuse=False):
+def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q, records=None, chunks=None, reuse=False, expect16=None,
+            deep=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -105,9 +162,13 @@ def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q, records=None
 
         rng = np.random.default_rng(77)
         vol = blocky_labels(shape, nlabels=5, zero_frac=0.15, block=5, rng=rng).astype(np.uint32)
+        if deep:
+            vol[:, :, shape[2] // 2:] = 3                 # one label over whole slices: rows deeper than 16 bits of quanta hold
         vol = np.asfortranarray(vol)                      # (sx, sy, sz), x fastest
         zyx = np.ascontiguousarray(vol.T)                  # (sz, sy, sx)
-        plan = edist.ShardedEDT(shape, 2, ops=OracleOps(), records=records, chunks=chunks, reuse_output=reuse)
+        ops = OracleOps()
+        ops.allow16 = expect16 is not None
+        plan = edist.ShardedEDT(shape, 2, ops=ops, records=records, chunks=chunks, reuse_output=reuse)
         assert records is None or plan.records == records
         zs, ze = plan.local_z()
         slab = torch.from_numpy(zyx[zs:ze].copy().view(np.int32))
@@ -131,6 +192,13 @@ def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q, records=None
         else:
             ys, ye = plan.local_y()
             ok = np.array_equal(out, want[:, ys:ye, :], equal_nan=True)
+        if expect16 == "used":
+            ok = ok and plan.last_records16 and plan.fallbacks16 == 0
+        elif expect16 == "fallback":
+            # the step met tiles without a 16-bit form: every rank repeated it with fp32 records, and the plan stays there
+            ok = ok and not plan.last_records16 and plan.fallbacks16 == 1
+            again = plan.run(slab, an, black_border=bb, sqrt=sqrt, gather_back=gather_back).numpy()
+            ok = ok and np.array_equal(again, out, equal_nan=True) and plan.fallbacks16 == 1
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -189,6 +257,32 @@ def test_slab_record_form_with_reused_buffers(world, shape, chunks):
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, shape, (1.0, 1.0, 2.0), False, False, False, q, True, chunks, True))
              for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, "worker crashed"
+    results = dict(q.get(timeout=5) for _ in range(world))
+    assert results == {r: True for r in range(world)}
+
+
+@pytest.mark.parametrize("world,shape,an,bb,sqrt,gather_back,chunks,expect16,deep", [
+    (2, (32, 70, 9), (6.0, 6.0, 30.0), True, False, False, 2, "used", False),
+    (3, (64, 100, 10), (1.0, 2.0, 3.0), True, True, True, 3, "used", False),
+    (2, (12, 64, 7), (2.0, 2.0, 2.0), True, False, False, 1, "used", False),
+    (2, (128, 128, 9), (30.0, 30.0, 6.0), True, False, False, 2, "fallback", True),   # 128 x 128 of one label: 25 k^2 quanta > 2^16
+    (3, (128, 160, 10), (30.0, 30.0, 6.0), True, False, True, 3, "fallback", True),
+    (2, (32, 70, 9), (1.0, 1.0, 1.0), False, False, False, 2, "fallback", True),    # no black border: rows without a boundary
+])
+def test_slab_records_of_16_bit_rows(world, shape, an, bb, sqrt, gather_back, chunks, expect16, deep):
+    """Records of 16-bit rows (2.25 bytes per voxel) where the voxel sizes share a quantum: used when every tile has that
+    form; when some rank meets a tile that has not, all ranks learn it from one all-reduce and repeat the step with fp32
+    records -- the driver logic of edt/distributed.py over gloo, the phases restated on the CPU."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, an, bb, sqrt, gather_back, q, True, chunks, False,
+                                               expect16, deep)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

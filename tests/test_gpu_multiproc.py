@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, records, chunks, q):
+def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, records, chunks, q, expect16=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -37,6 +37,8 @@ def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, records, chunks
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         vol = voronoi_labels(shape, nseeds=30, seed=11, upsample=4, membrane=0.04)   # (sx, sy, sz), x fastest
+        if expect16 == "fallback":
+            vol[:, :, shape[2] // 2:] = 7   # one label over whole slices, 300+ voxels across: beyond 16 bits of quanta at (1, 1, 1)
         zyx = np.ascontiguousarray(vol.T)
         plan = edist.ShardedEDT(shape, _lib.U32, records=records, chunks=chunks)
         assert plan.records == records
@@ -56,9 +58,39 @@ def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, records, chunks
             else:
                 ys, ye = plan.local_y()
                 ok = ok and np.array_equal(out, want[:, ys:ye, :], equal_nan=True)
+        if expect16 == "used":
+            ok = ok and plan.last_records16 and plan.fallbacks16 == 0
+        elif expect16 == "fallback":
+            ok = ok and not plan.last_records16 and plan.fallbacks16 == 1   # (the first run fell back, the second stayed there)
+        elif records:
+            ok = ok and not plan.last_records16
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,an,bb,sqrt,gather_back,chunks,expect16", [
+    (2, (64, 128, 100), (6.0, 6.0, 30.0), True, False, False, 3, "used"),
+    (3, (96, 200, 97), (1.0, 1.0, 1.0), True, True, True, 2, "used"),
+    (2, (640, 128, 100), (1.0, 1.0, 1.0), True, False, False, 2, "fallback"),
+])
+def test_processes_sharing_one_gpu_records_of_16_bit_rows(world, shape, an, bb, sqrt, gather_back, chunks, expect16):
+    """the driver's 16-bit records with the real kernels: used where every tile has that form; a step that meets tiles beyond
+    16 bits is repeated with fp32 records on every rank (one all-reduce of the refused-tile counter) and the plan stays there"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, an, bb, sqrt, gather_back, True, chunks, q, expect16))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "worker crashed"
+    results = dict(q.get(timeout=5) for _ in range(world))
+    assert results == {r: True for r in range(world)}
 
 
 @pytest.mark.parametrize("world,shape,an,bb,sqrt,gather_back,records,chunks", [
@@ -101,7 +133,8 @@ def test_bench_sharded_leg_on_one_gpu():
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["config"]["form"] == "slab records"
+    # (a 128 x 128 x 256 segmentation at (1, 1, 1): both scan axes on the integer kernel, every tile within 16 bits)
+    assert out["n_gpus"] == 2 and out["config"]["form"] == "slab records, 16-bit rows" and out["config"]["records16_fallbacks"] == 0
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libedt_ref.so")):
         assert out["config"]["output_verified"] is True, out["config"]
         assert out["cpu_baseline"]["kind"] == "reference"

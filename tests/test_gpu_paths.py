@@ -168,6 +168,93 @@ def test_shard_records_as_virtual_ranks(edt_gpu, oracle_port, world, chunks, sha
         assert same(got, want), (world, shape, an, bb)
 
 
+@pytest.mark.parametrize("world,chunks", [(1, 1), (2, 2), (3, 1), (8, 3)])
+@pytest.mark.parametrize("shape", [(96, 280, 100), (512, 128, 97), (64, 1000, 130), (36, 200, 1024), (1024, 256, 104)])
+def test_shard_records16_as_virtual_ranks(edt_gpu, oracle_port, world, chunks, shape):
+    """Slab records of 16-bit rows (edt_hip_shard_xy_records16_device / edt_hip_shard_z_records16_device: 2.25 bytes per
+    voxel): the same virtual ranks, voxel sizes that share a quantum, both scan axes on the integer kernel (97..1024 rows).
+    No tile is refused on these labels (the counter stays 0) and the gathered result is the oracle's, bit for bit."""
+    import torch
+    from edt import _lib
+    from edt.distributed import HipOps, balanced_partition
+
+    sx, sy, sz = shape
+    words = -(-sy // 32)
+    if sz < world or words < world:
+        pytest.skip("fewer slices / y-words than ranks")
+    dev = torch.device("cuda", 0)
+    ops = HipOps()
+    lab = voronoi_labels(shape, nseeds=60, seed=sum(shape), upsample=4, membrane=0.04)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev)
+    zparts = balanced_partition(sz, world)
+    yparts = [(32 * a, min(32 * b, sy)) for a, b in balanced_partition(words, world)]
+    y_splits = [a for a, _ in yparts] + [sy]
+    rec = [ops.record16_words(sx, b - a) for a, b in yparts]
+    assert rec[0] < ops.record_floats(sx, yparts[0][1] - yparts[0][0]) * 0.55
+    for an, bb, sqrt in (((6.0, 6.0, 30.0), True, False), ((1.0, 1.0, 1.0), True, True), ((2.0, 1.0, 3.0), True, False)):
+        assert ops.records16_supported(_lib.U32, sx, sy, sz, an)
+        flags = _lib.FLAG_BLACK_BORDER if bb else 0
+        refused = torch.zeros(1, dtype=torch.int32, device=dev)
+        dst = [torch.full((sz, rec[h]), -1, dtype=torch.int32, device=dev) for h in range(world)]
+        for r, (zs, ze) in enumerate(zparts):
+            halo = t[zs - 1] if r > 0 else None
+            for c0, c1 in balanced_partition(ze - zs, min(chunks, ze - zs)):
+                blocks = [dst[h][zs + c0:zs + c1] if h == r else
+                          torch.empty((c1 - c0, rec[h]), dtype=torch.int32, device=dev) for h in range(world)]
+                ops.xy_records16(t[zs + c0:zs + c1], halo, _lib.U32, an, flags, y_splits, blocks, refused)
+                for h in range(world):
+                    if h != r:
+                        dst[h][zs + c0:zs + c1].copy_(blocks[h])  # the exchange
+                halo = t[zs + c1 - 1]
+        assert int(refused.item()) == 0
+        outs = []
+        for h, (ys, ye) in enumerate(yparts):
+            out = torch.full((sz, ye - ys, sx), float("nan"), dtype=torch.float32, device=dev)
+            ops.z_records16(dst[h], out, an, flags | (_lib.FLAG_SQRT if sqrt else 0))
+            outs.append(out)
+        got = torch.cat(outs, 1).cpu().numpy().T
+        want = oracle_port.edtsq(lab, an, bb)
+        assert same(got, np.sqrt(want) if sqrt else want), (world, shape, an, bb)
+
+
+def test_shard_records16_count_the_tiles_without_a_16_bit_form(edt_gpu, oracle_port):
+    """a label 300 voxels across at (1, 1, 1): k^2 leaves 16 bits from k = 256 on -- the XY phase counts those tiles (and
+    nothing else is promised about them); rows without a boundary (no black border) likewise; a shallow volume counts none.
+    And the Z phase serves values beyond ITS limit: (1, 1, 6) -- a_z = 36, limit 36 * 42^2 < the Y pass's -- through fp32."""
+    import torch
+    from edt import _lib
+    from edt.distributed import HipOps
+
+    dev = torch.device("cuda", 0)
+    ops = HipOps()
+    sx, sy, sz = 640, 128, 100
+    lab = np.ones((sx, sy, sz), dtype=np.uint32, order="F")
+    lab[:, :, :50] = voronoi_labels((sx, sy, 50), nseeds=80, seed=5, upsample=4, membrane=0.04)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev)
+    rec = ops.record16_words(sx, sy)
+    for bb, lo, hi in ((True, 0, 50), (True, 50, 100), (False, 50, 100)):
+        refused = torch.zeros(1, dtype=torch.int32, device=dev)
+        blk = torch.empty((hi - lo, rec), dtype=torch.int32, device=dev)
+        ops.xy_records16(t[lo:hi], t[lo - 1] if lo else None, _lib.U32, (1.0, 1.0, 1.0), _lib.FLAG_BLACK_BORDER if bb else 0,
+                         [0, sy], [blk], refused)
+        n = int(refused.item())
+        assert (n == 0) if hi == 50 else (n > 0), (bb, lo, hi, n)
+    # the Z phase's own limit: one rank, one box 508 voxels across -- k <= 254, N <= 64 516 fits the XY phase (limit 255^2), not
+    # the Z pass at a_z = 36 (limit 36 * 42^2 = 63 504): those tiles get their rows as fp32 values and go to the fp32 kernel
+    shape = (508, 508, 100)
+    lab = np.ones(shape, dtype=np.uint32, order="F")
+    lab[100:104, 37, :] = 0
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).to(dev)
+    an = (1.0, 1.0, 6.0)
+    refused = torch.zeros(1, dtype=torch.int32, device=dev)
+    blk = torch.empty((shape[2], ops.record16_words(shape[0], shape[1])), dtype=torch.int32, device=dev)
+    ops.xy_records16(t, None, _lib.U32, an, _lib.FLAG_BLACK_BORDER, [0, shape[1]], [blk], refused)
+    assert int(refused.item()) == 0
+    out = torch.empty((shape[2], shape[1], shape[0]), dtype=torch.float32, device=dev)
+    ops.z_records16(blk, out, an, _lib.FLAG_BLACK_BORDER)
+    assert same(out.cpu().numpy().T, oracle_port.edtsq(lab, an, True))
+
+
 def test_device_entry_point_is_graph_capturable(edt_gpu, oracle_port):
     """edt_hip_edtsq_device only enqueues kernels on the caller's stream (no allocation, no synchronisation):
     a whole transform can be captured into a hipGraph and replayed (launch-bound small volumes)."""

@@ -43,6 +43,30 @@ t0 = time.perf_counter()
 for _ in range(10): run()
 torch.cuda.synchronize()
 print("per step (both phases, no exchange): %.3f ms" % ((time.perf_counter() - t0) / 10 * 1e3))
+# the same rank with records of 16-bit rows (2.25 bytes per voxel; the Z phase writes a dense array)
+if ops.records16_supported(_lib.U32, sx, sy, sz, an):
+    rec16 = [ops.record16_words(sx, b - a) for a, b in yparts]
+    dst16 = torch.zeros((sz, rec16[rank]), dtype=torch.int32, device=dev)
+    blocks16 = [dst16[zs:ze] if h == rank else torch.empty((ze - zs, rec16[h]), dtype=torch.int32, device=dev) for h in range(world)]
+    refused = torch.zeros(1, dtype=torch.int32, device=dev)
+    out16 = torch.empty((sz, yparts[rank][1] - yparts[rank][0], sx), dtype=torch.float32, device=dev)
+    def run16():
+        ops.xy_records16(labels, halo, _lib.U32, an, 0, y_splits, blocks16, refused)
+        ops.z_records16(dst16, out16, an, 0)
+    for _ in range(2): run16()
+    torch.cuda.synchronize()
+    device.set_profiling(True); acc = {}
+    for _ in range(5):
+        run16(); torch.cuda.synchronize()
+        for k, v in device.pass_times(): acc.setdefault(k, []).append(v)
+        device.set_profiling(False); device.set_profiling(True)
+    device.set_profiling(False)
+    t = {k: round(float(np.mean(v)), 3) for k, v in acc.items()}
+    t0 = time.perf_counter()
+    for _ in range(10): run16()
+    torch.cuda.synchronize()
+    print("16-bit records, phases (ms):", t, "sum", round(sum(t.values()), 3), "| per step: %.3f ms" % ((time.perf_counter() - t0) / 10 * 1e3),
+          "| tiles without a 16-bit form:", int(refused.item()), "| bytes per record:", 4 * rec16[rank], "vs", 4 * rec[rank])
 # the same slab through the single-device path (in-place Y pass instead of the scattering one)
 out = torch.empty((ze - zs, sy, sx), dtype=torch.float32, device=dev)
 plan = device.Plan((sx, sy, ze - zs), _lib.U32, dev)

@@ -328,9 +328,18 @@ class ShardedEDT:
         return outs
 
     def _chunk(self, r, k):
-        """z-range (global indices) of chunk k of rank r's slab; the same rule on every rank."""
+        """z-range (global indices) of chunk k of rank r's slab; the same rule on every rank.  The chunks are processed
+        top-down and only the LAST one's exchange has nothing to hide under: chunk 0 -- the last one processed -- is half
+        a fair share, the others split the rest evenly."""
         zs, ze = self.zparts[r]
-        c0, c1 = balanced_partition(ze - zs, self.nchunks)[k]
+        n = ze - zs
+        if self.nchunks >= 2 and n >= 2 * self.nchunks and self.world > 1:  # (one rank: nothing travels, nothing to hide)
+            first = max(1, n // (2 * self.nchunks))
+            if k == 0:
+                return zs, zs + first
+            c0, c1 = balanced_partition(n - first, self.nchunks - 1)[k - 1]
+            return zs + first + c0, zs + first + c1
+        c0, c1 = balanced_partition(n, self.nchunks)[k]
         return zs + c0, zs + c1
 
     def _use16(self, w):

@@ -230,6 +230,7 @@ def test_z_sharded_equals_single_process(world, shape, an, bb, sqrt, gather_back
     (2, (10, 64, 7), (1.0, 2.0, 3.0), False, True, True, 2),
     (3, (8, 100, 10), (0.5, 0.7, 1.3), False, False, False, 3),    # 4 words: 64 / 32 / 4 rows
     (3, (9, 97, 3), (4.0, 4.0, 40.0), True, False, True, 1),       # one slice per rank
+    (2, (8, 64, 41), (1.0, 1.0, 2.0), True, False, False, 4),      # 20 / 21 slices per rank: chunk 0 (processed last) is half a share
 ])
 def test_slab_record_form_equals_single_process(world, shape, an, bb, sqrt, gather_back, chunks):
     """The fast form of the driver: y cut at multiples of 32 rows, per-destination records, the
@@ -290,6 +291,23 @@ def test_slab_records_of_16_bit_rows(world, shape, an, bb, sqrt, gather_back, ch
         assert p.exitcode == 0, "worker crashed"
     results = dict(q.get(timeout=5) for _ in range(world))
     assert results == {r: True for r in range(world)}
+
+
+def test_chunks_cover_the_slab_and_the_last_processed_one_is_small():
+    from edt.distributed import ShardedEDT
+
+    class Plan(ShardedEDT):
+        def __init__(self, zparts, nchunks):
+            self.zparts, self.nchunks, self.world = zparts, nchunks, len(zparts)
+
+    for zparts, nchunks in (([(0, 128), (128, 256)], 4), ([(0, 20), (20, 41)], 4), ([(0, 5), (5, 9)], 4), ([(0, 64)], 1), ([(0, 7), (7, 15)], 3)):
+        p = Plan(zparts, nchunks)
+        for r, (zs, ze) in enumerate(zparts):
+            cuts = [p._chunk(r, k) for k in range(nchunks)]
+            assert cuts[0][0] == zs and cuts[-1][1] == ze and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            assert all(c1 > c0 for c0, c1 in cuts)
+            if nchunks >= 2 and ze - zs >= 2 * nchunks and len(zparts) > 1:
+                assert cuts[0][1] - cuts[0][0] == (ze - zs) // (2 * nchunks)   # e.g. 16 of 128 slices at 4 chunks
 
 
 def test_partition_helpers():

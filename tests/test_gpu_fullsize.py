@@ -84,11 +84,33 @@ def test_uneven_1024_world8_virtual_ranks_against_compiled_reference(edt_gpu, or
                 if h != r:
                     dst[h][zs + c0:zs + c1].copy_(blocks[h])  # the exchange
             halo = t[zs + c1 - 1]
-    del t
     got = np.empty((sz, sy, sx), dtype=np.float32)
     for h, (ys, ye) in enumerate(yparts):
         ops.z_records(dst[h], sx, ye - ys, an[2], 0, wxy=(an[0], an[1]))
         got[:, ys:ye, :] = dst[h][:, :(ye - ys) * sx].reshape(sz, ye - ys, sx).cpu().numpy()
+    assert np.array_equal(got.T, want)
+    del dst
+    # the same ranks with records of 16-bit rows (2.25 bytes per voxel: what an 8-GPU run of this volume exchanges)
+    assert ops.records16_supported(_lib.U32, sx, sy, sz, an)
+    rec16 = [ops.record16_words(sx, b - a) for a, b in yparts]
+    dst16 = [torch.full((sz, rec16[h]), -1, dtype=torch.int32, device=dev) for h in range(world)]
+    refused = torch.zeros(1, dtype=torch.int32, device=dev)
+    for r, (zs, ze) in enumerate(zparts):
+        halo = t[zs - 1] if r > 0 else None
+        for c0, c1 in balanced_partition(ze - zs, chunks):
+            blocks = [dst16[h][zs + c0:zs + c1] if h == r else
+                      torch.empty((c1 - c0, rec16[h]), dtype=torch.int32, device=dev) for h in range(world)]
+            ops.xy_records16(t[zs + c0:zs + c1], halo, _lib.U32, an, 0, y_splits, blocks, refused)
+            for h in range(world):
+                if h != r:
+                    dst16[h][zs + c0:zs + c1].copy_(blocks[h])
+            halo = t[zs + c1 - 1]
+    del t
+    assert int(refused.item()) == 0
+    for h, (ys, ye) in enumerate(yparts):
+        out = torch.empty((sz, ye - ys, sx), dtype=torch.float32, device=dev)
+        ops.z_records16(dst16[h], out, an, 0)
+        got[:, ys:ye, :] = out.cpu().numpy()
     assert np.array_equal(got.T, want)
 
 

@@ -404,6 +404,7 @@ def sharded_main(args, rank, world, dev):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    host_enqueue = time.perf_counter() - t0   # (what the host spent inside run(): enqueueing, and waiting for the records' agreement)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -555,6 +556,9 @@ def sharded_main(args, rank, world, dev):
                          "exchange_ms_exposed": (round(float(exposed_t.item()), 4) if float(exposed_t.item()) >= 0 else None),
                          "exchange_ms_exposed_note": "events on the compute stream around the waits for the slab records: how long "
                                                      "the slowest rank sat between its last XY kernel and the last record's arrival",
+                         "host_ms_per_step_in_run": round(host_enqueue / max(1, args.steps) * 1e3, 4),
+                         "host_ms_note": "rank 0's wall time inside plan.run() per step (enqueue + the wait for the 16-bit records' "
+                                         "agreement, which ends when the last exchange has landed): close to ms_per_step = the host is the bound",
                          "bytes_exchanged": int(sent_t.item()),
                          "link_floor_ms": round(int(sent_t.item()) / max(1, world - 1) / 76.8e9 * 1e3, 4) if world > 1 else 0.0},
         }

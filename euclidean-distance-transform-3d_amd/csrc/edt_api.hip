@@ -819,6 +819,7 @@ struct RecordPlan {
   uint32_t *nz_z = nullptr, *rs_z = nullptr;               // z-packed planes (Z phase)
   BandScatter *table = nullptr;
   uint32_t *q16_counts = nullptr, *q16_ids = nullptr;      // hand-over list of the integer column kernel (one phase per call)
+  uint32_t *ones_map = nullptr;                            // 16-bit records, Z phase: "every row of every tile is in the plane"
   size_t bytes = 0;
 };
 
@@ -837,6 +838,7 @@ static RecordPlan make_record_plan(int64_t sx, int64_t sy, int64_t sz, void *ws)
   p.table = c.take<BandScatter>(1);
   p.q16_counts = c.take<uint32_t>(4);
   p.q16_ids = c.take<uint32_t>((size_t)(ceil_div(sx, 16) * (ceil_div(std::max(sy, sz), 8) * 8)));
+  p.ones_map = c.take<uint32_t>((size_t)(ceil_div(sx, 32) * ceil_div(std::max(sy, sz), 32)));
   p.bytes = align_up(c.off, 256) + 256;
   return p;
 }
@@ -1441,9 +1443,11 @@ int edt_hip_shard_z_records16_device(const void *d_records, float *d_out, int64_
   // every row out of the records (16-bit elements: consecutive z are 2 * rec of them apart), results to the dense array; a
   // tile beyond THIS pass's limits gets its rows written there as fp32 values and goes to the fp32 kernel, in place
   EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, 4 * sizeof(uint32_t), stream));
+  const int map_words = (int)ceil_div(sz, 32);
+  EDT_HIP_TRY(hipMemsetAsync(p.ones_map, 0xFF, (size_t)(ceil_div(sx, 32) * map_words) * sizeof(uint32_t), stream));
   uint16_t *plane = reinterpret_cast<uint16_t *>(const_cast<void *>(d_records));
   rc = launch_column_pass_q16(d_out, nullptr, p.rs_z, gz, q, a[2], a[0], bb, epi, p.q16_counts, p.q16_ids, stream, nullptr, plane,
-                              nullptr, 0, nullptr, 2 * rec, sx);
+                              p.ones_map, map_words, nullptr, 2 * rec, sx);
   if (rc != EDT_OK) return rc;
   TileList list;
   list.count = p.q16_counts;

@@ -50,7 +50,7 @@ struct Q16Args {
   // results N over its indices (plane == codes, in place) instead of fp32 values to F and sets its bit in `map`
   // ([x-tile][outer index / 32], zeroed by the caller); pass Z takes every row from wherever pass Y left it.
   uint16_t *plane;
-  uint32_t *map;          // (nullptr with a plane to read: every row is in the plane; with a plane to write: no map kept)
+  uint32_t *map;          // (slab records: all ones where every row is read from the plane; nullptr where a plane is written and no map kept)
   int map_words;          // words per x-tile
   int64_t pst, p_outer;   // the plane's own row / outer strides in 16-bit elements (slab records: edt_api.hip), else g's
   // output stride 2 (S = 2: the doubled grids of the voxel-graph transform) only: nullptr = the even rows go to their places
@@ -154,7 +154,6 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     const uint16_t *src16 = qa.plane + x0 + o * qa.p_outer + 4 * cg;
     const int64_t pst = qa.pst;
     const uint32_t *mapw = qa.map + xt * qa.map_words;  // (IN == kQ16InMixed: bit z = row z of this x-tile is in the plane)
-    const bool all16 = qa.map == nullptr;                // (wave-uniform: kernel argument)
     const pk nlimpk = pk_both(qa.nlim);
     const float flim = (float)qa.nlim + 1.0f;
     // (eight loads per thread in flight; all sixteen of a 512-row tile at once measured no faster -- cfg2 Z 0.237 vs
@@ -172,7 +171,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
         bool p16 = false;
         if constexpr (IN == kQ16InMixed) {
           const int mrow = row < n ? row : 0;
-          const uint32_t mw = all16 ? ~0u : mapw[__builtin_amdgcn_readfirstlane(mrow >> 5)];
+          const uint32_t mw = mapw[__builtin_amdgcn_readfirstlane(mrow >> 5)];
           p16 = row < n && ((mw >> (row & 31)) & 1u) != 0u;
         }
         if (p16) {
@@ -227,7 +226,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       const uint32_t *mapw = qa.map + xt * qa.map_words;
       float *dstF = F + x0 + o * g.outer_stride + 4 * cg;
       for (int row = r_in; row < n; row += RPS) {
-        if ((qa.map == nullptr || ((mapw[row >> 5] >> (row & 31)) & 1u) != 0u) && col_ok) {
+        if (((mapw[row >> 5] >> (row & 31)) & 1u) != 0u && col_ok) {
           const v2u v = *reinterpret_cast<const v2u *>(img + (row + kPad) * kRowWords + 2 * cg);
           *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) =
               (v4f){(float)(v[0] & 0xFFFFu) * qa.q, (float)(v[0] >> 16) * qa.q, (float)(v[1] & 0xFFFFu) * qa.q, (float)(v[1] >> 16) * qa.q};
@@ -423,7 +422,7 @@ static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q
 // plane / map != nullptr: with codes -- the results go to the 16-bit plane (= codes, in place) and the tile's bit is set in
 // map; without -- the rows are taken from the plane wherever map says so (the pass after such a pass).
 // Slab records of 16-bit values (edt_api.hip): with codes, a scatter table AND a plane (any non-null value) the results go to
-// the table's destinations as 16-bit rows, refused tiles are only counted (ids == nullptr); without codes, map == nullptr
+// the table's destinations as 16-bit rows, refused tiles are only counted (ids == nullptr); without codes, a map of ones
 // and plane_stride > 0 every row is read from the plane at its own strides (16-bit elements) and F is only written.
 int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
                            uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,

@@ -346,11 +346,13 @@ class ShardedEDT:
         return (self._allow16 and hasattr(self.ops, "xy_records16")
                 and self.ops.records16_supported(self.code, self.sx, self.sy, self.sz, w))
 
-    def _run_records(self, labels, w, flags, sqrt, halo, halo_req=None, use16=False):
+    def _run_records(self, labels, w, flags, sqrt, halo, halo_req=None, use16=False, halo_start=None):
         """Slab-record form: chunked XY phase with the exchange of one chunk under the kernels of the next.  The chunks are
         taken TOP-DOWN: only the slab's first chunk needs the neighbour's slice (halo, in flight: halo_req), and it runs
         last -- the halo exchange is off the critical path whenever there is more than one chunk.
-        use16: records of 16-bit rows (int32 words); the ranks agree afterwards whether every tile had that form."""
+        use16: records of 16-bit rows (int32 words); the ranks agree afterwards whether every tile had that form.
+        halo_start: the halo exchange has not been posted yet -- it is, right after the first chunk's kernels and exchange
+        have been enqueued (nothing of it is needed before the last chunk; the host reaches its first launch sooner)."""
         zs, ze = self.local_z()
         ys, ye = self.local_y()
         if use16:
@@ -386,7 +388,12 @@ class ShardedEDT:
             side = self._streams
             for st in side:
                 st.wait_stream(main)
+        if halo_start is not None and self.nchunks == 1:
+            halo, halo_req = halo_start()
+            halo_start = None
         for i, k in enumerate(reversed(range(self.nchunks))):
+            if i == 1 and halo_start is not None:
+                halo, halo_req = halo_start()
             # (a later chunk continues this slab: the slice below it; the first one: the neighbour's slice, which has had
             # the other chunks' kernels to arrive -- waited for on the stream that reads it)
             h = halo if k == 0 else labels[self._chunk(self.rank, k)[0] - zs - 1]
@@ -424,9 +431,11 @@ class ShardedEDT:
                 if self.reuse_output:
                     self._out16 = out
             self.ops.z_records16(dst, out, w, flags | (_lib.FLAG_SQRT if sqrt else 0))
+            self._last_halo = halo
             if self._agree_finish(agreed) != 0:
                 return None  # (some tile somewhere had no 16-bit form: the caller repeats the step with fp32 records)
             return out
+        self._last_halo = halo
         self.ops.z_records(dst, self.sx, ye - ys, w[2], flags | (_lib.FLAG_SQRT if sqrt else 0), wxy=(w[0], w[1]))
         # the result is the float part of every record: a (sz, syl, sx) view with z-stride = record
         return dst[:, :(ye - ys) * self.sx].view(self.sz, ye - ys, self.sx)
@@ -513,10 +522,10 @@ class ShardedEDT:
         w = tuple(float(np.float32(v)) for v in weights_xyz)
         flags = (_lib.FLAG_BLACK_BORDER if black_border else 0)
         if self.records:
-            halo, halo_req = self._halo_start(labels)
             use16 = self._use16(w)
             self.last_records16 = use16
-            out = self._run_records(labels, w, flags, sqrt, halo, halo_req, use16)
+            out = self._run_records(labels, w, flags, sqrt, None, None, use16, halo_start=lambda: self._halo_start(labels))
+            halo = self._last_halo
             if out is None:
                 # a tile without a 16-bit form somewhere: the same step with fp32 records (the halo is here already), and the
                 # plan stays on those -- data that left the 16 bits once will again

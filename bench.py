@@ -389,14 +389,28 @@ def sharded_main(args, rank, world, dev):
     an, bb = ((6.0, 6.0, 30.0), True) if kind == "ones" else ((1.0, 1.0, 1.0), False)
     if (args.selftest or world > 1) and not args.no_selftest:
         selftest(rank, world, dev, ext, kind)
-    plan = ShardedEDT(ext, _lib.U32, reuse_output=True)  # (every step's result is consumed before the next step)
+    # Steps are independent transforms: `depth` of them are in flight, each on its own plan (its own buffers and scratch) and
+    # its own stream, taken in turn -- the Z phase of step i then runs while the XY phase of step i + 1 feeds the links,
+    # instead of the links idling through it.  Every rank issues the same collectives in the same order.  (--pipeline 1:
+    # one plan, one stream, nothing of step i + 1 before step i has finished.)
+    depth = args.pipeline if args.pipeline > 0 else (2 if world > 1 else 1)   # (one rank: nothing travels, nothing to hide)
+    plans = [ShardedEDT(ext, _lib.U32, reuse_output=True) for _ in range(depth)]  # (a step's result is consumed before its plan's next)
+    plan = plans[0]
+    lanes = [torch.cuda.Stream(dev) for _ in range(depth)] if depth > 1 else [None]
     zs, ze = plan.local_z()
     labels = slab_labels(ext, zs, ze, dev, kind)
+    torch.cuda.synchronize()
+    turn = [0]
 
     def step():
-        return plan.run(labels, an, black_border=bb)
+        i = turn[0] % depth
+        turn[0] += 1
+        if lanes[i] is None:
+            return plans[i].run(labels, an, black_border=bb)
+        with torch.cuda.stream(lanes[i]):
+            return plans[i].run(labels, an, black_border=bb)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, depth)):
         step()
     torch.cuda.synchronize()
     dist.barrier()
@@ -412,6 +426,11 @@ def sharded_main(args, rank, world, dev):
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
+    # (everything below -- per-kernel times, the exposed exchange, the check -- on ONE plan and the current stream)
+    last_plan = plans[(turn[0] - 1) % depth]
+    depth_timed, depth, lanes[:] = depth, 1, [None]
+    plans[0] = last_plan   # (`out` is its result)
+    plan = last_plan
     # per-kernel durations of one more step (hipEvents inside the library, this rank's stream)
     from edt import device
     acc = {}
@@ -521,6 +540,9 @@ def sharded_main(args, rank, world, dev):
             reading = (f"WEAK scaling on configs[3]: {args.size}^3 voxels per GPU of the multi-label segmentation -- NOT the --gpus 1 "
                        "headline's workload (single label); compare with single_gpu_same_workload, not with the N = 1 line; "
                        "scaling_efficiency = value / (n_gpus x single_gpu_same_workload.mvox_per_s)")
+        if depth_timed > 1:
+            reading += (f"; the K timed steps are independent transforms and {depth_timed} are in flight at a time (own plan and stream each: "
+                        "the Z phase of one runs under the XY phase and exchange of the next; --pipeline 1 for strictly one after the other)")
         eff = None
         if same_n1 and same_n1.get("mvox_per_s"):
             eff = round(value / (world * same_n1["mvox_per_s"]), 4)
@@ -541,6 +563,7 @@ def sharded_main(args, rank, world, dev):
                        "form": ("slab records, 16-bit rows" if plan.last_records16 else "slab records, fp32 rows") if plan.records
                                else "byte flags",
                        "records16_fallbacks": getattr(plan, "fallbacks16", 0),
+                       "steps_in_flight": depth_timed,
                        "chunks": getattr(plan, "nchunks", 1),
                        "output_verified": verified, "verified_by": how,
                        "single_gpu_same_workload": same_n1},
@@ -732,6 +755,9 @@ def main():
     ap.add_argument("--global-size", type=int, default=0,
                     help="--gpus N > 1: STRONG scaling -- one volume of this edge length whatever N (0: weak scaling, "
                          "--size^3 voxels per GPU)")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="N > 1 leg: independent steps in flight, each on its own plan and stream (default: 2 at N > 1; 1: strictly "
+                         "one after the other)")
     ap.add_argument("--selftest", action="store_true", help="run the sharded leg's self-test also at world size 1")
     ap.add_argument("--no-selftest", action="store_true", help="skip the self-test of the sharded leg (default at N > 1: run it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

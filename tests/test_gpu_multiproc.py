@@ -135,6 +135,8 @@ def test_bench_sharded_leg_on_one_gpu():
     out = json.loads(line)
     # (a 128 x 128 x 256 segmentation at (1, 1, 1): both scan axes on the integer kernel, every tile within 16 bits)
     assert out["n_gpus"] == 2 and out["config"]["form"] == "slab records, 16-bit rows" and out["config"]["records16_fallbacks"] == 0
+    # two independent steps in flight (own plan and stream each) at N > 1, said in the line
+    assert out["config"]["steps_in_flight"] == 2 and "in flight" in out["reading"]
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libedt_ref.so")):
         assert out["config"]["output_verified"] is True, out["config"]
         assert out["cpu_baseline"]["kind"] == "reference"
@@ -151,7 +153,7 @@ def test_bench_sharded_leg_on_one_gpu():
     assert res.stdout.strip().splitlines()[-1].startswith("{"), "the JSON line must be the last line of stdout"
 
 
-@pytest.mark.parametrize("extra,scaling,labels", [(["--labels", "ones"], "weak", "ones"),
+@pytest.mark.parametrize("extra,scaling,labels", [(["--labels", "ones", "--pipeline", "1"], "weak", "ones"),
                                                   (["--global-size", "128"], "strong", "cfg4"),
                                                   (["--global-size", "128", "--labels", "ones"], "strong", "ones")])
 def test_bench_sharded_leg_other_readings(extra, scaling, labels):

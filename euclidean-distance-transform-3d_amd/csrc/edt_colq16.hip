@@ -23,7 +23,7 @@
 //               grids --: blocks of 16 rows whose even rows are evaluated, 16 pairs x four such blocks per wave);
 //   results   = converted once at the end, (float)N * q (exact), optional correctly rounded sqrt, 8-byte stores (16 lanes =
 //               one 128-byte line per row); or the 16-bit values themselves, over the tile's indices (the plane between
-//               passes Y and Z); or the rows of the slab records of the Z-sharded path.
+//               passes Y and Z); or the rows of the slab records of the Z-sharded path, fp32 or 16-bit (edt_api.hip).
 #include "edt_common.h"
 #include "edt_kernels.h"
 
@@ -70,7 +70,8 @@ __host__ __device__ constexpr int q16_lds_words(int NB) {
 
 }  // namespace
 
-// (not in the anonymous namespace: hipFuncSetAttribute refuses the stub of a kernel with internal linkage)
+// (no static LDS anywhere in this kernel -- __syncthreads_or has some -- or hipFuncSetAttribute refuses the full 160 KiB of
+// dynamic LDS the 1024-row image asks for)
 // IN: where the tile comes from (fp32 values / indices of pass X / per row the 16-bit plane or fp32 values);
 // O16: the results go to the 16-bit plane (in place over the indices) instead of F; SC: ... to the slab records
 // T: threads of the workgroup -- 256 (four waves) up to 512 rows, 512 beyond (a 1024-row image leaves room for two

@@ -205,3 +205,24 @@ def test_field_floor_helper(lib):
     # null pointers are still argument errors with the _ex forms
     assert lib.edt_hip_shard_z_device_ex(None, None, 8, 8, 8, 1.0, 1.0, 0, None, 0, None) == -2
     assert lib.edt_hip_shard_z_records_device_ex(None, 8, 8, 8, 1.0, 1.0, 0, None, 0, None) == -2
+
+
+def test_records_of_16_bit_rows_host_side(lib):
+    """edt_hip_shard_record16_words / edt_hip_shard_records16_supported are host arithmetic (no GPU): the record layout of the
+    16-bit slab records (rows as packed pairs + the two bit planes, in 4-byte words) and where they apply -- voxel sizes that
+    share a quantum, rows of whole 8-byte granules of indices, both scan axes of 97..1024 rows."""
+    from edt import _lib
+    words = lib.edt_hip_shard_record16_words
+    assert words(1024, 128) == 128 * 1024 // 2 + 2 * 4 * 1024 == 73728          # 294 912 bytes against 557 056 of fp32 rows
+    assert 4 * words(1024, 128) * 1.88 < 4 * lib.edt_hip_shard_record_floats(1024, 128)
+    assert words(512, 40) == 40 * 512 // 2 + 2 * 2 * 512 and words(7, 32) == 0   # (odd rows have no packed form)
+    ok = lib.edt_hip_shard_records16_supported
+    assert ok(_lib.U32, 1024, 1024, 1024, 1.0, 1.0, 1.0) == 1 and ok(_lib.U8, 512, 512, 1024, 6.0, 6.0, 30.0) == 1
+    assert ok(_lib.U32, 512, 512, 512, 3.58, 3.58, 40.0) == 0      # no quantum
+    assert ok(_lib.U32, 512, 512, 64, 1.0, 1.0, 1.0) == 0          # z axis below four bands
+    assert ok(_lib.U32, 512, 2048, 512, 1.0, 1.0, 1.0) == 0        # y axis beyond the integer kernel's 1024 rows
+    assert ok(_lib.U32, 510, 512, 512, 1.0, 1.0, 1.0) == 0         # rows that are not whole granules
+    assert ok(_lib.U32, 512, 512, 512, 0.7, 0.7, 0.7) == 0         # 0.7 k is not exact in fp32: no index form of pass X
+    # the entry points refuse what they cannot serve before touching the device
+    rc = lib.edt_hip_shard_z_records16_device(None, None, 512, 128, 512, 1.0, 1.0, 1.0, 0, None, 0, None)
+    assert rc < 0 and b"null" in lib.edt_hip_last_error()

@@ -1359,8 +1359,9 @@ int edt_hip_shard_xy_records16_device(const void *d_labels, const void *d_halo, 
       set_error("y_splits must be increasing multiples of 32 (the last one is sy)");
       return EDT_ERR_BAD_ARG;
     }
-    if (!d_blocks[h] || (reinterpret_cast<uintptr_t>(d_blocks[h]) % 16) != 0) {
-      set_error("destination blocks must be non-null and 16-byte aligned");
+    // (4-byte stores of packed pairs and bit words; the Z phase reads 8 bytes at a time: records are an even number of words)
+    if (!d_blocks[h] || (reinterpret_cast<uintptr_t>(d_blocks[h]) % 8) != 0) {
+      set_error("destination blocks must be non-null and 8-byte aligned");
       return EDT_ERR_BAD_ARG;
     }
   }

@@ -18,6 +18,8 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a gpuru
   echo "the same, fp32 form of its pass X (0x100000), 150 cases:";       FUZZ_VG=1 EDT_HIP_DEBUG_MODE=0x100000 python tools/fuzz_gpu.py 150 89 2>&1 | tail -1
   echo "the same on the fp32 column kernels (0x8000000), 150 cases:";    FUZZ_VG=1 EDT_HIP_DEBUG_MODE=0x8000000 python tools/fuzz_gpu.py 150 90 2>&1 | tail -1
   echo "the two sharded phases as virtual ranks, 16-bit / fp32 records (tools/fuzz_shard.py), 400 cases:"; python tools/fuzz_shard.py 400 11 2>&1 | tail -1
+  echo "the whole sharded driver, W processes sharing the GPU over gloo (tools/fuzz_driver.py):"
+  for a in "2 500 21" "3 400 22" "4 300 23"; do python tools/fuzz_driver.py $a 2>&1 | grep "^world\|MISMATCH" | tail -3; done
 } > gpurun_out/r04_fuzz.txt 2>&1
 cat gpurun_out/r04_fuzz.txt
 # (SKIP_PROFILE=1: a closing session after a change that left the profiled kernels alone)

@@ -273,7 +273,8 @@ int edt_hip_shard_z_records_device_w(float *d_records, int64_t sx, int64_t sy_lo
  * quantum (csrc/edt_colq16.hip: w_i^2 = a_i q) and both column axes fit the integer kernel (97..1024 rows), the Y pass's
  * results are integers N < 2^16 in quanta: the record of destination h and slice z is then
  *     ylen_h * sx 16-bit values (row-major, as packed pairs)  |  the two bit planes as above
- * = edt_hip_shard_record16_words(sx, ylen_h) 4-byte words.  edt_hip_shard_records16_supported: the extents of the WHOLE volume
+ * = edt_hip_shard_record16_words(sx, ylen_h) 4-byte words (an even number: blocks are 8-byte aligned, the gathered buffer and
+ * d_out 16-byte).  edt_hip_shard_records16_supported: the extents of the WHOLE volume
  * and its voxel sizes allow it.  A tile the integer kernel cannot take (values beyond 16 bits, rows without any boundary)
  * has no 16-bit form: the XY phase adds the number of such tiles to *d_refused -- a device counter the caller zeroes and
  * reads -- and leaves their rows unspecified; a caller that finds it non-zero repeats the step with the fp32 records

@@ -293,6 +293,73 @@ def test_slab_records_of_16_bit_rows(world, shape, an, bb, sqrt, gather_back, ch
     assert results == {r: True for r in range(world)}
 
 
+def _random_worker(rank, world, port, ncases, seed, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from edt import distributed as edist
+        from oracle import harness
+        from synth import blocky_labels
+
+        rng = np.random.default_rng(seed)   # (the same cases on every rank)
+        port_lib = harness.port()
+        bad, n16, nfall = 0, 0, 0
+        for _ in range(ncases):
+            sx = 4 * int(rng.integers(1, 12)) if rng.random() < 0.8 else int(rng.integers(3, 40))
+            sy = int(rng.integers(32 * world, 32 * world + 80))
+            sz = int(rng.integers(world, 30))
+            an = tuple(float(a) for a in rng.choice([1, 2, 6, 30, 4, 3], size=3))
+            bb, sqrt, gather_back = bool(rng.integers(0, 2)), rng.random() < 0.3, rng.random() < 0.3
+            chunks = int(rng.integers(1, 5))
+            vol = blocky_labels((sx, sy, sz), nlabels=int(rng.integers(1, 9)), zero_frac=float(rng.random() * 0.2),
+                                block=int(rng.integers(2, 40)), rng=rng).astype(np.uint32)
+            if rng.random() < 0.2:
+                vol[:] = 1
+            vol = np.asfortranarray(vol)
+            zyx = np.ascontiguousarray(vol.T)
+            ops = OracleOps()
+            ops.allow16 = bool(rng.integers(0, 2))
+            plan = edist.ShardedEDT((sx, sy, sz), 2, ops=ops, chunks=chunks, reuse_output=bool(rng.integers(0, 2)))
+            zs, ze = plan.local_z()
+            slab = torch.from_numpy(zyx[zs:ze].copy().view(np.int32))
+            want = port_lib.edtsq(vol, an, bb)
+            if sqrt:
+                want = np.sqrt(want)
+            want = np.ascontiguousarray(want.T)
+            for _rep in range(2):
+                out = plan.run(slab, an, black_border=bb, sqrt=sqrt, gather_back=gather_back).numpy()
+                if gather_back:
+                    ok = np.array_equal(out, want[zs:ze], equal_nan=True)
+                else:
+                    ys, ye = plan.local_y()
+                    ok = np.array_equal(out, want[:, ys:ye, :], equal_nan=True)
+                bad += not ok
+            n16 += plan.last_records16
+            nfall += plan.fallbacks16
+        q.put((rank, bad, n16, nfall))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ncases,seed", [(2, 14, 5), (3, 10, 6)])
+def test_driver_random_cases_over_gloo(world, ncases, seed):
+    """the driver walked through random small cases (extents, voxel sizes, chunks, gather-back, reused buffers, 16-bit records
+    allowed or not -- with steps that fall back), every case run twice, the phases restated on the CPU: the CPU tier's
+    counterpart of tools/fuzz_driver.py"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_random_worker, args=(r, world, port, ncases, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "worker crashed"
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert all(r[1] == 0 for r in res), res
+    assert all(r[2:] == res[0][2:] for r in res), "the ranks disagree about the form of the records"
+
+
 def test_chunks_cover_the_slab_and_the_last_processed_one_is_small():
     from edt.distributed import ShardedEDT
 

@@ -126,6 +126,7 @@ struct Plan {
   // which tiles of pass Y left their results in the 16-bit plane (= codes): one bit per (x-tile, z), behind the counters
   uint32_t *q16_map = nullptr;
   int q16_map_words = 0;  // words per x-tile
+  int64_t q16_id_capacity = 0;  // tile ids q16_ids holds
   size_t bytes = 0;
 };
 
@@ -195,12 +196,14 @@ static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, v
   }
   if (ndim >= 2 && !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic()) {
     // (ids in the fp32 kernel's geometry: 16-column tiles for axes of more than 512 rows)
-    const int64_t ty = ceil_div(sx, 16) * (ceil_div(p.xy_slab > 0 ? p.xy_slab : sz, 8) * 8);
+    // (pass Y runs over all sz slices at once whenever the index form is not taken at run time: sized for that)
+    const int64_t ty = ceil_div(sx, 16) * (ceil_div(sz, 8) * 8);
     const int64_t tz = ceil_div(sx, 16) * (ceil_div(sy, 8) * 8);
     p.q16_map_words = (int)ceil_div(sz, 32);
     p.q16_counts = c.take<uint32_t>(kQ16Slots + (size_t)(ceil_div(sx, 32) * p.q16_map_words));  // (zeroed together)
     p.q16_map = p.q16_counts ? p.q16_counts + kQ16Slots : nullptr;
-    p.q16_ids = c.take<uint32_t>((size_t)std::max(ty, tz));
+    p.q16_id_capacity = std::max(ty, tz);
+    p.q16_ids = c.take<uint32_t>((size_t)p.q16_id_capacity);
   }
   if (ndim == 1) (void)c.take<unsigned char>(line_workspace_bytes(sx));  // block scan + table of the 1-D pipeline
   // rows too long for the row kernels (more than 4096 voxels; more than 2048 where the wave kernel does not apply): pass 1
@@ -270,6 +273,20 @@ static int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) 
   return EDT_OK;
 }
 
+// Voxel sizes must be positive and finite.  (The reference does not validate them: a negative size makes its pass 1 cross
+// label boundaries -- the unguarded backward fminf sweep, src/edt.hpp:107-109 -- and NaN / inf / 0 give NaN or all-zero
+// fields; no kernel here reproduces that, so the call is refused instead of answered differently by different kernels.)
+static int check_voxel_sizes(int naxes, float wx, float wy, float wz) {
+  const float w[3] = {wx, wy, wz};
+  for (int i = 0; i < naxes && i < 3; ++i) {
+    if (!(w[i] > 0.0f) || !(w[i] <= FLT_MAX)) {
+      set_error("voxel sizes (anisotropy) must be positive and finite");
+      return EDT_ERR_BAD_ARG;
+    }
+  }
+  return EDT_OK;
+}
+
 static int require_device() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -286,6 +303,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
                       size_t ws_bytes, hipStream_t stream) {
   int rc = check_shape(dtype, ndim, sx, sy, sz);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(ndim, wx, wy, wz)) != EDT_OK) return rc;
   if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
   if (!d_labels || !d_out) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   Plan p = make_plan(dtype, ndim, sx, sy, sz, d_ws, flags);
@@ -340,8 +358,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     list = TileList();
     // (the bits that force one form of the fp32 kernel on every tile -- the test tiers' way to cover them -- keep the call there)
     if (!q16 || q16_slot >= kQ16Slots || !column_pass_q16_supported(g) || !column_pass_wave_supported(g) ||
-        (g_debug_mode & kQ16Off))
+        !column_pass_q16_aligned(F, codes, plane) || (g_debug_mode & kQ16Off))
       return EDT_OK;
+    // (the id array was sized for these tile counts: make_plan)
+    if (ceil_div(g.sx, 16) * (ceil_div(g.nouter, 8) * 8) > p.q16_id_capacity) return EDT_OK;
     uint32_t *count = p.q16_counts + q16_slot++;
     const int r = launch_column_pass_q16(F, codes, rs, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, p.q16_ids, stream,
                                          nullptr, plane, p.q16_map, p.q16_map_words);
@@ -643,6 +663,7 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
                     float wx, float wy, float wz, int flags, float *output) {
   int rc = check_shape(dtype, ndim, sx, sy, sz);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(ndim, wx, wy, wz)) != EDT_OK) return rc;
   const int64_t voxels = sx * sy * sz;
   if (voxels == 0) return EDT_OK;
   if (!labels || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
@@ -713,6 +734,7 @@ static int sdf_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
                     float wy, float wz, int flags, float *output) {
   int rc = check_shape(dtype, ndim, sx, sy, sz);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(ndim, wx, wy, wz)) != EDT_OK) return rc;
   const int64_t voxels = sx * sy * sz;
   if (voxels == 0) return EDT_OK;
   if (!labels || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
@@ -752,6 +774,7 @@ static int voxel_graph_host(const void *labels, int dtype, const uint8_t *graph,
                             float *output) {
   int rc = check_shape(dtype, ndim, sx, sy, sz);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(ndim, wx, wy, wz)) != EDT_OK) return rc;
   const int64_t voxels = sx * sy * sz;
   if (voxels == 0) return EDT_OK;
   if (!labels || !graph || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
@@ -928,6 +951,7 @@ int edt_hip_edt3dsq_multi(const void *labels, int dtype, int64_t sx, int64_t sy,
                           int n_devices) {
   int rc = check_shape(dtype, 3, sx, sy, sz);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(3, wx, wy, wz)) != EDT_OK) return rc;
   if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
   if (!labels || !output || !devices || n_devices < 1) { set_error("null pointer / empty device list"); return EDT_ERR_BAD_ARG; }
   if ((rc = require_device()) != EDT_OK) return rc;
@@ -1057,6 +1081,7 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(dtype, 3, sx, sy, sz_local);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(2, wx, wy, 1.0f)) != EDT_OK) return rc;
   if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
   if (!d_labels || !d_partial || !d_zflags) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   ShardPlan p = make_shard_plan(sx, sy, sz_local, d_workspace);
@@ -1105,6 +1130,7 @@ int edt_hip_shard_z_device_ex(float *d_partial, const uint8_t *d_zflags, int64_t
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(1, wz, 1.0f, 1.0f)) != EDT_OK) return rc;
   if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
   if (!d_partial || !d_zflags) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   ShardPlan p = make_shard_plan(sx, sy_local, sz, d_workspace);
@@ -1160,6 +1186,7 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(dtype, 3, sx, sy, sz_local);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(2, wx, wy, 1.0f)) != EDT_OK) return rc;
   if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
   if (!d_labels || !y_splits || !d_blocks || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
   if (!edt_hip_shard_records_supported(dtype, sx, sy, sz_local)) {
@@ -1265,6 +1292,7 @@ static int shard_z_records(float *d_records, int64_t sx, int64_t sy_local, int64
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(1, wz, 1.0f, 1.0f)) != EDT_OK) return rc;
   if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
   if (!d_records) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   if (!edt_hip_shard_records_supported(EDT_U8, sx, sy_local, sz)) {
@@ -1351,6 +1379,7 @@ int edt_hip_shard_xy_records16_device(const void *d_labels, const void *d_halo, 
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(dtype, 3, sx, sy, sz_local);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(2, wx, wy, 1.0f)) != EDT_OK) return rc;
   if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
   if (!d_labels || !y_splits || !d_blocks || !d_refused || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
   if (y_splits[0] != 0 || y_splits[nparts] != sy) { set_error("y_splits must run from 0 to sy"); return EDT_ERR_BAD_ARG; }
@@ -1413,6 +1442,7 @@ int edt_hip_shard_z_records16_device(const void *d_records, float *d_out, int64_
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(1, wz, 1.0f, 1.0f)) != EDT_OK) return rc;
   if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
   if (!d_records || !d_out) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   const float w3[3] = {wx, wy, wz};
@@ -1484,6 +1514,7 @@ int edt_hip_edtsq_voxel_graph_device(const void *d_labels, int dtype, const uint
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(dtype, ndim, sx, sy, sz);
   if (rc != EDT_OK) return rc;
+  if ((rc = check_voxel_sizes(ndim, wx, wy, wz)) != EDT_OK) return rc;
   if (ndim < 2) { set_error("voxel_graph needs a 2-D or 3-D volume"); return EDT_ERR_BAD_ARG; }
   if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
   if (!d_labels || !d_graph || !d_output) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }

@@ -143,6 +143,12 @@ int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_
 // the quantum of a call: w_i^2 = a[i] * q (false: the voxel sizes share none, the fp32 kernels keep the call)
 bool q16_quantum(const float *w, int naxes, float *q, uint32_t *a);
 bool column_pass_q16_supported(const AxisGeom &g);
+// the kernel's vector accesses: 16-byte loads of fp32 rows, 8-byte stores of result pairs, 8-byte loads of index / plane
+// rows (a 4-byte-aligned view handed in through DLPack stays on the fp32 kernel, which gates its vector accesses itself)
+inline bool column_pass_q16_aligned(const float *F, const uint16_t *codes, const uint16_t *plane, const float *compact = nullptr) {
+  return (reinterpret_cast<uintptr_t>(F) % 16) == 0 && (reinterpret_cast<uintptr_t>(codes) % 8) == 0 &&
+         (reinterpret_cast<uintptr_t>(plane) % 8) == 0 && (reinterpret_cast<uintptr_t>(compact) % 8) == 0;
+}
 // codes != nullptr: pass X in index form (N = k^2 * ain), F is only written; else F is read (N = F / q, verified) and
 // written in place.  a: c_d = a * d^2 quanta.  Tiles that do not qualify are appended to (count, ids) for the fp32 kernel.
 // plane / map (volumes whose indices fit one slab): with codes, the results stay 16-bit -- written over the indices

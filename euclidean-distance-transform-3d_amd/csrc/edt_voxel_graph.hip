@@ -546,7 +546,7 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
   auto column_pass = [&](const uint16_t *in16, const uint32_t *nzp, const uint32_t *rsp, const AxisGeom &g, float h, int axis, int epi,
                          const ColumnOut &co, uint32_t *count) -> int {
     TileList list;
-    if (q16 && column_pass_q16_supported(g) && column_pass_wave_supported(g)) {
+    if (q16 && column_pass_q16_supported(g) && column_pass_wave_supported(g) && column_pass_q16_aligned(F1, in16, nullptr, co.compact)) {
       const int r = launch_column_pass_q16(F1, in16, rsp, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, q16_ids, stream, nullptr,
                                            nullptr, nullptr, 0, &co);
       if (r != EDT_OK) return r;

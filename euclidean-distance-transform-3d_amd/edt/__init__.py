@@ -260,6 +260,10 @@ def _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim, signed=Fa
     weights = tuple(float(np.float32(a)) for a in np.asarray(anisotropy, dtype=np.float64).reshape(-1))
     if len(weights) != ndim:
         raise ValueError(f"anisotropy must have {ndim} entries, got {len(weights)}")
+    # (stated deviation: the reference does not validate voxel sizes -- a negative one makes its pass 1 cross label
+    # boundaries, src/edt.hpp:107-109; the C ABI refuses them as well, include/edt_hip.h)
+    if not all(np.isfinite(a) and a > 0.0 for a in weights):
+        raise ValueError(f"anisotropy must be positive and finite, got {weights}")
 
     # x is the fastest axis of the buffer the kernels see.
     if order == "F":

@@ -226,3 +226,28 @@ def test_records_of_16_bit_rows_host_side(lib):
     # the entry points refuse what they cannot serve before touching the device
     rc = lib.edt_hip_shard_z_records16_device(None, None, 512, 128, 512, 1.0, 1.0, 1.0, 0, None, 0, None)
     assert rc < 0 and b"null" in lib.edt_hip_last_error()
+
+
+@pytest.mark.parametrize("bad", [-1.0, 0.0, float("nan"), float("inf"), -float("inf")])
+def test_voxel_sizes_are_validated_before_any_device_work(lib, bad):
+    """Non-positive / non-finite voxel sizes are refused at the boundary (the reference does not validate them and
+    its pass 1 crosses label boundaries for a negative size, src/edt.hpp:107-109 -- no kernel here answers that case, so every
+    entry point says EDT_ERR_BAD_ARG instead of different kernels giving different fields).  The check comes before the
+    device check: it can be exercised without a GPU."""
+    import edt
+    from edt import _lib
+    lab = np.ones((4, 4, 4), dtype=np.uint32)
+    out = np.empty(lab.size, dtype=np.float32)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    for w in ((bad, 1.0, 1.0), (1.0, bad, 1.0), (1.0, 1.0, bad)):
+        rc = lib.edt_hip_edt3dsq(p(lab), _lib.U32, 4, 4, 4, w[0], w[1], w[2], 1, 1, p(out))
+        assert rc == -2 and b"voxel sizes" in lib.edt_hip_last_error()   # EDT_ERR_BAD_ARG
+        with pytest.raises(ValueError):
+            edt.edtsq(lab, anisotropy=w)
+    assert lib.edt_hip_squared_edt_1d_multi_seg(p(lab), _lib.U32, p(out), 64, 1, bad, 1) == -2
+    assert lib.edt_hip_sdf(p(lab), _lib.U32, 3, 4, 4, 4, 1.0, bad, 1.0, 1, 1, p(out)) == -2
+    graph = np.zeros(lab.size, dtype=np.uint8)
+    assert lib.edt_hip_edt3dsq_voxel_graph(p(lab), _lib.U32, p(graph), 4, 4, 4, 1.0, 1.0, bad, 1, p(out)) == -2
+    # (an unused axis is not looked at)
+    with pytest.raises(ValueError):
+        edt.edt(np.ones((4, 4), dtype=np.uint8), anisotropy=(1.0, bad))

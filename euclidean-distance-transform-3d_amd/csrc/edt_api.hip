@@ -346,28 +346,47 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   uint32_t q16_a[3] = {1u, 1u, 1u};
   bool q16 = false;
   int q16_slot = 0;
+  bool q16_counts_zeroed = false;
   if (ndim >= 2 && p.q16_counts != nullptr) {
     const float ws3[3] = {wx, wy, wz};
     q16 = q16_quantum(ws3, (ndim == 3 && !(flags & EDT_FLAG_BATCH_2D)) ? 3 : 2, &q16_q, q16_a);
-    if (q16) EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, (kQ16Slots + (size_t)(ceil_div(sx, 32) * p.q16_map_words)) * sizeof(uint32_t), stream));
   }
   constexpr int kQ16Off = 16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000;
+  // When can the integer kernel refuse no tile at all?  With a black border every row of pass X has a boundary and its
+  // index is at most ceil(sx / 2); in the index form the values are integers by construction (k^2 * ax quanta), and so
+  // are the integer kernel's own results; so if ceil(sx / 2)^2 * ax is within the range of a pass (its 16-bit form, or the
+  // wide form: q16_value_limit) and everything that pass reads was written by pass X or by an integer pass that could
+  // not refuse either, the fp32 launch over the hand-over list has nothing to do and is not made -- nor is the list's
+  // counter zeroed.  (debug bit 0x20000000: always launch.)
+  const uint64_t q16_vmax = (uint64_t)ceil_div(sx, 2) * (uint64_t)ceil_div(sx, 2) * q16_a[0];
+  auto q16_cannot_refuse = [&](int axis) {
+    return q16 && bb && !(g_debug_mode & 0x20000000) && q16_vmax <= q16_value_limit(q16_q, q16_a[axis]);
+  };
   // F in place (codes == nullptr) or from the 16-bit indices of pass X; returns the list for the fp32 launch that follows
+  // (launched: the integer kernel ran; sure: the caller vouches for what the pass reads -- see above)
   auto q16_pass = [&](float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, int axis, int epi,
-                      TileList &list, uint16_t *plane = nullptr) -> int {
+                      TileList &list, uint16_t *plane, bool sure, bool &launched) -> int {
     list = TileList();
+    launched = false;
     // (the bits that force one form of the fp32 kernel on every tile -- the test tiers' way to cover them -- keep the call there)
     if (!q16 || q16_slot >= kQ16Slots || !column_pass_q16_supported(g) || !column_pass_wave_supported(g) ||
         !column_pass_q16_aligned(F, codes, plane) || (g_debug_mode & kQ16Off))
       return EDT_OK;
     // (the id array was sized for these tile counts: make_plan)
     if (ceil_div(g.sx, 16) * (ceil_div(g.nouter, 8) * 8) > p.q16_id_capacity) return EDT_OK;
+    sure = sure && q16_cannot_refuse(axis);
+    if (!sure && !q16_counts_zeroed) {
+      EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, kQ16Slots * sizeof(uint32_t), stream));
+      q16_counts_zeroed = true;
+    }
     uint32_t *count = p.q16_counts + q16_slot++;
     const int r = launch_column_pass_q16(F, codes, rs, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, p.q16_ids, stream,
                                          nullptr, plane, p.q16_map, p.q16_map_words);
     if (r != EDT_OK) return r;
+    launched = true;
     list.count = count;
     list.ids = p.q16_ids;
+    list.none = sure;
     return EDT_OK;
   };
 
@@ -395,9 +414,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   // volume (one slab), the tiles of pass Y that qualify write their results over their indices -- 2 bytes per voxel out
   // of pass Y and into pass Z instead of 4 -- and pass Z reads every row from wherever pass Y left it.  (debug bit
   // 0x10000000: fp32 between the passes.)
-  const bool plane16 = q16 && index_form && zpass && p.xy_slab >= sz && !(g_debug_mode & (kQ16Off | 0x10000000)) &&
+  bool plane16 = q16 && index_form && zpass && p.xy_slab >= sz && !(g_debug_mode & (kQ16Off | 0x10000000)) &&
                        column_pass_q16_supported(p.gy) && column_pass_q16_supported(p.gz) &&
                        column_pass_wave_supported(p.gy) && column_pass_wave_supported(p.gz);
+  bool y_sure = true;  // every tile of pass Y was served by the integer kernel, provably (q16_cannot_refuse)
   if (index_form) {
     const int64_t sxy = sx * sy, wpl = p.gy.sx * p.gy.nbands;  // voxels / bit words per slice
     const size_t lsz = dtype_size(dtype);
@@ -425,10 +445,15 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
         AxisGeom g = p.gy;
         g.nouter = zc;
         TileList list;
-        rc = q16_pass(cur + z0 * sxy, p.codes, p.rs_y + z0 * wpl, g, 1, zpass ? 0 : last_epi, list, plane16 ? p.codes : nullptr);
+        bool launched = false;
+        rc = q16_pass(cur + z0 * sxy, p.codes, p.rs_y + z0 * wpl, g, 1, zpass ? 0 : last_epi, list, plane16 ? p.codes : nullptr,
+                      true, launched);
         if (rc != EDT_OK) return rc;
-        rc = launch_column_pass_wave_codes(cur + z0 * sxy, p.codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
-                                           zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream, nullptr, list);
+        if (!launched) plane16 = false;  // (nothing wrote the plane or said where the rows are: pass Z reads fp32 values)
+        y_sure = y_sure && list.none;
+        if (!list.none)
+          rc = launch_column_pass_wave_codes(cur + z0 * sxy, p.codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
+                                             zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream, nullptr, list);
         if (rc != EDT_OK) return rc;
       }
     }
@@ -464,8 +489,11 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     const int epi = zpass ? 0 : last_epi;
     if (tiled_y) {
       TileList list;
-      rc = q16_pass(cur, nullptr, p.rs_y, p.gy, 1, epi, list);
+      bool launched = false;
+      // (fp32 values of pass X: (k * wx)^2 need not be on the quantum grid for large k -- the list stays)
+      rc = q16_pass(cur, nullptr, p.rs_y, p.gy, 1, epi, list, nullptr, false, launched);
       if (rc != EDT_OK) return rc;
+      y_sure = false;
       rc = launch_column_inplace(cur, p.nz_y, p.rs_y, p.gy, wy, bb, epi, stream, list);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_y, p.rs_y, p.stack, p.gy, wy, bb, epi, stream);
@@ -487,9 +515,10 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
     ScopedPass t("z_pass", stream);
     if (tiled_z) {
       TileList list;
-      rc = q16_pass(cur, nullptr, p.rs_z, p.gz, 2, last_epi, list, plane16 ? p.codes : nullptr);
+      bool launched = false;
+      rc = q16_pass(cur, nullptr, p.rs_z, p.gz, 2, last_epi, list, plane16 ? p.codes : nullptr, index_form && y_sure, launched);
       if (rc != EDT_OK) return rc;
-      rc = launch_column_inplace(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream, list);
+      if (!list.none) rc = launch_column_inplace(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream, list);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_z, p.rs_z, p.stack, p.gz, wz, bb, last_epi,
                                      stream);

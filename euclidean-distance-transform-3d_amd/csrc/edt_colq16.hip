@@ -28,6 +28,7 @@
 #include "edt_kernels.h"
 
 #include <cstdlib>
+#include <cstring>
 
 #define EDT_LANE __device__ __forceinline__
 #define EDT_LANE_MEMBER __device__ __forceinline__
@@ -43,6 +44,11 @@ struct Q16Args {
   uint32_t kmax;          // index form: largest k with k^2 * ain <= nlim
   uint32_t nlim;          // largest N a tile may hold: a * dmax^2
   uint32_t dmax;          // largest d with a * d^2 <= 65534
+  // The wide form (edt_colq16_lane.h: V<true>): a tile that holds values beyond nlim but on the quantum grid and at most
+  // nlimw is worked on as two half-tiles of 16 columns with 32-bit lanes instead of being handed over.  nlimw == nlim: no
+  // wide form (output stride 2, 16-bit slab records, quanta whose odd part leaves no room).
+  uint32_t nlimw, dmaxw, kmaxw;
+  uint32_t fwmax_bits;    // bit pattern of (float)nlimw * q (exact)
   uint32_t *count;        // tiles handed to the fp32 kernel: *count of them ...
   uint32_t *ids;          // ... their tile ids (outer index * x-tiles + x-tile) in the fp32 kernel's geometry:
   int list_cols;          // its tiles are 32 columns wide, or 16 (axes of more than 512 rows: two ids per refused tile)
@@ -116,7 +122,8 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   constexpr int RPS = T / 8;            // rows per sweep of the workgroup: 8 threads x 4 columns per row
   const int r_in = t >> 3, cg = t & 7;
   const bool col_ok = 4 * cg < cols_left;
-  bool bad = false;
+  bool bad = false;   // the tile has no integer form at all: handed to the fp32 kernel
+  bool over = false;  // ... no 16-bit form (a value beyond nlim): the wide form if `bad` stays false
   if (t < 64) bm[t] = 0u, bm[t + 32] = 0u;  // (96 words)
   if (t < 8 * kPad) {
     // +inf around the column: 2 x kPad rows x 16 words, one 16-byte store per thread
@@ -129,7 +136,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   }
   if constexpr (IN == kQ16InCodes) {
     const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
-    const pk kmaxpk = pk_both(qa.kmax), ainpk = pk_both(qa.ain);
+    const pk kmaxpk = pk_both(qa.kmax), kmaxwpk = pk_both(qa.kmaxw), ainpk = pk_both(qa.ain);
     for (int i0 = 0; i0 < nb32; i0 += RPS * 16) {
       v2u kk[16];
 #pragma unroll
@@ -142,8 +149,10 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       for (int j = 0; j < 16; ++j) {
         const int row = i0 + RPS * j + r_in;
         if (row < nb32) {
-          // k > kmax (also the "no boundary" index 0xFFFF): the tile does not qualify (k^2 may have wrapped: never used)
-          bad |= (pk_subs(kk[j][0], kmaxpk) | pk_subs(kk[j][1], kmaxpk)) != 0u;
+          // k > kmax: the tile has no 16-bit form (k^2 may have wrapped: never used); k > kmaxw (also the "no boundary"
+          // index 0xFFFF): no wide form either
+          over |= (pk_subs(kk[j][0], kmaxpk) | pk_subs(kk[j][1], kmaxpk)) != 0u;
+          bad |= (pk_subs(kk[j][0], kmaxwpk) | pk_subs(kk[j][1], kmaxwpk)) != 0u;
           v2u v = {pk_mul(pk_mul(kk[j][0], kk[j][0]), ainpk), pk_mul(pk_mul(kk[j][1], kk[j][1]), ainpk)};
           if (row >= n) v = (v2u){~0u, ~0u};
           *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = v;
@@ -190,8 +199,8 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       for (int j = 0; j < NL; ++j) {
         const int row = i0 + RPS * j + r_in;
         if (row < nb32 && ((in16 >> j) & 1u)) {
-          // (pass Y's limit may be the larger one)
-          bad |= (pk_subs(raw[j][0], nlimpk) | pk_subs(raw[j][1], nlimpk)) != 0u;
+          // (pass Y's limit may be the larger one; a 16-bit value is always within the wide form's range)
+          over |= (pk_subs(raw[j][0], nlimpk) | pk_subs(raw[j][1], nlimpk)) != 0u;
           *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = (v2u){raw[j][0], raw[j][1]};
         } else if (row < nb32) {
           uint32_t u[4];
@@ -205,7 +214,15 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
             const float e = fmaf(-(float)u[c], qa.q, f);
             err = fmaxf(err, fabsf(e));  // (+inf in, NaN out: fmaxf keeps the other operand -- caught by the range test)
           }
-          bad |= !(err == 0.0f) | (max(max(u[0], u[1]), max(u[2], u[3])) > qa.nlim);
+          // a value beyond nlim: the conversion above was clamped (err says nothing) -- the quad is verified with the wide
+          // form's conversion instead (rare: a divergent branch)
+          if (max(max(u[0], u[1]), max(u[2], u[3])) > qa.nlim) {
+            over = true;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bad |= !wide_value(__uint_as_float(raw[j][c]), qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, u[c]);
+          } else {
+            bad |= !(err == 0.0f);
+          }
           v2u v = {u[0] | (u[1] << 16), u[2] | (u[3] << 16)};
           if (row >= n) v = (v2u){~0u, ~0u};
           *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = v;
@@ -216,12 +233,23 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   // (every wave publishes its own verdict: no initialisation to order against, and no static LDS -- __syncthreads_or has
   // some, and hipFuncSetAttribute then refuses the full 160 KiB of dynamic LDS)
   if ((t & 63) == 0) flags[t >> 6] = 0u;
-  if (__ballot(bad) != 0ull && (t & 63) == 0) flags[t >> 6] = 1u;
+  {
+    const uint32_t v = (__ballot(bad) != 0ull ? 1u : 0u) | (__ballot(over) != 0ull ? 2u : 0u);
+    if (v != 0u && (t & 63) == 0) flags[t >> 6] = v;
+  }
   __syncthreads();
-  uint32_t refused = 0;
+  uint32_t verdict = 0;
 #pragma unroll
-  for (int i = 0; i < T / 64; ++i) refused |= flags[i];
-  if (refused != 0u) {
+  for (int i = 0; i < T / 64; ++i) verdict |= flags[i];
+  // the wide form: every row of every column, fp32 results (16-bit slab records cannot carry them; the stride-2 form keeps
+  // the hand-over)
+  constexpr bool kWide = S == 1 && !(O16 && SC);
+  const bool go_wide = kWide && verdict == 2u && qa.nlimw > qa.nlim;
+  if (verdict != 0u && !go_wide) {
+    if constexpr (O16 && !SC) {
+      // (the map is never zeroed: every tile of the pass says where it left its rows)
+      if (t == 0) atomicAnd(qa.map + xt * qa.map_words + (int)(o >> 5), ~(1u << (o & 31)));
+    }
     if constexpr (IN == kQ16InMixed) {
       // the fp32 kernel reads F: the rows this tile has in the 16-bit plane become fp32 values there first (exact)
       const uint32_t *mapw = qa.map + xt * qa.map_words;
@@ -249,6 +277,122 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       }
     }
     return;
+  }
+  if constexpr (kWide) {
+    if (go_wide) {
+      // ---- the wide form: two half-tiles of 16 columns, one 32-bit value per image word, the same lane code ----
+      if constexpr (O16) {
+        if (t == 0) atomicAnd(qa.map + xt * qa.map_words + (int)(o >> 5), ~(1u << (o & 31)));  // (its results are fp32 values in F)
+      }
+      {
+        uint16_t *lohi16 = reinterpret_cast<uint16_t *>(lohi);
+        if (t < 32) scan_runs_lo(rsp + t, 32, NB, lohi16 + 2 * t, 64);
+        else if (t < 64) scan_runs_hi(rsp + (t - 32), 32, NB, n, lohi16 + 2 * (t - 32) + 1, 64);
+      }
+      const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+      const int lane = t & 63;
+      const int cw = lane & 15, bq = lane >> 4;
+      constexpr int RPSW = T / 4;  // rows per sweep of the fill: 4 threads x 4 columns per row
+      const int rw = t >> 2, cgw = t & 3;
+      const int nhalf = cols_left > 16 ? 2 : 1;
+#pragma unroll 1
+      for (int h = 0; h < nhalf; ++h) {
+        __syncthreads();  // (everybody has read the verdict; the blocks of the half before are done with the image)
+        if (t < 64) bm[t] = 0u, bm[t + 32] = 0u;
+        if (t < 8 * kPad) {
+          const int row = t < 4 * kPad ? -kPad + (t >> 2) : nb32 + ((t - 4 * kPad) >> 2);
+          *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (t & 3)) = (v4u){kInfW, kInfW, kInfW, kInfW};
+        }
+        const int c0 = 16 * h + 4 * cgw;  // the thread's four columns inside the tile
+        const bool cw_ok = c0 < cols_left;
+#pragma unroll 2
+        for (int row = rw; row < nb32; row += RPSW) {
+          v4u v = (v4u){kInfW, kInfW, kInfW, kInfW};
+          if (row < n) {
+            v = (v4u){0u, 0u, 0u, 0u};
+            if (cw_ok) {
+              bool p16 = false;
+              if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
+              if constexpr (IN == kQ16InCodes) {
+                const v2u kk = *reinterpret_cast<const v2u *>(qa.codes + x0 + o * g.outer_stride + c0 + (int64_t)row * st);
+                const uint32_t k0 = kk[0] & 0xFFFFu, k1 = kk[0] >> 16, k2 = kk[1] & 0xFFFFu, k3 = kk[1] >> 16;
+                v = (v4u){k0 * k0 * qa.ain, k1 * k1 * qa.ain, k2 * k2 * qa.ain, k3 * k3 * qa.ain};
+              } else if (p16) {
+                const v2u pv = *reinterpret_cast<const v2u *>(qa.plane + x0 + o * qa.p_outer + c0 + (int64_t)row * qa.pst);
+                v = (v4u){pv[0] & 0xFFFFu, pv[0] >> 16, pv[1] & 0xFFFFu, pv[1] >> 16};
+              } else {
+                const v4f f = *reinterpret_cast<const v4f *>(F + x0 + o * g.outer_stride + c0 + (int64_t)row * st);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  uint32_t u;
+                  (void)wide_value(f[c], qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, u);  // (verified by the first fill)
+                  v[c] = u;
+                }
+              }
+            }
+          }
+          *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * cgw) = v;
+        }
+        __syncthreads();
+        for (int u = t; u < 16 * NB; u += T) {
+          const int c = u & 15, band = u >> 4;
+          const int valid = n - 32 * band;
+          const uint32_t bits = band_breaks<true>(img + (32 * band + kPad) * kRowWords + c, qa.a, band == 0, valid < 32 ? valid : 32);
+          if (bits) atomicOr(&bm[c * 6 + 1 + (band >> 3)], bits << (4 * (band & 7)));
+        }
+        __syncthreads();
+        const bool store_ok = 16 * h + cw < cols_left;
+#pragma unroll 1
+        for (int sb = wave; sb * 32 < nb32; sb += T / 64) {
+          Block L;
+          L.img = img;
+          L.cp = cw;
+          L.p0 = 32 * sb + 8 * bq;
+          const int s = L.p0 >> 5;
+          L.n = n;
+          L.nb32 = nb32;
+          L.rswA = rsp[s * 32 + 16 * h + cw];
+          const uint32_t lh = lohi[s * 32 + 16 * h + cw];
+          L.loA = (int)(lh & 0xFFFFu) - 1;
+          L.hiA = (int)(lh >> 16) - 1;
+          L.rswB = 0u;
+          L.loB = L.hiB = 0;
+          L.a = qa.a;
+          L.dmax = qa.dmaxw;
+          {
+            const int gi = L.p0 >> 3, wi = gi >> 5, sh = gi & 31;
+            const uint32_t *m = bm + cw * 6 + wi;
+            const uint32_t e0 = m[0], e1 = m[1], e2 = m[2];
+            const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
+            const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
+            L.win = ((uint64_t)hi << 32) | lo;
+          }
+          pk best[kB];
+          block_eval<BB, 1, true>(L, best);
+          float *dst;
+          if constexpr (SC) {
+            const int b = s < BandScatter::kBands ? s : 0;
+            dst = scatter->rows[b] + o * scatter->ostride[b] + x0 + 16 * h + cw - (int64_t)s * 32 * st;
+          } else {
+            dst = F + x0 + o * g.outer_stride + 16 * h + cw;
+          }
+          auto *gdst = (__attribute__((address_space(1))) float *)dst;
+          float out[kB];
+#pragma unroll
+          for (int j = 0; j < kB; ++j) out[j] = (float)best[j] * qa.q;
+          if (epi & kEpiSqrt) {
+#pragma unroll
+            for (int j = 0; j < kB; ++j) out[j] = sqrtf(out[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < kB; ++j) {
+            const int row = L.p0 + j;
+            if (row < n && store_ok) gdst[(int64_t)row * st] = out[j];
+          }
+        }
+      }
+      return;
+    }
   }
   if constexpr (O16 && !SC) {
     if (t == 0) atomicOr(qa.map + xt * qa.map_words + (int)(o >> 5), 1u << (o & 31));
@@ -440,6 +584,18 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
   uint32_t kmax = 0;
   while ((uint64_t)(kmax + 1) * (kmax + 1) * ain <= qa.nlim && kmax < 65534u) ++kmax;
   qa.kmax = kmax;
+  {
+    // the wide form's range (nlimw == nlim: there is none)
+    const uint32_t dw = (debug_mode() & 0x20000000) ? 0u : edt_q16::q16_dmax_wide(a, q);
+    const uint64_t nw = (uint64_t)a * dw * dw;
+    qa.dmaxw = nw > qa.nlim ? dw : qa.dmax;
+    qa.nlimw = nw > qa.nlim ? (uint32_t)nw : qa.nlim;
+    uint32_t kw = kmax;
+    while ((uint64_t)(kw + 1) * (kw + 1) * ain <= qa.nlimw && kw < 65534u) ++kw;
+    qa.kmaxw = kw;
+    const float fw = (float)qa.nlimw * q;  // exact: nlimw * odd(q) < 2^24 (nlim: < 2^16 * 255)
+    memcpy(&qa.fwmax_bits, &fw, sizeof(fw));
+  }
   qa.count = count;
   qa.ids = ids;
   qa.list_cols = g.nbands > 16 ? 16 : 32;  // (edt_colwave_lane.h: TileGeom -- 16-column tiles for the 1- and 2-column waves)
@@ -460,6 +616,14 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
   const bool o16 = codes != nullptr && plane != nullptr;
   return bb ? launch_q16_b<true>(F, rs, g, qa, in, o16, epi, stream, scatter, ostride)
             : launch_q16_b<false>(F, rs, g, qa, in, o16, epi, stream, scatter, ostride);
+}
+
+// the largest value (in quanta) a tile of a pass with c_d = a * d^2 may hold without being handed to the fp32 kernel
+uint32_t q16_value_limit(float q, uint32_t a) {
+  const uint32_t d16 = edt_q16::q16_dmax(a), n16 = a * d16 * d16;
+  const uint32_t dw = (debug_mode() & 0x20000000) ? 0u : edt_q16::q16_dmax_wide(a, q);
+  const uint64_t nw = (uint64_t)a * dw * dw;
+  return nw > n16 ? (uint32_t)nw : n16;
 }
 
 // the quantum of a call (edt_colq16_lane.h: quantum_of), host side

@@ -105,6 +105,49 @@ EDT_LANE pk pk_both(uint32_t v) { return (v & 0xFFFFu) * 0x10001u; }
 EDT_LANE pk pk_sel(pk mask, pk a, pk b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
 
 // ---------------------------------------------------------------------------------------
+// What a 32-bit word of the image holds.  V<false>: two adjacent columns as 16-bit values (everything above).  V<true>,
+// the WIDE form: ONE column as a 32-bit value -- the same lane code on tiles that hold values beyond 16 bits (objects
+// deeper than ~255 voxels; the middle of a 512-voxel row: k = 256, N = 2^16), which the kernel then works on as two
+// half-tiles of 16 columns, one after the other, on the same LDS image (edt_colq16.hip).  Exact by the same argument while
+// N * odd(q) < 2^24; +inf is kInfW, every sum stays below 2^31 (no saturation needed).
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kInfW = 0x3FFFFFFFu;
+template <bool W>
+struct V;
+template <>
+struct V<false> {
+  static constexpr uint32_t kInfWord = 0xFFFFFFFFu;  // +inf in (both halves of) an image word
+  EDT_LANE_MEMBER static pk vmin(pk a, pk b) { return pk_min(a, b); }
+  EDT_LANE_MEMBER static pk vmax(pk a, pk b) { return pk_max(a, b); }
+  EDT_LANE_MEMBER static pk adds(pk a, pk b) { return pk_adds(a, b); }
+  EDT_LANE_MEMBER static pk subs(pk a, pk b) { return pk_subs(a, b); }
+  EDT_LANE_MEMBER static pk add(pk a, pk b) { return pk_add(a, b); }
+  EDT_LANE_MEMBER static pk mul(pk a, pk b) { return pk_mul(a, b); }
+  EDT_LANE_MEMBER static pk both(uint32_t v) { return pk_both(v); }
+  // a wave-uniform candidate offset c (may exceed the range: +inf then)
+  EDT_LANE_MEMBER static pk cval(uint64_t c) { return pk_both(c < kInf ? (uint32_t)c : kInf); }
+  template <int J>
+  EDT_LANE_MEMBER static pk bitmask(pk starts) { return pk_sar15(pk_shl<15 - J>(starts)); }  // bit J of either half -> that half all ones
+  // per-column quantities of the pair (A: the even column, B: the odd one)
+  EDT_LANE_MEMBER static pk cols(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
+};
+template <>
+struct V<true> {
+  static constexpr uint32_t kInfWord = kInfW;
+  EDT_LANE_MEMBER static pk vmin(pk a, pk b) { return a < b ? a : b; }
+  EDT_LANE_MEMBER static pk vmax(pk a, pk b) { return a > b ? a : b; }
+  EDT_LANE_MEMBER static pk adds(pk a, pk b) { return a + b; }  // (operands below 2^30)
+  EDT_LANE_MEMBER static pk subs(pk a, pk b) { return a > b ? a - b : 0u; }
+  EDT_LANE_MEMBER static pk add(pk a, pk b) { return a + b; }
+  EDT_LANE_MEMBER static pk mul(pk a, pk b) { return a * b; }
+  EDT_LANE_MEMBER static pk both(uint32_t v) { return v; }
+  EDT_LANE_MEMBER static pk cval(uint64_t c) { return c < kInfW ? (uint32_t)c : kInfW; }
+  template <int J>
+  EDT_LANE_MEMBER static pk bitmask(pk starts) { return 0u - ((starts >> J) & 1u); }
+  EDT_LANE_MEMBER static pk cols(uint32_t a, uint32_t) { return a; }
+};
+
+// ---------------------------------------------------------------------------------------
 // The quantum of a call (host): w_i^2 = a_i * q for every axis of the call, q = odd * 2^e with odd <= 255, so that
 // N * q is exact in fp32 for every N < 2^16.  ok = false: no such quantum (the fp32 kernels keep the call).
 // ---------------------------------------------------------------------------------------
@@ -170,6 +213,40 @@ EDT_HOSTFN uint32_t q16_dmax(uint32_t a) {
   return d;
 }
 
+// wide form: the largest N a tile may hold -- N * odd(q) < 2^24 (exact in fp32), N <= a * d^2 for a d <= 2047 (the axis
+// has at most 1024 rows: the clamp of the border distance changes no minimum) -- and that d
+EDT_HOSTFN uint32_t q16_odd_of(float q) {
+  int ex;
+  const double fr = frexp((double)q, &ex);
+  uint64_t m = (uint64_t)ldexp(fr, 24);
+  while (m && !(m & 1u)) m >>= 1;
+  return (uint32_t)m;
+}
+EDT_HOSTFN uint32_t q16_dmax_wide(uint32_t a, float q) {
+  const uint64_t cap = ((1ull << 24) - 1) / q16_odd_of(q);
+  uint32_t d = 1;
+  while (d < 2047u && (uint64_t)a * (d + 1) * (d + 1) <= cap) ++d;
+  return (uint64_t)a * d * d <= cap ? d : 0u;  // 0: not even one row (the wide form does not apply)
+}
+
+// N = f / q as a 32-bit integer, exact or not at all (wide form; also the verdict on a value the 16-bit conversion of
+// edt_colq16.hip had to clamp): false unless f == N * q for an N <= nlimw.  fwmax_bits: bit pattern of (float)nlimw * q
+// (non-negative floats order like their bit patterns; negative values, NaN and +inf lie above every one of them).
+// f * rq is within 2 of N (rq and the product are rounded); the remainder f - u0 * q is a small multiple of q, exact as
+// ONE fma, and puts that right.
+EDT_LANE bool wide_value(float f, float q, float rq, uint32_t nlimw, uint32_t fwmax_bits, uint32_t &u) {
+  uint32_t fb;
+  memcpy(&fb, &f, sizeof(fb));
+  u = 0u;
+  if (fb > fwmax_bits) return false;
+  const float u0 = rintf(f * rq);
+  const float r = fmaf(-u0, q, f);
+  const float un = u0 + rintf(r * rq);
+  const float e = fmaf(-un, q, f);
+  u = (uint32_t)un;
+  return e == 0.0f && u <= nlimw;
+}
+
 // ---------------------------------------------------------------------------------------
 // Breaks of one band of a column pair: bit k of the result = some link r-1 -> r with r in block k of the band
 // (rows 8k .. 8k+7) has |N[r] - N[r-1]| > a in either column.  rows[0] = the row before the band, rows[1..32] the band.
@@ -177,10 +254,11 @@ EDT_HOSTFN uint32_t q16_dmax(uint32_t a) {
 // ---------------------------------------------------------------------------------------
 // band0: word of (first row of the band, pair).  top: the band is the column's first (no link into its first row).
 // valid: rows of the band that are rows of the column (32 but for the last band; the +inf rows after them are no links).
+template <bool W = false>
 EDT_LANE uint32_t band_breaks(const uint32_t *band0, pk apk, bool top, int valid) {
   uint32_t bits = 0;
   pk y = top ? band0[0] : band0[-kRowWords];
-  pk ty = pk_adds(y, apk);
+  pk ty = V<W>::adds(y, apk);
   EDT_Q16_UNROLL
   for (int k = 0; k < 4; ++k) {
     pk acc = 0;
@@ -188,8 +266,8 @@ EDT_LANE uint32_t band_breaks(const uint32_t *band0, pk apk, bool top, int valid
     for (int j = 0; j < 8; ++j) {
       pk x = band0[(8 * k + j) * kRowWords];
       if (valid < 32 && 8 * k + j >= valid) x = y;
-      const pk tx = pk_adds(x, apk);
-      acc |= pk_subs(x, ty) | pk_subs(y, tx);
+      const pk tx = V<W>::adds(x, apk);
+      acc |= V<W>::subs(x, ty) | V<W>::subs(y, tx);
       y = x;
       ty = tx;
     }
@@ -230,8 +308,9 @@ struct Block {
 
 // S = output stride: 1 = every row of the block is evaluated; 2 = a block is 16 rows of which the even ones are evaluated (the
 // doubled grids of the voxel-graph transform, whose odd rows are never read again) -- every row is a candidate either way.
-template <bool BB, int S = 1>
+template <bool BB, int S = 1, bool W = false>
 struct Steps {
+  typedef V<W> X;
   static constexpr int K = kK, B = kB, RW = kRowWords, NR = S * B;  // NR rows per block
   const Block &L;
   pk (&w)[NR + 2 * K];
@@ -243,11 +322,12 @@ struct Steps {
   EDT_LANE_MEMBER void refresh_bound() {
     pk m = best[0];
     EDT_Q16_UNROLL
-    for (int i = 1; i < B; ++i) m = pk_max(m, best[i]);
+    for (int i = 1; i < B; ++i) m = X::vmax(m, best[i]);
     bmax = m;
   }
-  // c_d as a packed constant (wave-uniform: scalar arithmetic), +inf once it leaves 16 bits
+  // c_d as a (packed) constant (wave-uniform: scalar arithmetic), +inf once it leaves the range
   EDT_LANE_MEMBER pk cpk(int d) const {
+    if constexpr (W) return X::cval((uint64_t)a * (uint32_t)(d * d));
     const uint32_t c = a * (uint32_t)(d * d);
     return pk_both(c < kInf ? c : kInf);
   }
@@ -259,7 +339,7 @@ struct Steps {
       const pk c1 = cpk(D), c2 = cpk(D + 1);
       // a candidate at distance d is at least c_d: once c_d >= every current minimum of the wave nothing further away
       // can lower any of them
-      if (!EDT_Q16_ANY(pk_subs(bmax, c1) != 0u)) return;
+      if (!EDT_Q16_ANY(X::subs(bmax, c1) != 0u)) return;
       w[K - D] = PB[(K - D) * RW];
       w[K + NR - 1 + D] = PB[(K + NR - 1 + D) * RW];
       w[K - D - 1] = PB[(K - D - 1) * RW];
@@ -268,9 +348,9 @@ struct Steps {
       for (int ii = 0; ii < B; ++ii) {
         // (the first and the last row of the block need the rows just requested: they come last)
         const int i = ii < B - 2 ? ii + 1 : (ii == B - 2 ? 0 : B - 1);
-        const pk m1 = pk_min(w[K + S * i - D], w[K + S * i + D]);
-        const pk m2 = pk_min(w[K + S * i - D - 1], w[K + S * i + D + 1]);
-        best[i] = pk_min(pk_min(best[i], pk_adds(m1, c1)), pk_adds(m2, c2));
+        const pk m1 = X::vmin(w[K + S * i - D], w[K + S * i + D]);
+        const pk m2 = X::vmin(w[K + S * i - D - 1], w[K + S * i + D + 1]);
+        best[i] = X::vmin(X::vmin(best[i], X::adds(m1, c1)), X::adds(m2, c2));
       }
       run<D + 2>();
     } else if constexpr (S == 2) {
@@ -293,7 +373,7 @@ struct Steps {
           const int d = d0 + e;
           if (e % kRefresh == 0) refresh_bound();
           const pk c1 = cpk(d);
-          if (!EDT_Q16_ANY(pk_subs(bmax, c1) != 0u)) { done = true; break; }
+          if (!EDT_Q16_ANY(X::subs(bmax, c1) != 0u)) { done = true; break; }
           if (e % 8 == 0) {
             int rl = L.p0 - d - 7, rh = L.p0 + NR - 1 + d;  // the rows of the next eight steps: rl .. rl+7, rh .. rh+7
             rl = rl < -kPad ? -kPad : rl;
@@ -306,8 +386,8 @@ struct Steps {
           rhi[sl] = shi[(e % 8) * RW];
           EDT_Q16_UNROLL
           for (int i = 0; i < B; ++i) {
-            const pk m = pk_min(rlo[(sl - 2 * i + 2 * R) % R], rhi[(sl - (NR - 1) + 2 * i + 2 * R) % R]);
-            best[i] = pk_min(best[i], pk_adds(m, c1));
+            const pk m = X::vmin(rlo[(sl - 2 * i + 2 * R) % R], rhi[(sl - (NR - 1) + 2 * i + 2 * R) % R]);
+            best[i] = X::vmin(best[i], X::adds(m, c1));
           }
         }
         if (done) break;
@@ -333,7 +413,7 @@ struct Steps {
           const int d = d0 + e;
           if (e % kRefresh == 0) refresh_bound();
           const pk c1 = cpk(d), c2 = cpk(d + 1);
-          if (!EDT_Q16_ANY(pk_subs(bmax, c1) != 0u)) { done = true; break; }
+          if (!EDT_Q16_ANY(X::subs(bmax, c1) != 0u)) { done = true; break; }
           if (e % 8 == 0) {
             int rl = L.p0 - d - 7, rh = L.p0 + B - 1 + d;  // the rows of the next eight steps: rl .. rl+7, rh .. rh+7
             rl = rl < -kPad ? -kPad : rl;
@@ -349,9 +429,9 @@ struct Steps {
           EDT_Q16_UNROLL
           for (int i = 0; i < B; ++i) {
             // row p0+i-d entered at step d-i, row p0+i+d at step d-(B-1-i)
-            const pk m1 = pk_min(rlo[(s1 - i + R) % R], rhi[(s1 - (B - 1 - i) + R) % R]);
-            const pk m2 = pk_min(rlo[(s2 - i + R) % R], rhi[(s2 - (B - 1 - i) + R) % R]);
-            best[i] = pk_min(pk_min(best[i], pk_adds(m1, c1)), pk_adds(m2, c2));
+            const pk m1 = X::vmin(rlo[(s1 - i + R) % R], rhi[(s1 - (B - 1 - i) + R) % R]);
+            const pk m2 = X::vmin(rlo[(s2 - i + R) % R], rhi[(s2 - (B - 1 - i) + R) % R]);
+            best[i] = X::vmin(X::vmin(best[i], X::adds(m1, c1)), X::adds(m2, c2));
           }
         }
         if (done) break;
@@ -377,8 +457,9 @@ EDT_LANE uint32_t dist_above(uint32_t rsw, int hi_out, int row0, int k0, int n, 
 
 // best[i] = result of row p0 + S * i (both columns), in quanta.  S = 2: the block is the 16 rows p0 .. p0 + 15 (p0 a multiple
 // of 16), its even rows are evaluated.
-template <bool BB, int S = 1>
+template <bool BB, int S = 1, bool W = false>
 EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
+  typedef V<W> X;
   constexpr int K = kK, B = kB, RW = kRowWords, NR = S * B;
   const int row0 = L.p0 & ~31, k0 = L.p0 & 31;
   const uint32_t *PB = L.img + (L.p0 - K + kPad) * RW + L.cp;
@@ -387,20 +468,21 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
   for (int j = 0; j < NR; ++j) w[K + j] = PB[(K + j) * RW];
   // ---- B_p: border distances as packed counters from run start to run start ----
   constexpr uint32_t kRowBits = S == 2 ? 0xFFFFu : 0xFFu;
-  const pk starts = ((L.rswA >> k0) & kRowBits) | (((L.rswB >> k0) & kRowBits) << 16);  // bit j of a half: a run starts at row p0 + j
-  pk dl = dist_below<BB>(L.rswA, L.loA, row0, k0) | (dist_below<BB>(L.rswB, L.loB, row0, k0) << 16);
+  // (wide form: one column per lane -- the B members of the block are not looked at)
+  const pk starts = X::cols((L.rswA >> k0) & kRowBits, W ? 0u : (L.rswB >> k0) & kRowBits);  // bit j of a half: a run starts at row p0 + j
+  pk dl = X::cols(dist_below<BB>(L.rswA, L.loA, row0, k0), W ? 0u : dist_below<BB>(L.rswB, L.loB, row0, k0));
   // (a block that reaches beyond the column's last row has a "negative" distance above: the counters are 16-bit modular,
   // the rows of the column come out right and the others are not rows)
-  pk dr = (dist_above<BB>(L.rswA, L.hiA, row0, k0, L.n, NR) & 0xFFFFu) | (dist_above<BB>(L.rswB, L.hiB, row0, k0, L.n, NR) << 16);
-  const pk one = 0x00010001u;
+  pk dr = X::cols(dist_above<BB>(L.rswA, L.hiA, row0, k0, L.n, NR), W ? 0u : dist_above<BB>(L.rswB, L.hiB, row0, k0, L.n, NR));
+  const pk one = X::both(1u);
   // a run that starts at row 0 of the column has a border below it only with black_border
-  const pk first0 = (BB || L.p0 > 0) ? one : pk_both(kFar);
+  const pk first0 = (BB || L.p0 > 0) ? one : X::both(kFar);
   pk mask[NR], dlv[B];
   {
 #define EDT_Q16_ROW_UP(J)                                                   \
-    mask[J] = pk_sar15(pk_shl<15 - J>(starts));                             \
+    mask[J] = X::template bitmask<J>(starts);                               \
     EDT_Q16_OPAQUE(mask[J]);                                                \
-    dl = pk_sel(mask[J], J == 0 ? first0 : one, pk_add(dl, one));           \
+    dl = pk_sel(mask[J], J == 0 ? first0 : one, X::add(dl, one));           \
     if ((J) % S == 0) dlv[(J) / S] = dl;
     EDT_Q16_ROW_UP(0) EDT_Q16_ROW_UP(1) EDT_Q16_ROW_UP(2) EDT_Q16_ROW_UP(3)
     EDT_Q16_ROW_UP(4) EDT_Q16_ROW_UP(5) EDT_Q16_ROW_UP(6) EDT_Q16_ROW_UP(7)
@@ -410,16 +492,16 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
     }
 #undef EDT_Q16_ROW_UP
   }
-  const pk dmaxpk = pk_both(L.dmax), apk = pk_both(L.a);
+  const pk dmaxpk = X::both(L.dmax), apk = X::both(L.a);
   pk bmax = 0;
   EDT_Q16_UNROLL
   for (int j = NR - 1; j >= 0; --j) {
-    dr = pk_add(dr, one);
+    dr = X::add(dr, one);
     if (j % S == 0) {
-      const pk dm = pk_min(pk_min(dlv[j / S], dr), dmaxpk);
-      // a * min(d, dmax)^2 fits 16 bits; a tile on this path holds no value above a * dmax^2, so the clamp changes no minimum
-      const pk bord = pk_mul(pk_mul(dm, dm), apk);
-      best[j / S] = pk_min(w[K + j], bord);
+      const pk dm = X::vmin(X::vmin(dlv[j / S], dr), dmaxpk);
+      // a * min(d, dmax)^2 fits the range; a tile on this path holds no value above a * dmax^2, so the clamp changes no minimum
+      const pk bord = X::mul(X::mul(dm, dm), apk);
+      best[j / S] = X::vmin(w[K + j], bord);
     }
     dr = dr & ~mask[j];  // (a set bit is a real row: the border site of the rows below it)
   }
@@ -430,15 +512,15 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
       if (L.p0 + S * i >= L.n) best[i] = 0u;
   }
   EDT_Q16_UNROLL
-  for (int i = 0; i < B; ++i) bmax = pk_max(bmax, best[i]);
+  for (int i = 0; i < B; ++i) bmax = X::vmax(bmax, best[i]);
   // ---- flat neighbourhood: nothing within reach can improve any row of the wave's blocks ----
   {
     uint32_t D1 = (uint32_t)flat_reach<S>(L.win) + 1u;
     D1 = D1 < L.dmax + 1u ? D1 : L.dmax + 1u;
-    const uint32_t cD = L.a * D1 * D1;
-    if (!EDT_Q16_ANY(pk_subs(bmax, pk_both(cD < kInf ? cD : kInf)) != 0u)) return;
+    const uint64_t cD = (uint64_t)L.a * D1 * D1;
+    if (!EDT_Q16_ANY(X::subs(bmax, X::cval(cD)) != 0u)) return;
   }
-  Steps<BB, S> steps{L, w, best, PB, bmax, L.a};
+  Steps<BB, S, W> steps{L, w, best, PB, bmax, L.a};
   steps.template run<1>();
 }
 

@@ -39,8 +39,11 @@ void set_error(const std::string &msg);
 //   0x4000000     rows of 1025..2048 voxels: the workgroup-phased kernel of pass X, not the two-wave form
 //   0x8000000     no 16-bit integer column kernel (edt_colq16.hip): every tile on the fp32 kernels
 //   0x10000000    integer column kernels: fp32 values between passes Y and Z, not the 16-bit plane
+//   0x20000000    integer column kernels: no wide form (tiles beyond 16 bits go to the fp32 kernel, as in round 4); with it
+//                 the fp32 launch over the hand-over list is never skipped
 constexpr int kDiagFormBits = 16 | 32 | 64 | 256 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |
-                              0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000 | 0x2000000 | 0x4000000 | 0x8000000 | 0x10000000;
+                              0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000 | 0x2000000 | 0x4000000 | 0x8000000 | 0x10000000 |
+                              0x20000000;
 #ifdef EDT_DIAG
 #define EDT_DIAG_BITS(dbg, bits) ((dbg) & (bits))
 #else

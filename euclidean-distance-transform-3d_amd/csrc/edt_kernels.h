@@ -126,6 +126,7 @@ struct ColumnOut {
 struct TileList {
   const uint32_t *count = nullptr;
   const uint32_t *ids = nullptr;
+  bool none = false;  // the integer kernel served EVERY tile and the host can prove it (edt_api.hip): no fp32 launch at all
 };
 // scatter != nullptr (device table): the rows are written to the slab records instead of F
 // out: see ColumnOut (default: every row, in place) -- (tiles on the windowed path evaluate and write
@@ -143,6 +144,9 @@ int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_
 // the quantum of a call: w_i^2 = a[i] * q (false: the voxel sizes share none, the fp32 kernels keep the call)
 bool q16_quantum(const float *w, int naxes, float *q, uint32_t *a);
 bool column_pass_q16_supported(const AxisGeom &g);
+// the largest value, in quanta, a tile of a pass with c_d = a * d^2 may hold and stay on the integer kernel (its 16-bit
+// form, or the wide form: two half-tiles with 32-bit lanes) -- what a host that knows a bound of the field compares with
+uint32_t q16_value_limit(float q, uint32_t a);
 // the kernel's vector accesses: 16-byte loads of fp32 rows, 8-byte stores of result pairs, 8-byte loads of index / plane
 // rows (a 4-byte-aligned view handed in through DLPack stays on the fp32 kernel, which gates its vector accesses itself)
 inline bool column_pass_q16_aligned(const float *F, const uint16_t *codes, const uint16_t *plane, const float *compact = nullptr) {

@@ -20,9 +20,90 @@ using namespace edt_q16;
 
 namespace {
 
-// one tile: columns x0 .. x0+31.  Returns false if the tile does not qualify (nothing is written then).
+bool g_no_wide = false;
+
+// The wide form of a tile (edt_colq16.hip, go_wide): two half-tiles of 16 columns, one 32-bit value per image word.
+template <bool BB>
+void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, float *out, int64_t sx, int n, int64_t x0,
+                    float q, uint32_t a, uint32_t ain, int epi, const uint16_t *plane_in, const uint8_t *row_in_plane,
+                    uint32_t dmaxw, uint32_t nlimw, uint32_t fwmax_bits) {
+  const int NB = (n + 31) / 32, nb32 = NB * 32;
+  const int cols_left = (int)(sx - x0);
+  std::vector<uint32_t> rsp((size_t)NB * 32, 0), lohi((size_t)NB * 32, 0);
+  for (int band = 0; band < NB; ++band)
+    for (int col = 0; col < 32; ++col)
+      rsp[(size_t)band * 32 + col] = col < cols_left ? rsbits[(size_t)band * sx + x0 + col] : 0u;
+  uint16_t *lohi16 = reinterpret_cast<uint16_t *>(lohi.data());
+  for (int t = 0; t < 32; ++t) {
+    scan_runs_lo(rsp.data() + t, 32, NB, lohi16 + 2 * t, 64);
+    scan_runs_hi(rsp.data() + t, 32, NB, n, lohi16 + 2 * t + 1, 64);
+  }
+  for (int h = 0; h < (cols_left > 16 ? 2 : 1); ++h) {
+    std::vector<uint32_t> img((size_t)(nb32 + 2 * kPad) * kRowWords, kInfW), bm(16 * 6, 0);
+    for (int row = 0; row < n; ++row)
+      for (int c = 0; c < 16; ++c) {
+        const int col = 16 * h + c;
+        uint32_t v = 0;
+        if (col < cols_left) {
+          if (plane_in && row_in_plane[row]) v = plane_in[(int64_t)row * sx + x0 + col];
+          else if (codes) {
+            const uint32_t k = codes[(int64_t)row * sx + x0 + col];
+            v = k * k * ain;
+          } else {
+            (void)wide_value(Fin[(int64_t)row * sx + x0 + col], q, 1.0f / q, nlimw, fwmax_bits, v);
+          }
+        }
+        img[(size_t)(row + kPad) * kRowWords + c] = v;
+      }
+    for (int u = 0; u < 16 * NB; ++u) {
+      const int c = u & 15, band = u >> 4;
+      const int valid = n - 32 * band;
+      const uint32_t bits = band_breaks<true>(img.data() + (size_t)(32 * band + kPad) * kRowWords + c, a, band == 0, valid < 32 ? valid : 32);
+      bm[c * 6 + 1 + (band >> 3)] |= bits << (4 * (band & 7));
+    }
+    for (int sb = 0; sb * 32 < nb32; ++sb)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int cw = lane & 15, bq = lane >> 4;
+        Block L;
+        L.img = img.data();
+        L.cp = cw;
+        L.p0 = 32 * sb + 8 * bq;
+        const int s = L.p0 >> 5;
+        L.n = n;
+        L.nb32 = nb32;
+        L.rswA = rsp[(size_t)s * 32 + 16 * h + cw];
+        const uint32_t lh = lohi[(size_t)s * 32 + 16 * h + cw];
+        L.loA = (int)(lh & 0xFFFFu) - 1;
+        L.hiA = (int)(lh >> 16) - 1;
+        L.rswB = 0u;
+        L.loB = L.hiB = 0;
+        L.a = a;
+        L.dmax = dmaxw;
+        {
+          const int gi = L.p0 >> 3, wi = gi >> 5, sh = gi & 31;
+          const uint32_t *m = bm.data() + cw * 6 + wi;
+          const uint32_t e0 = m[0], e1 = m[1], e2 = m[2];
+          const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
+          const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
+          L.win = ((uint64_t)hi << 32) | lo;
+        }
+        pk best[kB];
+        block_eval<BB, 1, true>(L, best);
+        for (int j = 0; j < kB; ++j) {
+          const int row = L.p0 + j, col = 16 * h + cw;
+          if (row >= n || col >= cols_left) continue;
+          float v = (float)best[j] * q;
+          if (epi & 2) v = sqrtf(v);
+          out[(int64_t)row * sx + x0 + col] = v;
+        }
+      }
+  }
+}
+
+// one tile: columns x0 .. x0+31.  Returns 0 if the tile does not qualify (nothing is written then), 1 if it was worked on in
+// its 16-bit form, 2 in the wide form (fp32 results in `out` whatever plane_out says).
 template <bool BB, int S = 1>
-bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, float *out, int64_t sx, int n, int64_t x0,
+int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, float *out, int64_t sx, int n, int64_t x0,
                float q, uint32_t a, uint32_t ain, int epi, long *steps_taken, const uint16_t *plane_in = nullptr,
                const uint8_t *row_in_plane = nullptr, uint16_t *plane_out = nullptr) {
   const int NB = (n + 31) / 32, nb32 = NB * 32;
@@ -30,6 +111,16 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
   const uint32_t dmax = q16_dmax(a), nlim = a * dmax * dmax;
   uint32_t kmax = 0;
   while ((uint64_t)(kmax + 1) * (kmax + 1) * ain <= nlim && kmax < 65534u) ++kmax;
+  // the wide form's range (edt_colq16.hip: launch_column_pass_q16)
+  const uint32_t dw = g_no_wide ? 0u : q16_dmax_wide(a, q);
+  const uint64_t nw = (uint64_t)a * dw * dw;
+  const uint32_t dmaxw = nw > nlim ? dw : dmax, nlimw = nw > nlim ? (uint32_t)nw : nlim;
+  uint32_t kmaxw = kmax;
+  while ((uint64_t)(kmaxw + 1) * (kmaxw + 1) * ain <= nlimw && kmaxw < 65534u) ++kmaxw;
+  const float fw = (float)nlimw * q;
+  uint32_t fwmax_bits;
+  memcpy(&fwmax_bits, &fw, sizeof(fw));
+  bool over = false;
   std::vector<uint32_t> img((size_t)(nb32 + 2 * kPad) * kRowWords, 0xFFFFFFFFu);
   std::vector<uint32_t> rsp((size_t)NB * 32, 0), lohi((size_t)NB * 32, 0), bm(16 * 6, 0);
   bool bad = false;
@@ -45,10 +136,11 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
       else if (col < cols_left) {
         if (plane_in && row_in_plane[row]) {  // (mixed input: this row of the tile is in the 16-bit plane)
           v = plane_in[(int64_t)row * sx + x0 + col];
-          if (v > nlim) bad = true;
+          if (v > nlim) over = true;
         } else if (codes) {
           const uint32_t k = codes[(int64_t)row * sx + x0 + col];
-          if (k > kmax) bad = true;
+          if (k > kmax) over = true;
+          if (k > kmaxw) bad = true;
           v = (uint32_t)(uint16_t)((uint16_t)(k * k) * (uint16_t)ain);  // (wraps like the packed multiply; unused if bad)
         } else {
           const float f = Fin[(int64_t)row * sx + x0 + col];
@@ -56,7 +148,11 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
           const float tq = fminf(f * (1.0f / q), flim);
           const uint32_t u = (uint32_t)(tq + 0.5f);
           const float e = fmaf(-(float)u, q, f);
-          if (!(fabsf(e) == 0.0f) || u > nlim) bad = true;
+          if (u > nlim) {  // (the conversion was clamped: the wide form's conversion gives the verdict)
+            over = true;
+            uint32_t uw;
+            if (!wide_value(f, q, 1.0f / q, nlimw, fwmax_bits, uw)) bad = true;
+          } else if (!(fabsf(e) == 0.0f)) bad = true;
           v = u & 0xFFFFu;
         }
       }
@@ -65,14 +161,20 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
   for (int band = 0; band < NB; ++band)
     for (int col = 0; col < 32; ++col)
       rsp[(size_t)band * 32 + col] = col < cols_left ? rsbits[(size_t)band * sx + x0 + col] : 0u;
-  if (bad) {
+  const bool go_wide = S == 1 && !bad && over && nlimw > nlim;
+  if (go_wide) {
+    if constexpr (S == 1)
+      tile_pass_wide<BB>(Fin, codes, rsbits, out, sx, n, x0, q, a, ain, epi, plane_in, row_in_plane, dmaxw, nlimw, fwmax_bits);
+    return 2;
+  }
+  if (bad || over) {
     // mixed input: the rows the tile has in the plane become fp32 values (the fp32 kernel reads F)
     if (plane_in)
       for (int row = 0; row < n; ++row)
         if (row_in_plane[row])
           for (int col = 0; col < 32 && col < cols_left; ++col)
             out[(int64_t)row * sx + x0 + col] = (float)plane_in[(int64_t)row * sx + x0 + col] * q;
-    return false;
+    return 0;
   }
   // ---- scans + breaks (phase 1) ----
   uint16_t *lohi16 = reinterpret_cast<uint16_t *>(lohi.data());
@@ -132,10 +234,13 @@ bool tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, 
         }
       }
     }
-  return true;
+  return 1;
 }
 
 }  // namespace
+
+// (tests: the 16-bit form only, as in round 4)
+extern "C" void q16_emul_set_no_wide(int v) { g_no_wide = v != 0; }
 
 // labels [n][sx] uint32 (the run structure along the scan axis), Fin [n][sx] fp32 or codes [n][sx] u16 (exactly one of
 // them), out [n][sx].  tile_ok[i] = 1 if x-tile i qualified (and was written).  Returns the number of tiles that did.
@@ -151,9 +256,9 @@ extern "C" int q16_emul_column_pass(const uint32_t *labels, const float *Fin, co
     }
   int ok = 0;
   for (int64_t x0 = 0, i = 0; x0 < sx; x0 += 32, ++i) {
-    const bool r = bb ? tile_pass<true>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr)
+    const int r = bb ? tile_pass<true>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr)
                       : tile_pass<false>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr);
-    tile_ok[i] = r ? 1 : 0;
+    tile_ok[i] = (uint8_t)r;
     ok += r ? 1 : 0;
   }
   return ok;
@@ -174,9 +279,9 @@ extern "C" int q16_emul_column_pass_plane(const uint32_t *labels, const float *F
     }
   int ok = 0;
   for (int64_t x0 = 0, i = 0; x0 < sx; x0 += 32, ++i) {
-    const bool r = bb ? tile_pass<true>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr, plane_in, row_in_plane, plane_out)
+    const int r = bb ? tile_pass<true>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr, plane_in, row_in_plane, plane_out)
                       : tile_pass<false>(Fin, codes, rs.data(), out, sx, (int)n, x0, q, a, ain, epi, nullptr, plane_in, row_in_plane, plane_out);
-    tile_ok[i] = r ? 1 : 0;
+    tile_ok[i] = (uint8_t)r;
     ok += r ? 1 : 0;
   }
   return ok;
@@ -195,9 +300,9 @@ extern "C" int q16_emul_column_pass_even(const uint32_t *labels, const float *Fi
     }
   int ok = 0;
   for (int64_t x0 = 0, i = 0; x0 < sx; x0 += 32, ++i) {
-    const bool r = bb ? tile_pass<true, 2>(Fin, nullptr, rs.data(), out, sx, (int)n, x0, q, a, 1u, epi, nullptr)
+    const int r = bb ? tile_pass<true, 2>(Fin, nullptr, rs.data(), out, sx, (int)n, x0, q, a, 1u, epi, nullptr)
                       : tile_pass<false, 2>(Fin, nullptr, rs.data(), out, sx, (int)n, x0, q, a, 1u, epi, nullptr);
-    tile_ok[i] = r ? 1 : 0;
+    tile_ok[i] = (uint8_t)r;
     ok += r ? 1 : 0;
   }
   return ok;

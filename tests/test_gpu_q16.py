@@ -12,7 +12,8 @@ from synth import blocky_labels, voronoi_labels
 
 pytestmark = pytest.mark.gpu
 
-MODES = [(0, "q16 + plane"), (0x10000000, "q16, fp32 between Y and Z"), (0x8000000, "fp32 kernels")]
+MODES = [(0, "q16 + plane"), (0x10000000, "q16, fp32 between Y and Z"), (0x8000000, "fp32 kernels"),
+         (0x20000000, "q16 without the wide form: tiles beyond 16 bits on the fp32 kernel, every list launched")]
 
 
 def run_modes(edt_gpu, lab, an, bb):
@@ -58,6 +59,39 @@ def test_q16_deep_objects_leave_the_16_bit_range(edt_gpu, oracle_port):
     want = oracle_port.edtsq(lab2, (1, 1, 1), False)
     for got, (_, name) in zip(run_modes(edt_gpu, lab2, (1, 1, 1), False), MODES):
         assert np.array_equal(got, want), name
+
+
+WIDE_SHAPES = [(640, 130, 140), (1100, 130, 100), (560, 520, 130), (2048, 130, 132), (600, 1024, 36), (640, 40, 1024),
+               (532, 260, 100), (528, 130, 100)]
+
+
+@pytest.mark.parametrize("shape", WIDE_SHAPES)
+def test_q16_wide_form(edt_gpu, oracle_port, shape):
+    """Tiles holding values beyond 16 bits -- the middle of rows of more than 510 voxels, objects deeper than ~255 voxels -- are
+    worked on by the integer kernel itself as two half-tiles of 16 columns with 32-bit lanes (csrc/edt_colq16.hip, go_wide):
+    against the oracle; against the same library without the wide form (0x20000000), with fp32 values between the passes
+    (0x10000000), with the fp32 form of pass X (0x100000: the Y pass reads fp32 values) and on the fp32 kernels.  Shapes: row
+    lengths that end in a half tile or a quarter of one, 1024-row axes (workgroups of 512 threads), deep multi-label cells."""
+    from edt import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(sum(shape))
+    labs = [np.ones(shape, dtype=np.uint32, order="F"),
+            np.asfortranarray(blocky_labels(shape, nlabels=3, zero_frac=0.0, block=int(rng.integers(270, 420)), rng=rng).astype(np.uint32))]
+    labs[1][rng.random(shape) < 0.0002] = 0
+    combos = (((1, 1, 1), True), ((6, 6, 30), True), ((1, 1, 1), False), ((30, 6, 6), True), ((0.5, 0.5, 1.0), True))
+    if shape[0] * shape[1] * shape[2] > 15_000_000:
+        combos = combos[1:3]  # (the oracle's time on the larger volumes)
+    for lab in labs:
+        for an, bb in combos:
+            want = oracle_port.edtsq(lab, an, bb)
+            try:
+                for mode in (0, 0x20000000, 0x10000000, 0x100000, 0x8000000):
+                    lib.edt_hip_set_debug_mode(mode)
+                    got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
+                    assert np.array_equal(got, want), (shape, an, bb, hex(mode))
+            finally:
+                lib.edt_hip_set_debug_mode(0)
+            assert np.array_equal(edt_gpu.edt(lab, anisotropy=an, black_border=bb), np.sqrt(want)), (shape, an, bb, "sqrt")
 
 
 def test_q16_two_dimensional_and_stacks(edt_gpu, oracle_port):

@@ -35,7 +35,21 @@ def q16():
     lib = ctypes.CDLL(so)
     lib.q16_emul_column_pass.restype = ctypes.c_int
     lib.q16_emul_quantum.restype = ctypes.c_int
+    lib.q16_emul_set_no_wide(0)
     return lib
+
+
+def wide_limit(a, q):
+    """largest N of the wide form (edt_colq16_lane.h: q16_dmax_wide): N * odd(q) < 2^24, N <= a * d^2 for a d <= 2047"""
+    m, _ = np.frexp(np.float64(q))
+    m = int(m * (1 << 24))
+    while m % 2 == 0:
+        m //= 2
+    cap = ((1 << 24) - 1) // m
+    d = 1
+    while d < 2047 and a * (d + 1) * (d + 1) <= cap:
+        d += 1
+    return a * d * d if a * d * d <= cap else 0
 
 
 def quantum(lib, w):
@@ -59,7 +73,7 @@ def column_pass(lib, labels_yx, f_yx, codes_yx, q, a, ain, bb, epi):
                              out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(sx), ctypes.c_int64(n),
                              ctypes.c_float(q), ctypes.c_uint32(a), ctypes.c_uint32(ain), ctypes.c_int(int(bb)),
                              ctypes.c_int(epi), ok.ctypes.data_as(ctypes.c_void_p))
-    return out, ok.astype(bool)
+    return out, ok   # per x-tile: 0 = handed to the fp32 kernel, 1 = 16-bit form, 2 = wide form (two half-tiles, 32-bit lanes)
 
 
 def x_pass(oracle, labels_yx, wx, bb):
@@ -116,10 +130,12 @@ def test_q16_column_pass_matches_oracle(q16, oracle_port, n, sx, kind):
                         assert np.array_equal(got_s[:, sl], np.sqrt(want[:, sl])), (n, sx, kind, wx, wy, bb, form, i, "sqrt")
                     else:
                         assert (got[:, sl] == -1.0).all(), "a refused tile was written"
-                        # a refusal has a reason: a value beyond the tile limit (rows without a boundary included)
+                        # a refusal has a reason: a value beyond the tile limit -- of the wide form, where there is one -- (rows
+                        # without a boundary included)
                         dmax = int(np.floor(np.sqrt(65534 / a[1])))
-                        assert (f1[:, sl].astype(np.float64) / q).max() > a[1] * dmax * dmax or \
-                            (codes[:, sl].astype(np.int64) ** 2 * a[0]).max() > a[1] * dmax * dmax
+                        lim = max(a[1] * dmax * dmax, wide_limit(a[1], q))
+                        assert (f1[:, sl].astype(np.float64) / q).max() > lim or \
+                            (codes[:, sl].astype(np.int64) ** 2 * a[0]).max() > lim
                 # (without a black border a row inside one label has no boundary at all: FLT_MAX, the tile is refused)
                 if bb and (kind in ("blocky", "noise", "cells") or (kind == "membrane" and n <= 512)) and wx <= 6.0:
                     assert tiles.any(), (n, sx, kind, wx, wy, bb, form)
@@ -130,12 +146,63 @@ def test_q16_refuses_values_off_the_quantum_grid(q16, oracle_port):
     lab = make_labels(128, 64, "cells", rng)
     f1, _ = x_pass(oracle_port, lab, 1.0, True)
     f1[40, 5] = np.float32(2.5)           # not a multiple of q = 1
-    f1[90, 40] = np.float32(70000.0)      # beyond 16 bits
+    f1[90, 40] = np.float32(70000.0)      # beyond 16 bits: the wide form
+    f1[91, 41] = np.float32(70000.5)      # ... and off the grid
     _, tiles = column_pass(q16, lab, f1, None, 1.0, 1, 1, True, 0)
-    assert list(tiles) == [False, False]
+    assert list(tiles) == [0, 0]
     f1[40, 5] = np.float32(2.0)
+    f1[91, 41] = np.float32(2047 ** 2 + 1)    # beyond the wide form (a = 1: N <= 2047^2; never more than 2^24 - 1)
     _, tiles = column_pass(q16, lab, f1, None, 1.0, 1, 1, True, 0)
-    assert list(tiles) == [True, False]
+    assert list(tiles) == [1, 0]
+    f1[91, 41] = np.float32(2047 ** 2)
+    _, tiles = column_pass(q16, lab, f1, None, 1.0, 1, 1, True, 0)
+    assert list(tiles) == [1, 2]
+    q16.q16_emul_set_no_wide(1)           # (the 16-bit form alone, as in round 4)
+    _, tiles = column_pass(q16, lab, f1, None, 1.0, 1, 1, True, 0)
+    q16.q16_emul_set_no_wide(0)
+    assert list(tiles) == [1, 0]
+
+
+WIDE_CASES = [(64, 640, "ones"), (300, 1100, "ones"), (700, 600, "ones"), (520, 560, "bigcells"), (1024, 1200, "bigcells"),
+              (200, 2048, "ones"), (96, 900, "sparse")]
+
+
+@pytest.mark.parametrize("n,sx,kind", WIDE_CASES)
+def test_q16_wide_form_matches_oracle(q16, oracle_port, n, sx, kind):
+    """Tiles that hold values beyond 16 bits (the middle of rows of more than 510 voxels, objects deeper than ~255 voxels) are
+    worked on as two half-tiles with 32-bit lanes -- the same lane code (V<true>) -- instead of being handed to the fp32
+    kernel: bit-identical to the oracle, both input forms, both borders, sqrt; and they do exist in these cases."""
+    rng = np.random.default_rng(n + 7 * sx)
+    if kind == "ones":
+        lab = np.ones((n, sx), dtype=np.uint32)
+    elif kind == "bigcells":
+        lab = blocky_labels((n, sx), nlabels=3, zero_frac=0.0, block=int(rng.integers(280, 420)), rng=rng).astype(np.uint32)
+        lab[rng.random((n, sx)) < 0.0002] = 0
+    else:
+        lab = np.ones((n, sx), dtype=np.uint32)
+        lab[rng.random((n, sx)) < 0.0005] = 0
+    seen_wide = False
+    for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (30.0, 6.0), (0.5, 1.0)):
+        ok, q, a = quantum(q16, (wx, wy))
+        assert ok
+        for bb in (True, False):
+            f1, codes = x_pass(oracle_port, lab, wx, bb)
+            want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
+            for form in ("f32", "codes"):
+                for epi in (0, 2):
+                    got, tiles = column_pass(q16, lab, f1 if form == "f32" else None, codes if form == "codes" else None,
+                                             q, a[1], a[0], bb, epi)
+                    exp = np.sqrt(want) if epi else want
+                    for i, t_ok in enumerate(tiles):
+                        sl = slice(32 * i, min(sx, 32 * i + 32))
+                        if t_ok:
+                            assert np.array_equal(got[:, sl], exp[:, sl]), (n, sx, kind, wx, wy, bb, form, epi, i, int(t_ok))
+                        else:
+                            assert (got[:, sl] == -1.0).all()
+                    seen_wide |= bool((tiles == 2).any())
+                    if bb and kind == "ones" and int(codes.max()) ** 2 * a[0] <= wide_limit(a[1], q):
+                        assert tiles.all(), "a single label inside a black border leaves nothing to the fp32 kernel"
+    assert seen_wide
 
 
 @pytest.mark.parametrize("n,sx,kind", [(1024, 32, "cells"), (512, 64, "blocky"), (500, 36, "membrane"), (300, 40, "cells"),

@@ -305,7 +305,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
         }
         const int c0 = 16 * h + 4 * cgw;  // the thread's four columns inside the tile
         const bool cw_ok = c0 < cols_left;
-#pragma unroll 2
+#pragma unroll 4
         for (int row = rw; row < nb32; row += RPSW) {
           v4u v = (v4u){kInfW, kInfW, kInfW, kInfW};
           if (row < n) {
@@ -366,6 +366,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
             const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
             const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
             L.win = ((uint64_t)hi << 32) | lo;
+            L.reach = flat_reach_full(bm + cw * 6, gi);
           }
           pk best[kB];
           block_eval<BB, 1, true>(L, best);

@@ -289,6 +289,25 @@ EDT_LANE int flat_reach(uint64_t win) {
   return dlo < dhi ? dlo : dhi;
 }
 
+// The same over the WHOLE column (the wide form: its windows may be hundreds of rows long, and a flat column -- the middle
+// of a single-label volume -- must not pay for them): m = the six mask words of the column (word 0 and 5 zero, block g = bit
+// g of words 1..4), gi = the block.  No break anywhere: 1 << 20.
+EDT_LANE int flat_reach_full(const uint32_t *m, int gi) {
+  const uint64_t lo64 = ((uint64_t)m[2] << 32) | m[1], hi64 = ((uint64_t)m[4] << 32) | m[3];  // blocks 0..63, 64..127
+  const int gb = gi & 63;
+  const uint64_t own = gi < 64 ? lo64 : hi64;
+  if ((own >> gb) & 1u) return 0;
+  const uint64_t lt = gb ? own & (~0ull >> (64 - gb)) : 0ull, gt = gb < 63 ? own & (~0ull << (gb + 1)) : 0ull;
+  int below = -1, above = -1;  // nearest break block on either side
+  if (lt) below = (gi & 64) + 63 - __builtin_clzll(lt);
+  else if (gi >= 64 && lo64) below = 63 - __builtin_clzll(lo64);
+  if (gt) above = (gi & 64) + __builtin_ctzll(gt);
+  else if (gi < 64 && hi64) above = 64 + __builtin_ctzll(hi64);
+  const int dlo = below >= 0 ? 8 * (gi - below) - 7 : (1 << 20);
+  const int dhi = above >= 0 ? 8 * (above - gi - 1) : (1 << 20);
+  return dlo < dhi ? dlo : dhi;
+}
+
 // ---------------------------------------------------------------------------------------
 // One block of a lane: rows p0 .. p0+7 of the column pair cp.
 // ---------------------------------------------------------------------------------------
@@ -304,6 +323,7 @@ struct Block {
   uint32_t a;            // c_d = a * d^2
   uint32_t dmax;         // q16_dmax(a)
   uint64_t win;          // break bits around the block (flat_reach)
+  int reach;             // wide form: the flat reach over the whole column (flat_reach_full); unused otherwise
 };
 
 // S = output stride: 1 = every row of the block is evaluated; 2 = a block is 16 rows of which the even ones are evaluated (the
@@ -515,7 +535,7 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
   for (int i = 0; i < B; ++i) bmax = X::vmax(bmax, best[i]);
   // ---- flat neighbourhood: nothing within reach can improve any row of the wave's blocks ----
   {
-    uint32_t D1 = (uint32_t)flat_reach<S>(L.win) + 1u;
+    uint32_t D1 = (uint32_t)(W ? L.reach : flat_reach<S>(L.win)) + 1u;
     D1 = D1 < L.dmax + 1u ? D1 : L.dmax + 1u;
     const uint64_t cD = (uint64_t)L.a * D1 * D1;
     if (!EDT_Q16_ANY(X::subs(bmax, X::cval(cD)) != 0u)) return;

@@ -174,6 +174,7 @@ int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz
                          int to_finite, hipStream_t stream, const void *halo = nullptr, uint16_t *codes = nullptr);
 // k * w exact for every k of a row of sx voxels: the 16-bit index form (codes) is bit-identical
 bool row_codes_exact(float w, int64_t sx);
+
 }  // namespace edt_amd
 
 namespace edt_amd {

@@ -1,0 +1,28 @@
+#!/bin/bash
+# round 5, GPU session B: pass X with four voxels per lane (tests + times), the wide form with the whole-column flat reach
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_rowquad.py tests/test_gpu_index_form.py tests/test_gpu_q16.py -m gpu -x -q 2>&1 | tail -8 | tee gpurun_out/r05b_pytest.txt
+b() {  # b <tag> <cfg> [env...]
+  local tag=$1 cfg=$2; shift 2
+  env "$@" python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary --config $cfg > gpurun_out/r05b_${tag}.json 2> gpurun_out/r05b_${tag}.err
+  python - $tag <<'PY'
+import json, sys
+t = sys.argv[1]
+try:
+    d = json.load(open(f"gpurun_out/r05b_{t}.json"))
+    print(t, d["ms_per_step"], d["roofline"]["kernel_ms"], "frac32B", d["roofline"]["whole_job_frac"], d["config"]["output_verified"])
+except Exception as e:
+    print(t, "ERR", e, open(f"gpurun_out/r05b_{t}.err").read()[-800:])
+PY
+}
+b cfg2 cfg2
+b cfg2_oldx cfg2 EDT_HIP_DEBUG_MODE=0x40000000
+b cfg2_nowide cfg2 EDT_HIP_DEBUG_MODE=0x20000000
+b cfg3 cfg3
+b cfg3_oldx cfg3 EDT_HIP_DEBUG_MODE=0x40000000
+b cfg3L cfg3L
+b cfg3m cfg3m
+b cfg2_again cfg2
+./tools/gpu_session.sh prof r05b cfg2
+./tools/gpu_session.sh prof r05b cfg3

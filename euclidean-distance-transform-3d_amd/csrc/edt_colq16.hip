@@ -134,11 +134,14 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     const int band = u >> 5, col = u & 31;
     rsp[u] = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
   }
+  // (index form: the whole tile in ONE sweep of sixteen loads per thread -- nb32 <= 16 RPS: 512 rows at 256 threads, 1024 at
+  // 512: launch_q16_k)
   if constexpr (IN == kQ16InCodes) {
+    v2u kk[16];
     const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
     const pk kmaxpk = pk_both(qa.kmax), kmaxwpk = pk_both(qa.kmaxw), ainpk = pk_both(qa.ain);
-    for (int i0 = 0; i0 < nb32; i0 += RPS * 16) {
-      v2u kk[16];
+    {
+      constexpr int i0 = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = i0 + RPS * j + r_in;
@@ -303,35 +306,59 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
           const int row = t < 4 * kPad ? -kPad + (t >> 2) : nb32 + ((t - 4 * kPad) >> 2);
           *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (t & 3)) = (v4u){kInfW, kInfW, kInfW, kInfW};
         }
-        const int c0 = 16 * h + 4 * cgw;  // the thread's four columns inside the tile
-        const bool cw_ok = c0 < cols_left;
-#pragma unroll 4
-        for (int row = rw; row < nb32; row += RPSW) {
-          v4u v = (v4u){kInfW, kInfW, kInfW, kInfW};
-          if (row < n) {
-            v = (v4u){0u, 0u, 0u, 0u};
-            if (cw_ok) {
-              bool p16 = false;
-              if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
-              if constexpr (IN == kQ16InCodes) {
-                const v2u kk = *reinterpret_cast<const v2u *>(qa.codes + x0 + o * g.outer_stride + c0 + (int64_t)row * st);
-                const uint32_t k0 = kk[0] & 0xFFFFu, k1 = kk[0] >> 16, k2 = kk[1] & 0xFFFFu, k3 = kk[1] >> 16;
-                v = (v4u){k0 * k0 * qa.ain, k1 * k1 * qa.ain, k2 * k2 * qa.ain, k3 * k3 * qa.ain};
-              } else if (p16) {
-                const v2u pv = *reinterpret_cast<const v2u *>(qa.plane + x0 + o * qa.p_outer + c0 + (int64_t)row * qa.pst);
-                v = (v4u){pv[0] & 0xFFFFu, pv[0] >> 16, pv[1] & 0xFFFFu, pv[1] >> 16};
-              } else {
-                const v4f f = *reinterpret_cast<const v4f *>(F + x0 + o * g.outer_stride + c0 + (int64_t)row * st);
+        if constexpr (IN == kQ16InCodes) {
+          // the first fill's mapping (whole 64-byte row pieces), by the threads that hold this half's columns (keeping the
+          // first fill's registers alive across the verdict instead spills: 46 scratch instructions)
+          if ((cg >> 2) == h) {
+            const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
+#pragma unroll 1
+            for (int jb = 0; jb < 16; jb += 8) {  // (eight loads in flight: sixteen tip this cold path into scratch)
+              v2u kk[8];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                  uint32_t u;
-                  (void)wide_value(f[c], qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, u);  // (verified by the first fill)
-                  v[c] = u;
+              for (int j = 0; j < 8; ++j) {
+                const int row = RPS * (jb + j) + r_in;
+                kk[j] = (v2u){0u, 0u};
+                if (row < n && col_ok) kk[j] = *reinterpret_cast<const v2u *>(src + (int64_t)row * st);
+              }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int row = RPS * (jb + j) + r_in;
+                if (row < nb32) {
+                  const uint32_t k0 = kk[j][0] & 0xFFFFu, k1 = kk[j][0] >> 16, k2 = kk[j][1] & 0xFFFFu, k3 = kk[j][1] >> 16;
+                  v4u v = (v4u){k0 * k0 * qa.ain, k1 * k1 * qa.ain, k2 * k2 * qa.ain, k3 * k3 * qa.ain};
+                  if (row >= n) v = (v4u){kInfW, kInfW, kInfW, kInfW};
+                  *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (cg & 3)) = v;
                 }
               }
             }
           }
-          *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * cgw) = v;
+        } else {
+          const int c0 = 16 * h + 4 * cgw;  // the thread's four columns inside the tile
+          const bool cw_ok = c0 < cols_left;
+#pragma unroll 4
+          for (int row = rw; row < nb32; row += RPSW) {
+            v4u v = (v4u){kInfW, kInfW, kInfW, kInfW};
+            if (row < n) {
+              v = (v4u){0u, 0u, 0u, 0u};
+              if (cw_ok) {
+                bool p16 = false;
+                if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
+                if (p16) {
+                  const v2u pv = *reinterpret_cast<const v2u *>(qa.plane + x0 + o * qa.p_outer + c0 + (int64_t)row * qa.pst);
+                  v = (v4u){pv[0] & 0xFFFFu, pv[0] >> 16, pv[1] & 0xFFFFu, pv[1] >> 16};
+                } else {
+                  const v4f f = *reinterpret_cast<const v4f *>(F + x0 + o * g.outer_stride + c0 + (int64_t)row * st);
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                    uint32_t u;
+                    (void)wide_value(f[c], qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, u);  // (verified by the first fill)
+                    v[c] = u;
+                  }
+                }
+              }
+            }
+            *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * cgw) = v;
+          }
         }
         __syncthreads();
         for (int u = t; u < 16 * NB; u += T) {

@@ -497,33 +497,53 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
   const pk one = X::both(1u);
   // a run that starts at row 0 of the column has a border below it only with black_border
   const pk first0 = (BB || L.p0 > 0) ? one : X::both(kFar);
-  pk mask[NR], dlv[B];
-  {
-#define EDT_Q16_ROW_UP(J)                                                   \
-    mask[J] = X::template bitmask<J>(starts);                               \
-    EDT_Q16_OPAQUE(mask[J]);                                                \
-    dl = pk_sel(mask[J], J == 0 ? first0 : one, X::add(dl, one));           \
-    if ((J) % S == 0) dlv[(J) / S] = dl;
-    EDT_Q16_ROW_UP(0) EDT_Q16_ROW_UP(1) EDT_Q16_ROW_UP(2) EDT_Q16_ROW_UP(3)
-    EDT_Q16_ROW_UP(4) EDT_Q16_ROW_UP(5) EDT_Q16_ROW_UP(6) EDT_Q16_ROW_UP(7)
-    if constexpr (S == 2) {
-      EDT_Q16_ROW_UP(8) EDT_Q16_ROW_UP(9) EDT_Q16_ROW_UP(10) EDT_Q16_ROW_UP(11)
-      EDT_Q16_ROW_UP(12) EDT_Q16_ROW_UP(13) EDT_Q16_ROW_UP(14) EDT_Q16_ROW_UP(15)
-    }
-#undef EDT_Q16_ROW_UP
-  }
   const pk dmaxpk = X::both(L.dmax), apk = X::both(L.a);
   pk bmax = 0;
-  EDT_Q16_UNROLL
-  for (int j = NR - 1; j >= 0; --j) {
-    dr = X::add(dr, one);
-    if (j % S == 0) {
-      const pk dm = X::vmin(X::vmin(dlv[j / S], dr), dmaxpk);
-      // a * min(d, dmax)^2 fits the range; a tile on this path holds no value above a * dmax^2, so the clamp changes no minimum
-      const pk bord = X::mul(X::mul(dm, dm), apk);
-      best[j / S] = X::vmin(w[K + j], bord);
+  // Two wave-uniform short cuts (round 5; the general form below costs ~100 of the ~250 instructions a block takes before
+  // its window).  No block of the wave holds a run start: the border distances are linear in the row, dl + j + 1 below
+  // and dr + NR - j above.  And if no border is nearer than dmax to any of those rows either, the border parabolas are at
+  // least a * dmax^2 >= every value of the tile: B_p = N.  (A block that reaches beyond the column's last row has a
+  // modular "negative" dr: it takes the linear form, whose additions put that right.)
+  const bool has_start = EDT_Q16_ANY(starts != 0u);
+  if (!has_start) {
+    const bool ends_here = L.p0 + NR > L.n;
+    if (!EDT_Q16_ANY(ends_here || (X::subs(dmaxpk, dl) | X::subs(dmaxpk, dr)) != 0u)) {
+      EDT_Q16_UNROLL
+      for (int i = 0; i < B; ++i) best[i] = w[K + S * i];
+    } else {
+      EDT_Q16_UNROLL
+      for (int j = 0; j < NR; j += S) {
+        const pk dm = X::vmin(X::vmin(X::add(dl, X::both((uint32_t)(j + 1))), X::add(dr, X::both((uint32_t)(NR - j)))), dmaxpk);
+        best[j / S] = X::vmin(w[K + j], X::mul(X::mul(dm, dm), apk));
+      }
     }
-    dr = dr & ~mask[j];  // (a set bit is a real row: the border site of the rows below it)
+  } else {
+    pk mask[NR], dlv[B];
+    {
+  #define EDT_Q16_ROW_UP(J)                                                   \
+      mask[J] = X::template bitmask<J>(starts);                               \
+      EDT_Q16_OPAQUE(mask[J]);                                                \
+      dl = pk_sel(mask[J], J == 0 ? first0 : one, X::add(dl, one));           \
+      if ((J) % S == 0) dlv[(J) / S] = dl;
+      EDT_Q16_ROW_UP(0) EDT_Q16_ROW_UP(1) EDT_Q16_ROW_UP(2) EDT_Q16_ROW_UP(3)
+      EDT_Q16_ROW_UP(4) EDT_Q16_ROW_UP(5) EDT_Q16_ROW_UP(6) EDT_Q16_ROW_UP(7)
+      if constexpr (S == 2) {
+        EDT_Q16_ROW_UP(8) EDT_Q16_ROW_UP(9) EDT_Q16_ROW_UP(10) EDT_Q16_ROW_UP(11)
+        EDT_Q16_ROW_UP(12) EDT_Q16_ROW_UP(13) EDT_Q16_ROW_UP(14) EDT_Q16_ROW_UP(15)
+      }
+  #undef EDT_Q16_ROW_UP
+    }
+    EDT_Q16_UNROLL
+    for (int j = NR - 1; j >= 0; --j) {
+      dr = X::add(dr, one);
+      if (j % S == 0) {
+        const pk dm = X::vmin(X::vmin(dlv[j / S], dr), dmaxpk);
+        // a * min(d, dmax)^2 fits the range; a tile on this path holds no value above a * dmax^2, so the clamp changes no minimum
+        const pk bord = X::mul(X::mul(dm, dm), apk);
+        best[j / S] = X::vmin(w[K + j], bord);
+      }
+      dr = dr & ~mask[j];  // (a set bit is a real row: the border site of the rows below it)
+    }
   }
   // rows that complete the last band are not rows of the column
   if (L.p0 + NR > L.n) {

@@ -40,8 +40,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r04"    # profiles/<tag>_traffic.json holds the PMC-derived HBM bytes per launch
+PROFILE_TAG = "r05"    # profiles/<tag>_traffic.json holds the PMC-derived HBM bytes per launch
 HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming kernel reaches on this part (MI355X_MICROARCH.md)
+VG_NATIVE_MODEL_BPV = 42  # bytes per voxel the native voxel-graph form has to move (voxel_graph_secondary)
+WARM_MS = 60.0         # untimed steps run for at least this long before the `--warmup` ones (steady clocks)
 
 
 def algorithmic_bytes_per_voxel(label_bytes, fused=False):
@@ -233,15 +235,34 @@ class DeviceRun:
 
     def measure(self, steps, warmup, generic=False):
         from edt import device
+        # Warm-up by TIME, then by count: a handful of sub-millisecond steps does not bring the part to its steady clocks
+        # (round 4: the driver's 20-step figure sat 4 % above the 1000-step one).  At least WARM_MS of untimed steps, then
+        # the `warmup` steps of the contract.
+        t0 = time.perf_counter()
+        extra = 0
+        while (time.perf_counter() - t0) * 1e3 < WARM_MS:
+            for _ in range(8):
+                self.step(generic)
+            torch.cuda.synchronize()
+            extra += 8
         for _ in range(warmup):
             self.step(generic)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step(generic)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        ms = elapsed / steps * 1e3
+        # EXACTLY `steps` timed steps, as at most five batches between synchronisations: the figure is the MEDIAN of the
+        # batch means (a stray batch -- another process's burst, a clock dip -- does not move it), the mean is kept beside it
+        nb = max(1, min(5, steps))
+        sizes = [steps // nb + (1 if i < steps % nb else 0) for i in range(nb)]
+        batch_ms = []
+        for k in sizes:
+            t0 = time.perf_counter()
+            for _ in range(k):
+                self.step(generic)
+            torch.cuda.synchronize()
+            batch_ms.append((time.perf_counter() - t0) / k * 1e3)
+        ms = float(np.median(batch_ms))
+        self.timing = {"statistic": "median of the batch means", "batches": sizes, "batch_ms": [round(b, 4) for b in batch_ms],
+                       "mean_ms": round(float(np.dot(batch_ms, sizes) / steps), 4),
+                       "untimed_steps_before": extra + warmup, "warm_ms": WARM_MS}
         # per-kernel durations with hipEvents on the launch stream (separate profiled steps)
         device.set_profiling(True)
         acc = {}
@@ -282,6 +303,13 @@ def voxel_graph_secondary(n, dev, steps, warmup, ref=None):
     entry = {"config": "cfg5", "workload": f"{n}^3 uint8 blobs + voxel graph (1 % of the +x links cut), anisotropy (6, 6, 30), "
                                            "black_border=True, device-resident in/out, 1 GPU",
              "ms_per_step": round(ms, 4), "mvox_per_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1), "output_verified": None}
+    # A byte model for the NATIVE form (SURVEY 8(d)'s 202 B/voxel prices the reference's 8x up-sampled volume, which no longer
+    # exists here): labels + graph read once by pass X (2 B) and once by each of the two bit-plane kernels (4 B); pass X
+    # writes the even-X cells of the four doubled rows of a voxel row as 16-bit indices (8 B); pass Y reads them (8 B) and
+    # writes its even rows compactly as fp32 (8 B); pass Z reads those (8 B) and writes the result (4 B): 42 B per voxel.
+    model = VG_NATIVE_MODEL_BPV * n ** 3 / (ms * 1e-3) / 1e9
+    entry.update({"model_bytes_per_voxel": VG_NATIVE_MODEL_BPV, "model_GBs": round(model, 1), "model_frac": round(model / HBM_PEAK_GBS, 4),
+                  "model_note": "native even-cell form: X 2 + 8, bit planes 2 x 2, Y 8 + 8, Z 8 + 4 bytes per voxel"})
     if n == 512:
         entry.update(real_traffic_fields(ms, {}, None, "cfg5"))
     if ref is not None and os.environ.get("EDT_BENCH_VERIFY", "1") != "0":
@@ -431,6 +459,26 @@ def sharded_main(args, rank, world, dev):
     depth_timed, depth, lanes[:] = depth, 1, [None]
     plans[0] = last_plan   # (`out` is its result)
     plan = last_plan
+    # The other reading of the same job, in the same line: ONE volume at a time -- one plan, one stream, nothing of
+    # step i + 1 before step i has finished -- i.e. the latency of a step, comparable with the --gpus 1 line and with the
+    # SCALE records of earlier rounds; `value` / `ms_per_step` above are throughput with `steps_in_flight` steps in flight.
+    serial = None
+    if depth_timed > 1:
+        n1 = max(3, min(args.steps, 50))
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            out = step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        e1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(e1, op=dist.ReduceOp.MAX)
+        serial = {"steps_in_flight": 1, "steps": n1, "ms_per_step": round(float(e1.item()) / n1 * 1e3, 4)}
     # per-kernel durations of one more step (hipEvents inside the library, this rank's stream)
     from edt import device
     acc = {}
@@ -552,6 +600,12 @@ def sharded_main(args, rank, world, dev):
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "reading": reading,
+            # both readings of the job: `value` / `ms_per_step` = the first (what the K timed steps ran as)
+            "readings": [{"steps_in_flight": depth_timed, "steps": args.steps, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "mvox_per_s": value, "what": "throughput: independent transforms pipelined over plans / streams"
+                          if depth_timed > 1 else "one volume at a time (latency = throughput)"}]
+                        + ([dict(serial, mvox_per_s=round(vox / (serial["ms_per_step"] * 1e-3) / 1e6, 1),
+                                 what="latency: one volume at a time, one plan, one stream")] if serial else []),
             "single_gpu_same_workload": same_n1,
             "scaling_efficiency": eff,
             "dtype": DTYPE, "data": "synthetic",
@@ -813,6 +867,9 @@ def main():
     else:
         ok = None
     head_lab, head_an, head_bb = head.lab_np, head.an, head.bb
+    head_timing = getattr(head, "timing", None)
+    # (kept on the host for the comparison with the compiled reference's output on the same volume, below)
+    head_out = head.out.cpu().numpy().reshape(-1) if (not args.no_cpu_baseline and head_lab is not None) else None
 
     # numpy in -> numpy out through the host-buffer entry point (C ABI, PCIe both ways); reported beside the
     # device-resident figure, never as `value`
@@ -837,12 +894,13 @@ def main():
     if not args.no_secondary and args.config == "cfg2" and not args.generic:
         del head
         torch.cuda.empty_cache()
-        what = {"cfg3": "2000 labels (up-sampled x4: cells ~34 voxels)", "cfg3m": "2000 labels + 5 % zero membranes",
+        what = {"cfg1": "all-ones labels (BASELINE configs[0]: the reference's own CPU-runnable case, timed beside it with parallel=1)",
+                "cfg3": "2000 labels (up-sampled x4: cells ~34 voxels)", "cfg3m": "2000 labels + 5 % zero membranes",
                 "cfg3f": "the 2000 labels of cfg3 at voxel sizes whose multiples are not exact in fp32",
                 "cfg3L": "~60 full-resolution Voronoi cells (~130 voxels across)", "cfg3La": "~60 full-resolution cells",
                 "cfg3M": "~500 full-resolution Voronoi cells (~65 voxels across)", "cfg3Ma": "~500 full-resolution cells",
                 "cfg4": "the 1024^3 segmentation of configs[3] (16 000 seeds) on ONE GPU"}
-        todo = [("cfg3", n), ("cfg3f", n), ("cfg3m", n), ("cfg3L", n), ("cfg3La", n), ("cfg3M", n), ("cfg3Ma", n), ("cfg4", 2 * n)]
+        todo = [("cfg1", n), ("cfg3", n), ("cfg3f", n), ("cfg3m", n), ("cfg3L", n), ("cfg3La", n), ("cfg3M", n), ("cfg3Ma", n), ("cfg4", 2 * n)]
         only = [c for c in args.secondary.split(",") if c]
         verify = os.environ.get("EDT_BENCH_VERIFY", "1") != "0"
         for name, size in todo:
@@ -852,13 +910,15 @@ def main():
                 run = DeviceRun(name, size, dev)
                 s, kern, _ = run.measure(max(5, min(args.steps, 200) // 2) if size > n else min(args.steps, 400), args.warmup)
                 entry = {"config": name,
-                         "workload": f"{size}^3 uint32 multi-label: {what[name]}, anisotropy {tuple(run.an)}, "
-                                     f"black_border={run.bb}, device-resident in/out, 1 GPU", **s}
+                         "workload": f"{size}^3 uint32 {'single-label' if name == 'cfg1' else 'multi-label'}: {what[name]}, "
+                                     f"anisotropy {tuple(run.an)}, black_border={run.bb}, device-resident in/out, 1 GPU", **s}
                 entry.update(real_traffic_fields(s["ms_per_step"], kern, None, name))
                 entry["output_verified"] = None
                 if lib is not None and verify:
                     # the timed output, bit for bit against the CPU reference on the same volume (all threads), timed as well
-                    res, want = time_reference(lib, kind, run.host_labels(), tuple(run.an), run.bb, threads[-1:])
+                    # (configs[0] asks for the reference with parallel=1: both thread counts there)
+                    res, want = time_reference(lib, kind, run.host_labels(), tuple(run.an), run.bb,
+                                               threads if name == "cfg1" else threads[-1:])
                     got = run.out.cpu().numpy().reshape(-1)
                     entry["output_verified"] = bool(np.array_equal(got, want))
                     cpu_secondary[name] = {f"{p} thread(s)": round(v, 1) for p, v in res.items()}
@@ -890,6 +950,8 @@ def main():
                    "path": "generic" if args.generic else "default", "output_verified": ok},
         "roofline": roofline,
     }
+    if head_timing is not None:
+        result["timing"] = head_timing
     if end_to_end is not None:
         result["end_to_end"] = end_to_end
     if secondary:
@@ -900,7 +962,15 @@ def main():
         else:
             m = min(n, 512)
             lab = head_lab if head_lab is not None and head_lab.shape[0] == m else np.ones((m, m, m), np.uint32, order="F")
-            res, _ = time_reference(lib, kind, lab, tuple(head_an), head_bb, threads)
+            res, want = time_reference(lib, kind, lab, tuple(head_an), head_bb, threads)
+            if head_out is not None and lab is head_lab and want is not None:
+                # the timed headline output, bit for bit against what the CPU reference just computed on the very same volume
+                same = bool(np.array_equal(head_out, np.asarray(want).reshape(-1)))
+                result["config"]["output_verified_against_reference"] = same
+                result["config"]["output_verified"] = bool(result["config"]["output_verified"] is not False and same)
+                result["config"]["verified_by"] = ("closed form of the box + " if ok is not None else "") + (
+                    "the compiled CPU reference on the whole volume" if kind == "reference" else "the CPU restatement (oracle port)")
+            del want
             top = max(res, key=lambda k: res[k])
             result["cpu_baseline"] = {
                 # cores: the physical cores the fastest figure ran on (all of them when every hardware thread was used);

@@ -40,3 +40,48 @@ def test_column_kernels_have_no_scratch_in_their_bodies(scans, cw):
         assert f["vgprs"] is None or f["vgprs"] <= 128, f
     # (no non-inlined device functions in the default build: a call would push callee-saved registers through scratch)
     assert all(f["kernel"] for f in funcs), [f["name"] for f in funcs if not f["kernel"]]
+
+
+def test_integer_column_kernels_have_no_scratch_and_four_waves_per_simd():
+    """csrc/edt_colq16.hip with the wide form inlined (round 5): every instantiation free of scratch instructions, at most
+    128 VGPRs (four workgroups of four waves per CU is what the 39 KiB image was sized for)."""
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    import q16_resources
+    funcs = q16_resources.scan()
+    assert len(funcs) >= 30
+    for f in funcs:
+        assert f["scratch_ops"] == 0, f
+        assert f["vgprs"] <= 128 and (f["occupancy"] is None or f["occupancy"] >= 4), f
+
+
+def test_traffic_table_names_kernels_of_this_build():
+    """bench.py prices the kernels' real traffic with a table from a committed profile (profiles/<tag>_traffic.json: PMC
+    passes of a profiling run, not re-measured in the bench run).  Nothing used to fail when the kernels changed and the
+    table did not: every kernel the table names must be a kernel of the library as built now --
+    a renamed / re-templated / removed kernel means the profile has to be taken again."""
+    import json
+    import re
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    lib = os.path.join(ROOT, "euclidean-distance-transform-3d_amd", "lib", "libedt_hip.so")
+    if not os.path.exists(lib) or shutil.which("c++filt") is None or shutil.which("strings") is None:
+        pytest.skip("library not built / binutils missing")
+    table = os.path.join(ROOT, "profiles", f"{bench.PROFILE_TAG}_traffic.json")
+    if not os.path.exists(table):
+        pytest.skip(f"{table}: this round's profile has not been taken yet (bench.py then reports no real_* fields)")
+    mangled = sorted(set(re.findall(r"_ZN7edt_amd\w+", subprocess.run(["strings", "-n", "16", lib], capture_output=True, text=True).stdout)))
+    dem = subprocess.run(["c++filt"], input="\n".join(mangled), capture_output=True, text=True).stdout.splitlines()
+    have = {re.sub(r"\(.*", "", d.replace("(anonymous namespace)::", "")).replace("void ", "").replace("edt_amd::", "") for d in dem}
+    blob = json.load(open(table))
+    named = set()
+    for cfg, passes in blob.items():
+        if not isinstance(passes, dict):
+            continue
+        for p, entry in passes.items():
+            if isinstance(entry, dict):
+                named.update(k for k in entry.get("kernels", []) if not k.startswith("__amd_rocclr"))
+    assert named, "the table names no kernel"
+    missing = sorted(k for k in named if k not in have)
+    assert not missing, f"{table} names kernels this build does not have (profile again): {missing}"

@@ -70,8 +70,8 @@ namespace {
 
 __host__ __device__ constexpr int q16_lds_words(int NB) {
   // image (NB bands of 32 rows + 2 kPad rows, 16 words each) + run-start plane + lo/hi plane + break masks (16 pairs x 6
-  // words) + flags + granule codes (a byte per block of 8 rows and column pair)
-  return (NB * 32 + 2 * edt_q16::kPad) * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 8 + NB * 16;
+  // words) + flags
+  return (NB * 32 + 2 * edt_q16::kPad) * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 8;
 }
 
 }  // namespace
@@ -98,7 +98,6 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   uint32_t *lohi = rsp + NB * 32;                          // [NB][32]: (lo_in + 1) | (hi_out + 1) << 16
   uint32_t *bm = lohi + NB * 32;                           // [16][6]: break bits of the pair's blocks, words 1..4 (0, 5: zero)
   uint32_t *flags = bm + 16 * 6;                           // [T / 64]: per wave, "the tile does not qualify"
-  uint8_t *gmin = reinterpret_cast<uint8_t *>(flags + 8);  // [4 NB][16]: granule codes (edt_colq16_lane.h: band_breaks)
   const int t = (int)threadIdx.x;
 
   // ---- tile -> (x-tile, outer index): the XCD-aware order of edt_colwave_kernel.h ----
@@ -365,8 +364,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
         for (int u = t; u < 16 * NB; u += T) {
           const int c = u & 15, band = u >> 4;
           const int valid = n - 32 * band;
-          const uint32_t bits = band_breaks<true>(img + (32 * band + kPad) * kRowWords + c, qa.a, band == 0, valid < 32 ? valid : 32,
-                                                  gmin + band * 64 + c, 16);
+          const uint32_t bits = band_breaks<true>(img + (32 * band + kPad) * kRowWords + c, qa.a, band == 0, valid < 32 ? valid : 32);
           if (bits) atomicOr(&bm[c * 6 + 1 + (band >> 3)], bits << (4 * (band & 7)));
         }
         __syncthreads();
@@ -397,7 +395,6 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
             L.win = ((uint64_t)hi << 32) | lo;
             L.reach = flat_reach_full(bm + cw * 6, gi);
           }
-          L.gmin = gmin;
           pk best[kB];
           block_eval<BB, 1, true>(L, best);
           float *dst;
@@ -438,8 +435,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     for (int u = t; u < 16 * NB; u += T) {
       const int cp = u & 15, band = u >> 4;
       const int valid = n - 32 * band;
-      const uint32_t bits = band_breaks(img + (32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32,
-                                        S == 1 ? gmin + band * 64 + cp : nullptr, 16);
+      const uint32_t bits = band_breaks(img + (32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32);
       if (bits) atomicOr(&bm[cp * 6 + 1 + (band >> 3)], bits << (4 * (band & 7)));
     }
   }
@@ -485,7 +481,6 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
       L.win = ((uint64_t)hi << 32) | lo;
     }
-    L.gmin = gmin;
     pk best[kB];
     block_eval<BB, S>(L, best);
     // ---- results: (float)N * q is exact; sqrt of the last pass (src/edt.hpp:599-601) ----

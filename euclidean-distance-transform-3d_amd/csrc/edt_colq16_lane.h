@@ -254,33 +254,24 @@ EDT_LANE bool wide_value(float f, float q, float rq, uint32_t nlimw, uint32_t fw
 // ---------------------------------------------------------------------------------------
 // band0: word of (first row of the band, pair).  top: the band is the column's first (no link into its first row).
 // valid: rows of the band that are rows of the column (32 but for the last band; the +inf rows after them are no links).
-// gcode (optional): four bytes, one per block of the band -- floor(sqrt(min(m, 65535))) of the smallest value m the block
-// holds in either column: code^2 is a lower bound of every value of the granule, what the far windows test before they look
-// at its rows (Steps::run).  (Rows that complete the last band repeat the row before them: the bound only gets lower.)
 template <bool W = false>
-EDT_LANE uint32_t band_breaks(const uint32_t *band0, pk apk, bool top, int valid, uint8_t *gcode = nullptr, int gstride = 0) {
+EDT_LANE uint32_t band_breaks(const uint32_t *band0, pk apk, bool top, int valid) {
   uint32_t bits = 0;
   pk y = top ? band0[0] : band0[-kRowWords];
   pk ty = V<W>::adds(y, apk);
   EDT_Q16_UNROLL
   for (int k = 0; k < 4; ++k) {
-    pk acc = 0, mn = V<W>::kInfWord;
+    pk acc = 0;
     EDT_Q16_UNROLL
     for (int j = 0; j < 8; ++j) {
       pk x = band0[(8 * k + j) * kRowWords];
       if (valid < 32 && 8 * k + j >= valid) x = y;
       const pk tx = V<W>::adds(x, apk);
       acc |= V<W>::subs(x, ty) | V<W>::subs(y, tx);
-      mn = V<W>::vmin(mn, x);
       y = x;
       ty = tx;
     }
     bits |= acc ? (1u << k) : 0u;
-    if (gcode != nullptr) {
-      uint32_t m = W ? mn : ((mn & 0xFFFFu) < (mn >> 16) ? (mn & 0xFFFFu) : (mn >> 16));
-      m = m < 65535u ? m : 65535u;
-      gcode[k * gstride] = (uint8_t)(uint32_t)sqrtf((float)m);  // (exact floor: m < 2^16, the root is correctly rounded)
-    }
   }
   return bits;
 }
@@ -333,7 +324,6 @@ struct Block {
   uint32_t dmax;         // q16_dmax(a)
   uint64_t win;          // break bits around the block (flat_reach)
   int reach;             // wide form: the flat reach over the whole column (flat_reach_full); unused otherwise
-  const uint8_t *gmin;   // granule codes of the tile (band_breaks): byte of (granule g, pair cp) = gmin[g * 16 + cp]
 };
 
 // S = output stride: 1 = every row of the block is evaluated; 2 = a block is 16 rows of which the even ones are evaluated (the
@@ -423,71 +413,48 @@ struct Steps {
         if (done) break;
       }
     } else {
-      // Windows beyond the register-resident part (rows p0-16 .. p0+23 are done), GRANULE BY GRANULE and side by side (round 5):
-      // the granule at offset +-k holds the rows p0 +- 8k .. p0 +- 8k + 7, at distances 8k-7 .. 8k+7 from the rows of the block.
-      // Before its eight rows are read a granule is TESTED: every candidate it can offer is at least c_{8k-7} + (its smallest
-      // value), and the smallest value has a lower bound code^2 in the tile's granule codes (band_breaks) -- if no lane of the
-      // wave has a current minimum above that, the granule is skipped: ~10 instructions instead of 136.  The symmetric steps
-      // this replaces (3 packed instructions per row and step for BOTH sides, exit only once c_d alone reaches the minima)
-      // spent most of a large cell's window proving that rows far inside the cell cannot win; cfg3L: 12.9 granules per block
-      // looked at by the wave before, 7.6 now (tools/window_granule_sim.py).  One side costs 2 instructions per row and
-      // candidate (no min of the two sides first).  Exact: a skipped granule cannot lower any minimum of the wave.
-      // (after K = 16 steps row i has seen the rows p0+i-16 .. p0+i+16: of the granules at offset +-2, whose rows are still in
-      // the registers of the window, the candidates at distances 17 .. 23 are missing -- row p0+16+j for the rows i < j, row
-      // p0-16+j for the rows i > j)
-      static_assert(K == 16 && B == 8, "the granules at offset 2 are the window's outermost rows");
-      {
-        refresh_bound();
-        if (!EDT_Q16_ANY(X::subs(bmax, cpk(K + 1)) != 0u)) return;
+      // Windows beyond the register-resident part: the same step as a rolled loop.  At step d row i looks at the rows
+      // p0+i-d and p0+i+d, i.e. at the B rows that entered the window most recently on either side: rings of 16 registers
+      // indexed by d mod 16, static once the loop body covers 16 consecutive steps.  Eight consecutive steps read eight
+      // consecutive rows on either side through one address; a stretch beyond the image is moved onto +inf rows.
+      constexpr int R = 16;
+      static_assert((K % R) == 0 && B < R, "ring phase / size");
+      pk rlo[R], rhi[R];
+      EDT_Q16_UNROLL
+      for (int s = K - B + 2; s <= K; ++s) {
+        rlo[s % R] = w[K - s];
+        rhi[s % R] = w[K + B - 1 + s];
+      }
+      const uint32_t *slo = L.img, *shi = L.img;
+      for (int d0 = K + 1; d0 < 4096; d0 += R) {
+        bool done = false;
         EDT_Q16_UNROLL
-        for (int j = 0; j < B; ++j) {
+        for (int e = 0; e < R; e += 2) {  // steps d, d + 1 with d = d0 + e;  d mod R == (1 + e) mod R
+          const int d = d0 + e;
+          if (e % kRefresh == 0) refresh_bound();
+          const pk c1 = cpk(d), c2 = cpk(d + 1);
+          if (!EDT_Q16_ANY(X::subs(bmax, c1) != 0u)) { done = true; break; }
+          if (e % 8 == 0) {
+            int rl = L.p0 - d - 7, rh = L.p0 + B - 1 + d;  // the rows of the next eight steps: rl .. rl+7, rh .. rh+7
+            rl = rl < -kPad ? -kPad : rl;
+            rh = rh > L.nb32 + kPad - 8 ? L.nb32 + kPad - 8 : rh;
+            slo = L.img + (rl + kPad) * RW + L.cp;
+            shi = L.img + (rh + kPad) * RW + L.cp;
+          }
+          const int s1 = (1 + e) % R, s2 = (2 + e) % R;
+          rlo[s1] = slo[(7 - e % 8) * RW];
+          rhi[s1] = shi[(e % 8) * RW];
+          rlo[s2] = slo[(6 - e % 8) * RW];
+          rhi[s2] = shi[(e % 8 + 1) * RW];
           EDT_Q16_UNROLL
           for (int i = 0; i < B; ++i) {
-            if (j > i) best[i] = X::vmin(best[i], X::adds(w[K + 16 + j], cpk(16 + j - i)));
-            if (i > j) best[i] = X::vmin(best[i], X::adds(w[j], cpk(16 + i - j)));
+            // row p0+i-d entered at step d-i, row p0+i+d at step d-(B-1-i)
+            const pk m1 = X::vmin(rlo[(s1 - i + R) % R], rhi[(s1 - (B - 1 - i) + R) % R]);
+            const pk m2 = X::vmin(rlo[(s2 - i + R) % R], rhi[(s2 - (B - 1 - i) + R) % R]);
+            best[i] = X::vmin(X::vmin(best[i], X::adds(m1, c1)), X::adds(m2, c2));
           }
         }
-      }
-      const int NG = L.nb32 >> 3, gb = L.p0 >> 3;
-      for (int k = 3; 8 * k - 7 < 4096; ++k) {
-        refresh_bound();
-        const pk cmin = cpk(8 * k - 7);
-        if (!EDT_Q16_ANY(X::subs(bmax, cmin) != 0u)) break;
-        // (c_{8k-7} is below some minimum here, i.e. within the range: no overflow)
-        const uint32_t cm = a * (uint32_t)((8 * k - 7) * (8 * k - 7));
-        const uint32_t bl = W ? bmax : ((bmax & 0xFFFFu) > (bmax >> 16) ? (bmax & 0xFFFFu) : (bmax >> 16));
-        {  // above: rows p0 + 8k + j, distance to row p0 + i: 8k + j - i
-          const int g = gb + k;
-          const bool in = g < NG;
-          const uint32_t code = L.gmin[(in ? g : NG - 1) * 16 + L.cp];
-          if (EDT_Q16_ANY(in && bl > cm + code * code)) {
-            int r0 = L.p0 + 8 * k;
-            r0 = r0 > L.nb32 + kPad - 8 ? L.nb32 + kPad - 8 : r0;  // (beyond the image: +inf rows)
-            const uint32_t *src = L.img + (r0 + kPad) * RW + L.cp;
-            EDT_Q16_UNROLL
-            for (int j = 0; j < B; ++j) {
-              const pk wj = src[j * RW];
-              EDT_Q16_UNROLL
-              for (int i = 0; i < B; ++i) best[i] = X::vmin(best[i], X::adds(wj, cpk(8 * k + j - i)));
-            }
-          }
-        }
-        {  // below: rows p0 - 8k + j, distance to row p0 + i: 8k + i - j
-          const int g = gb - k;
-          const bool in = g >= 0;
-          const uint32_t code = L.gmin[(in ? g : 0) * 16 + L.cp];
-          if (EDT_Q16_ANY(in && bl > cm + code * code)) {
-            int r0 = L.p0 - 8 * k;
-            r0 = r0 < -kPad ? -kPad : r0;
-            const uint32_t *src = L.img + (r0 + kPad) * RW + L.cp;
-            EDT_Q16_UNROLL
-            for (int j = 0; j < B; ++j) {
-              const pk wj = src[j * RW];
-              EDT_Q16_UNROLL
-              for (int i = 0; i < B; ++i) best[i] = X::vmin(best[i], X::adds(wj, cpk(8 * k + i - j)));
-            }
-          }
-        }
+        if (done) break;
       }
     }
   }

@@ -40,7 +40,6 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
   }
   for (int h = 0; h < (cols_left > 16 ? 2 : 1); ++h) {
     std::vector<uint32_t> img((size_t)(nb32 + 2 * kPad) * kRowWords, kInfW), bm(16 * 6, 0);
-    std::vector<uint8_t> gmin((size_t)NB * 64, 0);
     for (int row = 0; row < n; ++row)
       for (int c = 0; c < 16; ++c) {
         const int col = 16 * h + c;
@@ -59,8 +58,7 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
     for (int u = 0; u < 16 * NB; ++u) {
       const int c = u & 15, band = u >> 4;
       const int valid = n - 32 * band;
-      const uint32_t bits = band_breaks<true>(img.data() + (size_t)(32 * band + kPad) * kRowWords + c, a, band == 0, valid < 32 ? valid : 32,
-                                              gmin.data() + band * 64 + c, 16);
+      const uint32_t bits = band_breaks<true>(img.data() + (size_t)(32 * band + kPad) * kRowWords + c, a, band == 0, valid < 32 ? valid : 32);
       bm[c * 6 + 1 + (band >> 3)] |= bits << (4 * (band & 7));
     }
     for (int sb = 0; sb * 32 < nb32; ++sb)
@@ -90,7 +88,6 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
           L.win = ((uint64_t)hi << 32) | lo;
           L.reach = flat_reach_full(bm.data() + cw * 6, gi);
         }
-        L.gmin = gmin.data();
         pk best[kB];
         block_eval<BB, 1, true>(L, best);
         for (int j = 0; j < kB; ++j) {
@@ -127,7 +124,6 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
   bool over = false;
   std::vector<uint32_t> img((size_t)(nb32 + 2 * kPad) * kRowWords, 0xFFFFFFFFu);
   std::vector<uint32_t> rsp((size_t)NB * 32, 0), lohi((size_t)NB * 32, 0), bm(16 * 6, 0);
-  std::vector<uint8_t> gmin((size_t)NB * 64, 0);
   bool bad = false;
   // ---- fill (edt_colq16.hip, phase 0) ----
   auto put = [&](int row, int col, uint32_t v) {
@@ -191,8 +187,7 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
   for (int u = 0; u < 16 * NB; ++u) {
     const int cp = u & 15, band = u >> 4;
     const int valid = n - 32 * band;
-    const uint32_t bits = band_breaks(img.data() + (size_t)(32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32,
-                                      S == 1 ? gmin.data() + band * 64 + cp : nullptr, 16);
+    const uint32_t bits = band_breaks(img.data() + (size_t)(32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32);
     bm[cp * 6 + 1 + (band >> 3)] |= bits << (4 * (band & 7));
   }
   // ---- blocks (phase 2): a wave works on 16 pairs x four consecutive blocks (of 8 rows, or -- S = 2 -- of 16) ----
@@ -224,7 +219,6 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
         const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
         L.win = ((uint64_t)hi << 32) | lo;
       }
-      L.gmin = gmin.data();
       pk best[kB];
       block_eval<BB, S>(L, best);
       (void)steps_taken;

@@ -196,6 +196,14 @@ class ShardedEDT:
         self._allow16 = records16 is not False and _os.environ.get("EDT_SHARD_RECORDS16", "1") != "0"
         self.last_records16 = False
         self.fallbacks16 = 0
+        # After a step that had to be repeated with fp32 records the plan stays on those for `_backoff16` steps, then tries
+        # the 16-bit form again; every further fall-back doubles the wait (8, 16, ... 1024 steps): data that refuses every
+        # time pays a wasted XY phase ever more rarely, data that refused once (one volume of a stream) gets the 1.9x back.
+        # All ranks count alike (the verdict is an all-reduce), so they switch in the same step.  reset_records16() re-arms
+        # at once; retry16 = False restores round 4's "stays on fp32 for good".
+        self.retry16 = True
+        self._backoff16 = 0      # fp32 steps still to run before the next 16-bit attempt
+        self._backoff16_next = 8
         self._dst16 = None
         self._out16 = None
         self._refused = None
@@ -343,8 +351,18 @@ class ShardedEDT:
         return zs + c0, zs + c1
 
     def _use16(self, w):
-        return (self._allow16 and hasattr(self.ops, "xy_records16")
-                and self.ops.records16_supported(self.code, self.sx, self.sy, self.sz, w))
+        if not (self._allow16 and hasattr(self.ops, "xy_records16")
+                and self.ops.records16_supported(self.code, self.sx, self.sy, self.sz, w)):
+            return False
+        if self._backoff16 > 0:       # (a fall-back not long ago: fp32 records for now)
+            self._backoff16 -= 1
+            return False
+        return True
+
+    def reset_records16(self):
+        """Try records of 16-bit rows again from the next run() on (after a fall-back: see `retry16`)."""
+        self._backoff16 = 0
+        self._backoff16_next = 8
 
     def _run_records(self, labels, w, flags, sqrt, halo, halo_req=None, use16=False, halo_start=None):
         """Slab-record form: chunked XY phase with the exchange of one chunk under the kernels of the next.  The chunks are
@@ -515,7 +533,13 @@ class ShardedEDT:
     def run(self, labels, weights_xyz, black_border=False, sqrt=False, gather_back=False):
         """Returns this rank's Y-slab of the result (all z, its rows) -- in the slab-record form a
         VIEW with a z-stride of one record, not a contiguous tensor -- or, with gather_back, its
-        original Z-slab."""
+        original Z-slab.
+
+        Enqueue-only with fp32 records.  With records of 16-bit rows (`last_records16`) run() BLOCKS the host at its end
+        until the ranks' agreement "every tile had a 16-bit form" has arrived (one 4-byte all-reduce behind the last
+        exchange, read back on a side stream): the result may only be handed out once it is known to be complete, and a
+        refused tile anywhere means the step is repeated here with fp32 records before run() returns.  The wait ends when
+        the last exchange has landed, i.e. a Z phase before the step's kernels do; `fallbacks16` counts the repeats."""
         zs, ze = self.local_z()
         if tuple(labels.shape) != (ze - zs, self.sy, self.sx) or not labels.is_contiguous():
             raise ValueError(f"rank {self.rank}: expected a contiguous ({ze - zs}, {self.sy}, {self.sx}) slab")
@@ -527,9 +551,13 @@ class ShardedEDT:
             out = self._run_records(labels, w, flags, sqrt, None, None, use16, halo_start=lambda: self._halo_start(labels))
             halo = self._last_halo
             if out is None:
-                # a tile without a 16-bit form somewhere: the same step with fp32 records (the halo is here already), and the
-                # plan stays on those -- data that left the 16 bits once will again
-                self._allow16 = False
+                # a tile without a 16-bit form somewhere: the same step with fp32 records (the halo is here already); the plan
+                # stays on those for a while (see __init__: retry16)
+                if self.retry16:
+                    self._backoff16 = self._backoff16_next
+                    self._backoff16_next = min(1024, 2 * self._backoff16_next)
+                else:
+                    self._allow16 = False
                 self.last_records16 = False
                 self.fallbacks16 += 1
                 out = self._run_records(labels, w, flags, sqrt, halo, None, False)

@@ -199,6 +199,12 @@ def _worker(rank, world, port, shape, an, bb, sqrt, gather_back, q, records=None
             ok = ok and not plan.last_records16 and plan.fallbacks16 == 1
             again = plan.run(slab, an, black_border=bb, sqrt=sqrt, gather_back=gather_back).numpy()
             ok = ok and np.array_equal(again, out, equal_nan=True) and plan.fallbacks16 == 1
+            # ... for a while: the next attempt comes 8 steps later (then 16, 32, ...), or at once after reset_records16()
+            ok = ok and plan._backoff16 == 7 and plan._backoff16_next == 16
+            plan.reset_records16()
+            third = plan.run(slab, an, black_border=bb, sqrt=sqrt, gather_back=gather_back).numpy()
+            ok = ok and np.array_equal(third, out, equal_nan=True) and plan.fallbacks16 == 2 and not plan.last_records16
+            ok = ok and plan._backoff16 == 8 and plan._backoff16_next == 16
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -71,7 +71,8 @@ namespace {
 __host__ __device__ constexpr int q16_lds_words(int NB) {
   // image (NB bands of 32 rows + 2 kPad rows, 16 words each) + run-start plane + lo/hi plane + break masks (16 pairs x 6
   // words) + flags
-  return (NB * 32 + 2 * edt_q16::kPad) * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 8;
+  // + the mask of the tile's over-range columns and the column map of a wide pass (8 + 16 words)
+  return (NB * 32 + 2 * edt_q16::kPad) * edt_q16::kRowWords + NB * 32 + NB * 32 + 16 * 6 + 8 + 8 + 16;
 }
 
 }  // namespace
@@ -98,6 +99,8 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   uint32_t *lohi = rsp + NB * 32;                          // [NB][32]: (lo_in + 1) | (hi_out + 1) << 16
   uint32_t *bm = lohi + NB * 32;                           // [16][6]: break bits of the pair's blocks, words 1..4 (0, 5: zero)
   uint32_t *flags = bm + 16 * 6;                           // [T / 64]: per wave, "the tile does not qualify"
+  uint32_t *ovm = flags + 8;                               // [0]: the columns of the tile that hold a value beyond 16 bits
+  uint32_t *wcol = ovm + 8;                                // [16]: tile column of every image column of a wide pass
   const int t = (int)threadIdx.x;
 
   // ---- tile -> (x-tile, outer index): the XCD-aware order of edt_colwave_kernel.h ----
@@ -124,7 +127,12 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   const bool col_ok = 4 * cg < cols_left;
   bool bad = false;   // the tile has no integer form at all: handed to the fp32 kernel
   bool over = false;  // ... no 16-bit form (a value beyond nlim): the wide form if `bad` stays false
+  // which of the thread's columns (4 cg .. 4 cg + 3) hold such a value: the two halves of ov01 / ov23 (index, plane rows), the
+  // low bits of ovq (fp32 rows)
+  pk ov01 = 0u, ov23 = 0u;
+  uint32_t ovq = 0u;
   if (t < 64) bm[t] = 0u, bm[t + 32] = 0u;  // (96 words)
+  if (t == 0) ovm[0] = 0u;
   if (t < 8 * kPad) {
     // +inf around the column: 2 x kPad rows x 16 words, one 16-byte store per thread
     const int row = t < 4 * kPad ? -kPad + (t >> 2) : nb32 + ((t - 4 * kPad) >> 2);
@@ -154,7 +162,8 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
         if (row < nb32) {
           // k > kmax: the tile has no 16-bit form (k^2 may have wrapped: never used); k > kmaxw (also the "no boundary"
           // index 0xFFFF): no wide form either
-          over |= (pk_subs(kk[j][0], kmaxpk) | pk_subs(kk[j][1], kmaxpk)) != 0u;
+          ov01 |= pk_subs(kk[j][0], kmaxpk);
+          ov23 |= pk_subs(kk[j][1], kmaxpk);
           bad |= (pk_subs(kk[j][0], kmaxwpk) | pk_subs(kk[j][1], kmaxwpk)) != 0u;
           v2u v = {pk_mul(pk_mul(kk[j][0], kk[j][0]), ainpk), pk_mul(pk_mul(kk[j][1], kk[j][1]), ainpk)};
           if (row >= n) v = (v2u){~0u, ~0u};
@@ -203,7 +212,8 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
         const int row = i0 + RPS * j + r_in;
         if (row < nb32 && ((in16 >> j) & 1u)) {
           // (pass Y's limit may be the larger one; a 16-bit value is always within the wide form's range)
-          over |= (pk_subs(raw[j][0], nlimpk) | pk_subs(raw[j][1], nlimpk)) != 0u;
+          ov01 |= pk_subs(raw[j][0], nlimpk);
+          ov23 |= pk_subs(raw[j][1], nlimpk);
           *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = (v2u){raw[j][0], raw[j][1]};
         } else if (row < nb32) {
           uint32_t u[4];
@@ -222,7 +232,11 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
           if (max(max(u[0], u[1]), max(u[2], u[3])) > qa.nlim) {
             over = true;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bad |= !wide_value(__uint_as_float(raw[j][c]), qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, u[c]);
+            for (int c = 0; c < 4; ++c) {
+              ovq |= (u[c] > qa.nlim ? 1u : 0u) << c;
+              uint32_t uw;  // (u[c] stays the clamped value: it must not spill into the neighbour's half of the image word)
+              bad |= !wide_value(__uint_as_float(raw[j][c]), qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, uw);
+            }
           } else {
             bad |= !(err == 0.0f);
           }
@@ -235,6 +249,8 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   }
   // (every wave publishes its own verdict: no initialisation to order against, and no static LDS -- __syncthreads_or has
   // some, and hipFuncSetAttribute then refuses the full 160 KiB of dynamic LDS)
+  ovq |= ((ov01 & 0xFFFFu) ? 1u : 0u) | ((ov01 >> 16) ? 2u : 0u) | ((ov23 & 0xFFFFu) ? 4u : 0u) | ((ov23 >> 16) ? 8u : 0u);
+  over |= ovq != 0u;
   if ((t & 63) == 0) flags[t >> 6] = 0u;
   {
     const uint32_t v = (__ballot(bad) != 0ull ? 1u : 0u) | (__ballot(over) != 0ull ? 2u : 0u);
@@ -281,83 +297,282 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     }
     return;
   }
+  // What becomes of a tile with values beyond 16 bits (and nothing worse):
+  //   redo      at most 16 of its columns hold such values (the middle of a 512-voxel row: ONE column per tile): those columns
+  //             become background in the 16-bit image, the tile is worked on as usual -- columns are independent of one another --
+  //             with fp32 results, and only the marked columns are worked on again afterwards, 32-bit lanes on an image of
+  //             their own (the same LDS): one wide pass over up to 16 columns instead of two over all of them;
+  //   full_wide more columns than that: two wide passes, columns 0..15 and 16..31, the 16-bit form not at all.
+  uint32_t redo = 0u;
+  bool full_wide = false;
   if constexpr (kWide) {
     if (go_wide) {
-      // ---- the wide form: two half-tiles of 16 columns, one 32-bit value per image word, the same lane code ----
-      if constexpr (O16) {
-        if (t == 0) atomicAnd(qa.map + xt * qa.map_words + (int)(o >> 5), ~(1u << (o & 31)));  // (its results are fp32 values in F)
+      if (ovq != 0u) atomicOr(ovm, ovq << (4 * cg));
+      __syncthreads();
+      const uint32_t mask = ovm[0];
+      if (__builtin_popcount(mask) > 16 || (dbg & 0x40000000)) {
+        full_wide = true;
+      } else {
+        redo = mask;
+        // the marked columns leave the 16-bit image: background (columns are independent of one another, and a column of
+        // zeros asks for no window -- a column of +inf would: its border parabolas reach a * dmax^2, beyond what the 64-block
+        // view of the break bits can call flat)
+        for (int row = t; row < n; row += T) {
+          uint16_t *r16 = reinterpret_cast<uint16_t *>(img + (row + kPad) * kRowWords);
+          for (uint32_t m = mask; m != 0u; m &= m - 1u) r16[__builtin_ctz(m)] = 0u;
+        }
+        __syncthreads();
       }
+    }
+  }
+  // (O16: the results of a tile with marked columns -- all of its columns -- are fp32 values in F, like a wide tile's)
+  const bool to_f32 = !O16 || redo != 0u;
+  if (!full_wide) {
+    if constexpr (O16 && !SC) {
+      if (t == 0) {
+        if (to_f32) atomicAnd(qa.map + xt * qa.map_words + (int)(o >> 5), ~(1u << (o & 31)));
+        else atomicOr(qa.map + xt * qa.map_words + (int)(o >> 5), 1u << (o & 31));
+      }
+    }
+
+    // ---- phase 1: run extents across bands (one thread per column and direction), break bits per block and pair ----
+    {
+      uint16_t *lohi16 = reinterpret_cast<uint16_t *>(lohi);
+      if (t < 32) scan_runs_lo(rsp + t, 32, NB, lohi16 + 2 * t, 64);
+      else if (t < 64) scan_runs_hi(rsp + (t - 32), 32, NB, n, lohi16 + 2 * (t - 32) + 1, 64);
+      const pk apk = pk_both(qa.a);
+      for (int u = t; u < 16 * NB; u += T) {
+        const int cp = u & 15, band = u >> 4;
+        const int valid = n - 32 * band;
+        const uint32_t bits = band_breaks(img + (32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32);
+        if (bits) atomicOr(&bm[cp * 6 + 1 + (band >> 3)], bits << (4 * (band & 7)));
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2: the blocks ----------------------------------------------------------------------
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63;
+    const int cp = lane & 15, bq = lane >> 4;
+    const bool store_ok = 2 * cp < cols_left;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+  #pragma unroll 1
+    for (int sb = wave; sb * 32 * S < nb32; sb += T / 64) {
+      Block L;
+      L.img = img;
+      L.cp = cp;
+      L.p0 = 32 * S * sb + 8 * S * bq;
+      // (S = 2 and an odd number of bands: the last two blocks of the last iteration do not exist -- their lanes repeat the
+      // column's last block and store nothing, so that the wave-wide exit tests stay what they are)
+      const bool lane_on = L.p0 < nb32;
+      if (!lane_on) L.p0 = nb32 - 8 * S;
+      const int s = L.p0 >> 5;  // the block's band
+      L.n = n;
+      L.nb32 = nb32;
       {
+        const v2u rs2 = *reinterpret_cast<const v2u *>(rsp + s * 32 + 2 * cp);
+        const v2u lh2 = *reinterpret_cast<const v2u *>(lohi + s * 32 + 2 * cp);
+        L.rswA = rs2[0];
+        L.rswB = rs2[1];
+        L.loA = (int)(lh2[0] & 0xFFFFu) - 1;
+        L.hiA = (int)(lh2[0] >> 16) - 1;
+        L.loB = (int)(lh2[1] & 0xFFFFu) - 1;
+        L.hiB = (int)(lh2[1] >> 16) - 1;
+      }
+      L.a = qa.a;
+      L.dmax = qa.dmax;
+      {
+        // the break bits of blocks gi - 32 .. gi + 31 (gi = p0 / 8): bits gi .. gi + 63 of the padded mask
+        const int gi = L.p0 >> 3, wi = gi >> 5, sh = gi & 31;
+        const uint32_t *m = bm + cp * 6 + wi;
+        const uint32_t e0 = m[0], e1 = m[1], e2 = m[2];
+        const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
+        const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
+        L.win = ((uint64_t)hi << 32) | lo;
+        L.bmw = bm + cp * 6;
+      }
+      pk best[kB];
+      block_eval<BB, S>(L, best);
+      // ---- results: (float)N * q is exact; sqrt of the last pass (src/edt.hpp:599-601) ----
+      float *dst;
+      int64_t dstep = st;  // between consecutive EVALUATED rows: S rows of the column, or one row of a compact destination
+      if constexpr (SC) {
+        const int b = s < BandScatter::kBands ? s : 0;
+        dst = scatter->rows[b] + o * scatter->ostride[b] + x0 + 2 * cp - (int64_t)s * 32 * st;
+      } else if (S == 2 && qa.compact != nullptr) {  // (wave-uniform: kernel argument)
+        dst = qa.compact + x0 + 2 * cp + o * qa.c_outer;
+        dstep = qa.c_row2;
+      } else {
+        dst = F + x0 + o * g.outer_stride + 2 * cp;
+        dstep = st * S;
+      }
+      if (O16 && !to_f32) {
+        // (SC: the record's rows are 16-bit here -- the table's pointers and strides count 4-byte words, a row is st / 2 of them)
+        auto *ndst = SC ? (__attribute__((address_space(1))) uint32_t *)dst - ((x0 + 2 * cp) >> 1) + (((int64_t)s * 32 * st) >> 1)
+                        : (__attribute__((address_space(1))) uint32_t *)(qa.plane + x0 + o * g.outer_stride + 2 * cp);
+  #pragma unroll
+        for (int j = 0; j < kB; ++j) {
+          const int row = L.p0 + j;
+          if (row < n && store_ok && lane_on) ndst[((int64_t)row * st) >> 1] = best[j];  // (st % 4 == 0: the pair is a whole word)
+        }
+        continue;
+      }
+      auto *gdst = (__attribute__((address_space(1))) float *)dst;
+      const float q = qa.q;
+      v2f out[kB];
+  #pragma unroll
+      for (int j = 0; j < kB; ++j) out[j] = (v2f){(float)(best[j] & 0xFFFFu) * q, (float)(best[j] >> 16) * q};
+      if (epi & kEpiSqrt) {
+  #pragma unroll
+        for (int j = 0; j < kB; ++j) out[j] = (v2f){sqrtf(out[j].x), sqrtf(out[j].y)};
+      }
+      if (redo == 0u) {
+  #pragma unroll
+        for (int j = 0; j < kB; ++j) {
+          const int row = L.p0 + S * j;
+          if (row < n && store_ok && lane_on)
+            *reinterpret_cast<__attribute__((address_space(1))) v2f *>(gdst + (int64_t)(row / S) * dstep) = out[j];
+        }
+      } else {
+        // a marked column is not written here: what is in F there may be the INPUT its wide pass still has to read (the
+        // passes that work in place), and its result comes from that pass
+        const uint32_t pm = (redo >> (2 * cp)) & 3u;
+  #pragma unroll
+        for (int j = 0; j < kB; ++j) {
+          const int row = L.p0 + S * j;
+          if (row < n && store_ok && lane_on) {
+            if (!(pm & 1u)) gdst[(int64_t)(row / S) * dstep] = out[j].x;
+            if (!(pm & 2u)) gdst[(int64_t)(row / S) * dstep + 1] = out[j].y;
+          }
+        }
+      }
+    }
+
+  }  // (!full_wide)
+
+  if constexpr (kWide) {
+    if (full_wide || redo != 0u) {
+      // ---- wide passes: 16 columns at a time, one 32-bit value per image word, the same lane code (V<true>) ----
+      if constexpr (O16) {
+        if (full_wide && t == 0) atomicAnd(qa.map + xt * qa.map_words + (int)(o >> 5), ~(1u << (o & 31)));  // (fp32 values in F)
+      }
+      if (full_wide) {
         uint16_t *lohi16 = reinterpret_cast<uint16_t *>(lohi);
         if (t < 32) scan_runs_lo(rsp + t, 32, NB, lohi16 + 2 * t, 64);
         else if (t < 64) scan_runs_hi(rsp + (t - 32), 32, NB, n, lohi16 + 2 * (t - 32) + 1, 64);
       }
       const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
       const int lane = t & 63;
-      const int cw = lane & 15, bq = lane >> 4;
-      constexpr int RPSW = T / 4;  // rows per sweep of the fill: 4 threads x 4 columns per row
+      constexpr int RPSW = T / 4;  // rows per sweep of the vector fill: 4 threads x 4 columns per row
       const int rw = t >> 2, cgw = t & 3;
-      const int nhalf = cols_left > 16 ? 2 : 1;
+      const int npass = full_wide ? (cols_left > 16 ? 2 : 1) : 1;
 #pragma unroll 1
-      for (int h = 0; h < nhalf; ++h) {
-        __syncthreads();  // (everybody has read the verdict; the blocks of the half before are done with the image)
+      for (int h = 0; h < npass; ++h) {
+        __syncthreads();  // (everybody has read the verdict / is done with the image of the pass before)
         if (t < 64) bm[t] = 0u, bm[t + 32] = 0u;
         if (t < 8 * kPad) {
           const int row = t < 4 * kPad ? -kPad + (t >> 2) : nb32 + ((t - 4 * kPad) >> 2);
           *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (t & 3)) = (v4u){kInfW, kInfW, kInfW, kInfW};
         }
-        if constexpr (IN == kQ16InCodes) {
-          // the first fill's mapping (whole 64-byte row pieces), by the threads that hold this half's columns (keeping the
-          // first fill's registers alive across the verdict instead spills: 46 scratch instructions)
-          if ((cg >> 2) == h) {
-            const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
-#pragma unroll 1
-            for (int jb = 0; jb < 16; jb += 8) {  // (eight loads in flight: sixteen tip this cold path into scratch)
-              v2u kk[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const int row = RPS * (jb + j) + r_in;
-                kk[j] = (v2u){0u, 0u};
-                if (row < n && col_ok) kk[j] = *reinterpret_cast<const v2u *>(src + (int64_t)row * st);
-              }
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const int row = RPS * (jb + j) + r_in;
-                if (row < nb32) {
-                  const uint32_t k0 = kk[j][0] & 0xFFFFu, k1 = kk[j][0] >> 16, k2 = kk[j][1] & 0xFFFFu, k3 = kk[j][1] >> 16;
-                  v4u v = (v4u){k0 * k0 * qa.ain, k1 * k1 * qa.ain, k2 * k2 * qa.ain, k3 * k3 * qa.ain};
-                  if (row >= n) v = (v4u){kInfW, kInfW, kInfW, kInfW};
-                  *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (cg & 3)) = v;
-                }
-              }
-            }
+        // image column -> tile column (32: none).  Marked columns alone: each is REPLICATED over rep = 16 / (their number) image
+        // columns, and block b of a marked column is worked on in replica b % rep -- a lane per block of ONE image column would
+        // put all 64 lanes of a wave on one LDS bank (rows 8 apart are 128 words apart): measured 15 us per tile.
+        const int nact = full_wide ? 16 : __builtin_popcount(redo);
+        const int rep = full_wide ? 1 : 16 / nact;
+        if (t < 16) {
+          uint32_t c = 32u;
+          if (full_wide) {
+            c = 16u * (uint32_t)h + (uint32_t)t;
+          } else if (t / rep < nact) {
+            uint32_t m = redo;
+            for (int i = 0; i < t / rep; ++i) m &= m - 1u;
+            c = (uint32_t)__builtin_ctz(m);
           }
-        } else {
-          const int c0 = 16 * h + 4 * cgw;  // the thread's four columns inside the tile
-          const bool cw_ok = c0 < cols_left;
-#pragma unroll 4
-          for (int row = rw; row < nb32; row += RPSW) {
-            v4u v = (v4u){kInfW, kInfW, kInfW, kInfW};
-            if (row < n) {
-              v = (v4u){0u, 0u, 0u, 0u};
-              if (cw_ok) {
-                bool p16 = false;
-                if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
-                if (p16) {
-                  const v2u pv = *reinterpret_cast<const v2u *>(qa.plane + x0 + o * qa.p_outer + c0 + (int64_t)row * qa.pst);
-                  v = (v4u){pv[0] & 0xFFFFu, pv[0] >> 16, pv[1] & 0xFFFFu, pv[1] >> 16};
-                } else {
-                  const v4f f = *reinterpret_cast<const v4f *>(F + x0 + o * g.outer_stride + c0 + (int64_t)row * st);
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                    uint32_t u;
-                    (void)wide_value(f[c], qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, u);  // (verified by the first fill)
-                    v[c] = u;
+          wcol[t] = c < (uint32_t)cols_left ? c : 32u;
+        }
+        if (full_wide) {
+          if constexpr (IN == kQ16InCodes) {
+            // the first fill's mapping (whole 64-byte row pieces), by the threads that hold this half's columns (keeping the
+            // first fill's registers alive across the verdict instead spills: 46 scratch instructions)
+            if ((cg >> 2) == h) {
+              const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
+  #pragma unroll 1
+              for (int jb = 0; jb < 16; jb += 8) {  // (eight loads in flight: sixteen tip this cold path into scratch)
+                v2u kk[8];
+  #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const int row = RPS * (jb + j) + r_in;
+                  kk[j] = (v2u){0u, 0u};
+                  if (row < n && col_ok) kk[j] = *reinterpret_cast<const v2u *>(src + (int64_t)row * st);
+                }
+  #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const int row = RPS * (jb + j) + r_in;
+                  if (row < nb32) {
+                    const uint32_t k0 = kk[j][0] & 0xFFFFu, k1 = kk[j][0] >> 16, k2 = kk[j][1] & 0xFFFFu, k3 = kk[j][1] >> 16;
+                    v4u v = (v4u){k0 * k0 * qa.ain, k1 * k1 * qa.ain, k2 * k2 * qa.ain, k3 * k3 * qa.ain};
+                    if (row >= n) v = (v4u){kInfW, kInfW, kInfW, kInfW};
+                    *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (cg & 3)) = v;
                   }
                 }
               }
             }
-            *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * cgw) = v;
+          } else {
+            const int c0 = 16 * h + 4 * cgw;  // the thread's four columns inside the tile
+            const bool cw_ok = c0 < cols_left;
+  #pragma unroll 4
+            for (int row = rw; row < nb32; row += RPSW) {
+              v4u v = (v4u){kInfW, kInfW, kInfW, kInfW};
+              if (row < n) {
+                v = (v4u){0u, 0u, 0u, 0u};
+                if (cw_ok) {
+                  bool p16 = false;
+                  if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
+                  if (p16) {
+                    const v2u pv = *reinterpret_cast<const v2u *>(qa.plane + x0 + o * qa.p_outer + c0 + (int64_t)row * qa.pst);
+                    v = (v4u){pv[0] & 0xFFFFu, pv[0] >> 16, pv[1] & 0xFFFFu, pv[1] >> 16};
+                  } else {
+                    const v4f f = *reinterpret_cast<const v4f *>(F + x0 + o * g.outer_stride + c0 + (int64_t)row * st);
+  #pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                      uint32_t u;
+                      (void)wide_value(f[c], qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, u);  // (verified by the first fill)
+                      v[c] = u;
+                    }
+                  }
+                }
+              }
+              *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * cgw) = v;
+            }
+          }
+        } else {
+          // the marked columns, value by value (their lines are in the L2 since the first fill): zeros everywhere first (an
+          // image column without a tile column is background), then every thread its rows of every marked column -- all
+          // of a thread's loads in flight at once
+          for (int row = t; row < nb32; row += T) {
+            const uint32_t z = row < n ? 0u : kInfW;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * c4) = (v4u){z, z, z, z};
+          }
+          __syncthreads();  // (wcol; the zeros)
+#pragma unroll 4
+          for (int j = 0; j < nact; ++j) {
+            const uint32_t c = wcol[j * rep];
+            if (c >= 32u) continue;
+            for (int row = t; row < n; row += T) {
+              uint32_t v;
+              bool p16 = false;
+              if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
+              if constexpr (IN == kQ16InCodes) {
+                const uint32_t k = qa.codes[x0 + o * g.outer_stride + c + (int64_t)row * st];
+                v = k * k * qa.ain;
+              } else if (p16) {
+                v = qa.plane[x0 + o * qa.p_outer + c + (int64_t)row * qa.pst];
+              } else {
+                (void)wide_value(F[x0 + o * g.outer_stride + c + (int64_t)row * st], qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, v);
+              }
+              for (int r = 0; r < rep; ++r) img[(row + kPad) * kRowWords + j * rep + r] = v;
+            }
           }
         }
         __syncthreads();
@@ -368,18 +583,29 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
           if (bits) atomicOr(&bm[c * 6 + 1 + (band >> 3)], bits << (4 * (band & 7)));
         }
         __syncthreads();
-        const bool store_ok = 16 * h + cw < cols_left;
+        // lane -> (active column, block): the blocks of the active columns dealt densely (16 columns: 16 columns x the four
+        // blocks of a band per wave, as in the 16-bit form; one marked column: its 64 blocks are ONE iteration of one wave)
+        const int nblk = nb32 >> 3;
 #pragma unroll 1
-        for (int sb = wave; sb * 32 < nb32; sb += T / 64) {
+        for (int it = wave; it * 64 < nact * nblk; it += T / 64) {
+          const int item = it * 64 + lane;
+          int blk = item / nact;
+          const int jm = item - blk * nact;       // which active column
+          const bool lane_on = blk < nblk;
+          if (!lane_on) blk = nblk - 1;
+          const int cw = jm * rep + blk % rep;    // its image column (replica)
+          const uint32_t col = wcol[cw];
+          const bool store_ok = lane_on && col < 32u;
+          const uint32_t colc = col < 32u ? col : 0u;
           Block L;
           L.img = img;
           L.cp = cw;
-          L.p0 = 32 * sb + 8 * bq;
+          L.p0 = 8 * blk;
           const int s = L.p0 >> 5;
           L.n = n;
           L.nb32 = nb32;
-          L.rswA = rsp[s * 32 + 16 * h + cw];
-          const uint32_t lh = lohi[s * 32 + 16 * h + cw];
+          L.rswA = col < 32u ? rsp[s * 32 + colc] : 0u;
+          const uint32_t lh = lohi[s * 32 + colc];
           L.loA = (int)(lh & 0xFFFFu) - 1;
           L.hiA = (int)(lh >> 16) - 1;
           L.rswB = 0u;
@@ -400,9 +626,9 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
           float *dst;
           if constexpr (SC) {
             const int b = s < BandScatter::kBands ? s : 0;
-            dst = scatter->rows[b] + o * scatter->ostride[b] + x0 + 16 * h + cw - (int64_t)s * 32 * st;
+            dst = scatter->rows[b] + o * scatter->ostride[b] + x0 + colc - (int64_t)s * 32 * st;
           } else {
-            dst = F + x0 + o * g.outer_stride + 16 * h + cw;
+            dst = F + x0 + o * g.outer_stride + colc;
           }
           auto *gdst = (__attribute__((address_space(1))) float *)dst;
           float out[kB];
@@ -419,108 +645,6 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
           }
         }
       }
-      return;
-    }
-  }
-  if constexpr (O16 && !SC) {
-    if (t == 0) atomicOr(qa.map + xt * qa.map_words + (int)(o >> 5), 1u << (o & 31));
-  }
-
-  // ---- phase 1: run extents across bands (one thread per column and direction), break bits per block and pair ----
-  {
-    uint16_t *lohi16 = reinterpret_cast<uint16_t *>(lohi);
-    if (t < 32) scan_runs_lo(rsp + t, 32, NB, lohi16 + 2 * t, 64);
-    else if (t < 64) scan_runs_hi(rsp + (t - 32), 32, NB, n, lohi16 + 2 * (t - 32) + 1, 64);
-    const pk apk = pk_both(qa.a);
-    for (int u = t; u < 16 * NB; u += T) {
-      const int cp = u & 15, band = u >> 4;
-      const int valid = n - 32 * band;
-      const uint32_t bits = band_breaks(img + (32 * band + kPad) * kRowWords + cp, apk, band == 0, valid < 32 ? valid : 32);
-      if (bits) atomicOr(&bm[cp * 6 + 1 + (band >> 3)], bits << (4 * (band & 7)));
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 2: the blocks ----------------------------------------------------------------------
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int lane = t & 63;
-  const int cp = lane & 15, bq = lane >> 4;
-  const bool store_ok = 2 * cp < cols_left;
-  typedef float v2f __attribute__((ext_vector_type(2)));
-#pragma unroll 1
-  for (int sb = wave; sb * 32 * S < nb32; sb += T / 64) {
-    Block L;
-    L.img = img;
-    L.cp = cp;
-    L.p0 = 32 * S * sb + 8 * S * bq;
-    // (S = 2 and an odd number of bands: the last two blocks of the last iteration do not exist -- their lanes repeat the
-    // column's last block and store nothing, so that the wave-wide exit tests stay what they are)
-    const bool lane_on = L.p0 < nb32;
-    if (!lane_on) L.p0 = nb32 - 8 * S;
-    const int s = L.p0 >> 5;  // the block's band
-    L.n = n;
-    L.nb32 = nb32;
-    {
-      const v2u rs2 = *reinterpret_cast<const v2u *>(rsp + s * 32 + 2 * cp);
-      const v2u lh2 = *reinterpret_cast<const v2u *>(lohi + s * 32 + 2 * cp);
-      L.rswA = rs2[0];
-      L.rswB = rs2[1];
-      L.loA = (int)(lh2[0] & 0xFFFFu) - 1;
-      L.hiA = (int)(lh2[0] >> 16) - 1;
-      L.loB = (int)(lh2[1] & 0xFFFFu) - 1;
-      L.hiB = (int)(lh2[1] >> 16) - 1;
-    }
-    L.a = qa.a;
-    L.dmax = qa.dmax;
-    {
-      // the break bits of blocks gi - 32 .. gi + 31 (gi = p0 / 8): bits gi .. gi + 63 of the padded mask
-      const int gi = L.p0 >> 3, wi = gi >> 5, sh = gi & 31;
-      const uint32_t *m = bm + cp * 6 + wi;
-      const uint32_t e0 = m[0], e1 = m[1], e2 = m[2];
-      const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
-      const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
-      L.win = ((uint64_t)hi << 32) | lo;
-    }
-    pk best[kB];
-    block_eval<BB, S>(L, best);
-    // ---- results: (float)N * q is exact; sqrt of the last pass (src/edt.hpp:599-601) ----
-    float *dst;
-    int64_t dstep = st;  // between consecutive EVALUATED rows: S rows of the column, or one row of a compact destination
-    if constexpr (SC) {
-      const int b = s < BandScatter::kBands ? s : 0;
-      dst = scatter->rows[b] + o * scatter->ostride[b] + x0 + 2 * cp - (int64_t)s * 32 * st;
-    } else if (S == 2 && qa.compact != nullptr) {  // (wave-uniform: kernel argument)
-      dst = qa.compact + x0 + 2 * cp + o * qa.c_outer;
-      dstep = qa.c_row2;
-    } else {
-      dst = F + x0 + o * g.outer_stride + 2 * cp;
-      dstep = st * S;
-    }
-    if constexpr (O16) {
-      // (SC: the record's rows are 16-bit here -- the table's pointers and strides count 4-byte words, a row is st / 2 of them)
-      auto *ndst = SC ? (__attribute__((address_space(1))) uint32_t *)dst - ((x0 + 2 * cp) >> 1) + (((int64_t)s * 32 * st) >> 1)
-                      : (__attribute__((address_space(1))) uint32_t *)(qa.plane + x0 + o * g.outer_stride + 2 * cp);
-#pragma unroll
-      for (int j = 0; j < kB; ++j) {
-        const int row = L.p0 + j;
-        if (row < n && store_ok && lane_on) ndst[((int64_t)row * st) >> 1] = best[j];  // (st % 4 == 0: the pair is a whole word)
-      }
-      continue;
-    }
-    auto *gdst = (__attribute__((address_space(1))) float *)dst;
-    const float q = qa.q;
-    v2f out[kB];
-#pragma unroll
-    for (int j = 0; j < kB; ++j) out[j] = (v2f){(float)(best[j] & 0xFFFFu) * q, (float)(best[j] >> 16) * q};
-    if (epi & kEpiSqrt) {
-#pragma unroll
-      for (int j = 0; j < kB; ++j) out[j] = (v2f){sqrtf(out[j].x), sqrtf(out[j].y)};
-    }
-#pragma unroll
-    for (int j = 0; j < kB; ++j) {
-      const int row = L.p0 + S * j;
-      if (row < n && store_ok && lane_on)
-        *reinterpret_cast<__attribute__((address_space(1))) v2f *>(gdst + (int64_t)(row / S) * dstep) = out[j];
     }
   }
 }

@@ -324,6 +324,7 @@ struct Block {
   uint32_t dmax;         // q16_dmax(a)
   uint64_t win;          // break bits around the block (flat_reach)
   int reach;             // wide form: the flat reach over the whole column (flat_reach_full); unused otherwise
+  const uint32_t *bmw;   // the six mask words of the block's column pair (flat_reach_full)
 };
 
 // S = output stride: 1 = every row of the block is evaluated; 2 = a block is 16 rows of which the even ones are evaluated (the
@@ -555,10 +556,22 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
   for (int i = 0; i < B; ++i) bmax = X::vmax(bmax, best[i]);
   // ---- flat neighbourhood: nothing within reach can improve any row of the wave's blocks ----
   {
-    uint32_t D1 = (uint32_t)(W ? L.reach : flat_reach<S>(L.win)) + 1u;
+    const int r1 = W ? L.reach : flat_reach<S>(L.win);
+    uint32_t D1 = (uint32_t)r1 + 1u;
     D1 = D1 < L.dmax + 1u ? D1 : L.dmax + 1u;
     const uint64_t cD = (uint64_t)L.a * D1 * D1;
     if (!EDT_Q16_ANY(X::subs(bmax, X::cval(cD)) != 0u)) return;
+    if constexpr (!W && S == 1) {
+      // The 64-block view of the break bits ends 248 rows away.  A lane that saw no break in it looks at the whole column
+      // before the wave runs hundreds of steps over a flat one (round 5: columns of 65025 = 255^2 next to the middle of a
+      // 512-voxel row -- 255 steps for nothing; values that large did not reach this kernel's windows before).
+      if (EDT_Q16_ANY(r1 >= 8 * 31)) {
+        const int r2 = r1 >= 8 * 31 ? flat_reach_full(L.bmw, L.p0 >> 3) : r1;
+        uint32_t D2 = (uint32_t)(r2 < (1 << 20) ? r2 : (1 << 20)) + 1u;
+        D2 = D2 < L.dmax + 1u ? D2 : L.dmax + 1u;
+        if (!EDT_Q16_ANY(X::subs(bmax, X::cval((uint64_t)L.a * D2 * D2)) != 0u)) return;
+      }
+    }
   }
   Steps<BB, S, W> steps{L, w, best, PB, bmax, L.a};
   steps.template run<1>();

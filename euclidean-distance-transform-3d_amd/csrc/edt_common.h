@@ -41,9 +41,10 @@ void set_error(const std::string &msg);
 //   0x10000000    integer column kernels: fp32 values between passes Y and Z, not the 16-bit plane
 //   0x20000000    integer column kernels: no wide form (tiles beyond 16 bits go to the fp32 kernel, as in round 4); with it
 //                 the fp32 launch over the hand-over list is never skipped
+//   0x40000000    integer column kernels: a tile beyond 16 bits always as two wide passes over all its columns (no column subset)
 constexpr int kDiagFormBits = 16 | 32 | 64 | 256 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |
                               0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000 | 0x2000000 | 0x4000000 | 0x8000000 | 0x10000000 |
-                              0x20000000;
+                              0x20000000 | 0x40000000;
 #ifdef EDT_DIAG
 #define EDT_DIAG_BITS(dbg, bits) ((dbg) & (bits))
 #else

@@ -21,12 +21,13 @@ using namespace edt_q16;
 namespace {
 
 bool g_no_wide = false;
+bool g_full_wide = false;  // tests: a tile beyond 16 bits always as two wide passes over all its columns
 
 // The wide form of a tile (edt_colq16.hip, go_wide): two half-tiles of 16 columns, one 32-bit value per image word.
 template <bool BB>
 void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, float *out, int64_t sx, int n, int64_t x0,
                     float q, uint32_t a, uint32_t ain, int epi, const uint16_t *plane_in, const uint8_t *row_in_plane,
-                    uint32_t dmaxw, uint32_t nlimw, uint32_t fwmax_bits) {
+                    uint32_t dmaxw, uint32_t nlimw, uint32_t fwmax_bits, uint32_t colmask = 0xFFFFFFFFu) {
   const int NB = (n + 31) / 32, nb32 = NB * 32;
   const int cols_left = (int)(sx - x0);
   std::vector<uint32_t> rsp((size_t)NB * 32, 0), lohi((size_t)NB * 32, 0);
@@ -38,13 +39,26 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
     scan_runs_lo(rsp.data() + t, 32, NB, lohi16 + 2 * t, 64);
     scan_runs_hi(rsp.data() + t, 32, NB, n, lohi16 + 2 * t + 1, 64);
   }
-  for (int h = 0; h < (cols_left > 16 ? 2 : 1); ++h) {
+  // the passes: columns 0..15 and 16..31 (two wide passes over the whole tile), or the marked columns alone (colmask)
+  const bool subset = colmask != 0xFFFFFFFFu;
+  for (int h = 0; h < (subset ? 1 : (cols_left > 16 ? 2 : 1)); ++h) {
+    int wcol[16];
+    for (int i = 0; i < 16; ++i) {
+      int c = 32;
+      if (!subset) c = 16 * h + i;
+      else {
+        uint32_t m = colmask;
+        for (int k = 0; k < i && m; ++k) m &= m - 1;
+        if (m) c = __builtin_ctz(m);
+      }
+      wcol[i] = c < cols_left ? c : 32;
+    }
     std::vector<uint32_t> img((size_t)(nb32 + 2 * kPad) * kRowWords, kInfW), bm(16 * 6, 0);
     for (int row = 0; row < n; ++row)
       for (int c = 0; c < 16; ++c) {
-        const int col = 16 * h + c;
+        const int col = wcol[c];
         uint32_t v = 0;
-        if (col < cols_left) {
+        if (col < 32) {
           if (plane_in && row_in_plane[row]) v = plane_in[(int64_t)row * sx + x0 + col];
           else if (codes) {
             const uint32_t k = codes[(int64_t)row * sx + x0 + col];
@@ -64,6 +78,7 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
     for (int sb = 0; sb * 32 < nb32; ++sb)
       for (int lane = 0; lane < 64; ++lane) {
         const int cw = lane & 15, bq = lane >> 4;
+        const int colc = wcol[cw] < 32 ? wcol[cw] : 0;
         Block L;
         L.img = img.data();
         L.cp = cw;
@@ -71,8 +86,8 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
         const int s = L.p0 >> 5;
         L.n = n;
         L.nb32 = nb32;
-        L.rswA = rsp[(size_t)s * 32 + 16 * h + cw];
-        const uint32_t lh = lohi[(size_t)s * 32 + 16 * h + cw];
+        L.rswA = wcol[cw] < 32 ? rsp[(size_t)s * 32 + colc] : 0u;
+        const uint32_t lh = lohi[(size_t)s * 32 + colc];
         L.loA = (int)(lh & 0xFFFFu) - 1;
         L.hiA = (int)(lh >> 16) - 1;
         L.rswB = 0u;
@@ -91,8 +106,8 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
         pk best[kB];
         block_eval<BB, 1, true>(L, best);
         for (int j = 0; j < kB; ++j) {
-          const int row = L.p0 + j, col = 16 * h + cw;
-          if (row >= n || col >= cols_left) continue;
+          const int row = L.p0 + j, col = wcol[cw];
+          if (row >= n || col >= 32) continue;
           float v = (float)best[j] * q;
           if (epi & 2) v = sqrtf(v);
           out[(int64_t)row * sx + x0 + col] = v;
@@ -122,6 +137,7 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
   uint32_t fwmax_bits;
   memcpy(&fwmax_bits, &fw, sizeof(fw));
   bool over = false;
+  uint32_t overmask = 0;  // the tile's columns that hold a value beyond the 16-bit form
   std::vector<uint32_t> img((size_t)(nb32 + 2 * kPad) * kRowWords, 0xFFFFFFFFu);
   std::vector<uint32_t> rsp((size_t)NB * 32, 0), lohi((size_t)NB * 32, 0), bm(16 * 6, 0);
   bool bad = false;
@@ -137,10 +153,10 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
       else if (col < cols_left) {
         if (plane_in && row_in_plane[row]) {  // (mixed input: this row of the tile is in the 16-bit plane)
           v = plane_in[(int64_t)row * sx + x0 + col];
-          if (v > nlim) over = true;
+          if (v > nlim) { over = true; overmask |= 1u << col; }
         } else if (codes) {
           const uint32_t k = codes[(int64_t)row * sx + x0 + col];
-          if (k > kmax) over = true;
+          if (k > kmax) { over = true; overmask |= 1u << col; }
           if (k > kmaxw) bad = true;
           v = (uint32_t)(uint16_t)((uint16_t)(k * k) * (uint16_t)ain);  // (wraps like the packed multiply; unused if bad)
         } else {
@@ -151,6 +167,7 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
           const float e = fmaf(-(float)u, q, f);
           if (u > nlim) {  // (the conversion was clamped: the wide form's conversion gives the verdict)
             over = true;
+            overmask |= 1u << col;
             uint32_t uw;
             if (!wide_value(f, q, 1.0f / q, nlimw, fwmax_bits, uw)) bad = true;
           } else if (!(fabsf(e) == 0.0f)) bad = true;
@@ -163,12 +180,19 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
     for (int col = 0; col < 32; ++col)
       rsp[(size_t)band * 32 + col] = col < cols_left ? rsbits[(size_t)band * sx + x0 + col] : 0u;
   const bool go_wide = S == 1 && !bad && over && nlimw > nlim;
+  uint32_t redo = 0;  // (edt_colq16.hip: at most 16 marked columns -- the 16-bit form with those columns at +inf, then ONE wide pass over them)
   if (go_wide) {
-    if constexpr (S == 1)
-      tile_pass_wide<BB>(Fin, codes, rsbits, out, sx, n, x0, q, a, ain, epi, plane_in, row_in_plane, dmaxw, nlimw, fwmax_bits);
-    return 2;
+    if (__builtin_popcount(overmask) > 16 || g_full_wide) {
+      if constexpr (S == 1)
+        tile_pass_wide<BB>(Fin, codes, rsbits, out, sx, n, x0, q, a, ain, epi, plane_in, row_in_plane, dmaxw, nlimw, fwmax_bits);
+      return 2;
+    }
+    redo = overmask;
+    for (int row = 0; row < n; ++row)
+      for (uint32_t m = redo; m; m &= m - 1) put(row, __builtin_ctz(m), 0u);
+    plane_out = nullptr;  // (fp32 results for the whole tile)
   }
-  if (bad || over) {
+  if (bad || (over && redo == 0)) {
     // mixed input: the rows the tile has in the plane become fp32 values (the fp32 kernel reads F)
     if (plane_in)
       for (int row = 0; row < n; ++row)
@@ -218,6 +242,7 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
         const uint32_t lo = (uint32_t)((((uint64_t)e1 << 32) | e0) >> sh);
         const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
         L.win = ((uint64_t)hi << 32) | lo;
+        L.bmw = bm.data() + cp * 6;
       }
       pk best[kB];
       block_eval<BB, S>(L, best);
@@ -227,7 +252,7 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
         if (row >= n) continue;
         for (int h = 0; h < 2; ++h) {
           const int col = 2 * cp + h;
-          if (col >= cols_left) continue;
+          if (col >= cols_left || ((redo >> col) & 1u)) continue;  // (a marked column's result comes from its wide pass)
           if (plane_out) { plane_out[(int64_t)row * sx + x0 + col] = (uint16_t)((best[j] >> (16 * h)) & 0xFFFFu); continue; }
           float v = (float)((best[j] >> (16 * h)) & 0xFFFFu) * q;
           if (epi & 2) v = sqrtf(v);
@@ -235,6 +260,11 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
         }
       }
     }
+  if (redo != 0) {
+    if constexpr (S == 1)
+      tile_pass_wide<BB>(Fin, codes, rsbits, out, sx, n, x0, q, a, ain, epi, plane_in, row_in_plane, dmaxw, nlimw, fwmax_bits, redo);
+    return 3;
+  }
   return 1;
 }
 
@@ -242,6 +272,7 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
 
 // (tests: the 16-bit form only, as in round 4)
 extern "C" void q16_emul_set_no_wide(int v) { g_no_wide = v != 0; }
+extern "C" void q16_emul_set_full_wide(int v) { g_full_wide = v != 0; }
 
 // labels [n][sx] uint32 (the run structure along the scan axis), Fin [n][sx] fp32 or codes [n][sx] u16 (exactly one of
 // them), out [n][sx].  tile_ok[i] = 1 if x-tile i qualified (and was written).  Returns the number of tiles that did.

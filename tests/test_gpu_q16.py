@@ -13,6 +13,7 @@ from synth import blocky_labels, voronoi_labels
 pytestmark = pytest.mark.gpu
 
 MODES = [(0, "q16 + plane"), (0x10000000, "q16, fp32 between Y and Z"), (0x8000000, "fp32 kernels"),
+         (0x40000000, "q16, tiles beyond 16 bits as two wide passes (no column subsets)"),
          (0x20000000, "q16 without the wide form: tiles beyond 16 bits on the fp32 kernel, every list launched")]
 
 
@@ -85,7 +86,8 @@ def test_q16_wide_form(edt_gpu, oracle_port, shape):
         for an, bb in combos:
             want = oracle_port.edtsq(lab, an, bb)
             try:
-                for mode in (0, 0x20000000, 0x10000000, 0x100000, 0x8000000):
+                # (0x40000000: every tile beyond 16 bits as two wide passes; default: its marked columns alone where there are <= 16)
+                for mode in (0, 0x40000000, 0x20000000, 0x10000000, 0x100000, 0x100000 | 0x40000000, 0x8000000):
                     lib.edt_hip_set_debug_mode(mode)
                     got = edt_gpu.edtsq(lab, anisotropy=an, black_border=bb)
                     assert np.array_equal(got, want), (shape, an, bb, hex(mode))

@@ -36,6 +36,7 @@ def q16():
     lib.q16_emul_column_pass.restype = ctypes.c_int
     lib.q16_emul_quantum.restype = ctypes.c_int
     lib.q16_emul_set_no_wide(0)
+    lib.q16_emul_set_full_wide(0)
     return lib
 
 
@@ -73,7 +74,9 @@ def column_pass(lib, labels_yx, f_yx, codes_yx, q, a, ain, bb, epi):
                              out.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(sx), ctypes.c_int64(n),
                              ctypes.c_float(q), ctypes.c_uint32(a), ctypes.c_uint32(ain), ctypes.c_int(int(bb)),
                              ctypes.c_int(epi), ok.ctypes.data_as(ctypes.c_void_p))
-    return out, ok   # per x-tile: 0 = handed to the fp32 kernel, 1 = 16-bit form, 2 = wide form (two half-tiles, 32-bit lanes)
+    # per x-tile: 0 = handed to the fp32 kernel, 1 = 16-bit form, 2 = wide form (two passes of 16 columns, 32-bit lanes),
+    # 3 = 16-bit form + ONE wide pass over the (at most 16) columns that hold values beyond 16 bits
+    return out, ok
 
 
 def x_pass(oracle, labels_yx, wx, bb):
@@ -156,6 +159,10 @@ def test_q16_refuses_values_off_the_quantum_grid(q16, oracle_port):
     assert list(tiles) == [1, 0]
     f1[91, 41] = np.float32(2047 ** 2)
     _, tiles = column_pass(q16, lab, f1, None, 1.0, 1, 1, True, 0)
+    assert list(tiles) == [1, 3]              # (one column beyond 16 bits: that column alone gets a wide pass)
+    q16.q16_emul_set_full_wide(1)
+    _, tiles = column_pass(q16, lab, f1, None, 1.0, 1, 1, True, 0)
+    q16.q16_emul_set_full_wide(0)
     assert list(tiles) == [1, 2]
     q16.q16_emul_set_no_wide(1)           # (the 16-bit form alone, as in round 4)
     _, tiles = column_pass(q16, lab, f1, None, 1.0, 1, 1, True, 0)
@@ -181,7 +188,7 @@ def test_q16_wide_form_matches_oracle(q16, oracle_port, n, sx, kind):
     else:
         lab = np.ones((n, sx), dtype=np.uint32)
         lab[rng.random((n, sx)) < 0.0005] = 0
-    seen_wide = False
+    seen_wide = seen_subset = False
     for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (30.0, 6.0), (0.5, 1.0)):
         ok, q, a = quantum(q16, (wx, wy))
         assert ok
@@ -189,9 +196,12 @@ def test_q16_wide_form_matches_oracle(q16, oracle_port, n, sx, kind):
             f1, codes = x_pass(oracle_port, lab, wx, bb)
             want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
             for form in ("f32", "codes"):
-                for epi in (0, 2):
+                for epi, full in ((0, 0), (2, 0), (0, 1)):   # (full: no column subsets -- two wide passes over every such tile)
+                    q16.q16_emul_set_full_wide(full)
                     got, tiles = column_pass(q16, lab, f1 if form == "f32" else None, codes if form == "codes" else None,
                                              q, a[1], a[0], bb, epi)
+                    q16.q16_emul_set_full_wide(0)
+                    assert not full or not (tiles == 3).any()
                     exp = np.sqrt(want) if epi else want
                     for i, t_ok in enumerate(tiles):
                         sl = slice(32 * i, min(sx, 32 * i + 32))
@@ -200,9 +210,10 @@ def test_q16_wide_form_matches_oracle(q16, oracle_port, n, sx, kind):
                         else:
                             assert (got[:, sl] == -1.0).all()
                     seen_wide |= bool((tiles == 2).any())
+                    seen_subset |= bool((tiles == 3).any())
                     if bb and kind == "ones" and int(codes.max()) ** 2 * a[0] <= wide_limit(a[1], q):
                         assert tiles.all(), "a single label inside a black border leaves nothing to the fp32 kernel"
-    assert seen_wide
+    assert seen_wide and (seen_subset or kind == "bigcells")
 
 
 @pytest.mark.parametrize("n,sx,kind", [(1024, 32, "cells"), (512, 64, "blocky"), (500, 36, "membrane"), (300, 40, "cells"),

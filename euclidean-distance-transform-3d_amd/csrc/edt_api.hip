@@ -1,6 +1,7 @@
-// edt_api.hip -- the C ABI (include/edt_hip.h): orchestration of the passes, workspace
-// carving, host-buffer staging, per-pass event timing.  No compute happens on the host and
-// there is no CPU fallback: every entry point needs a HIP device.
+// edt_api.hip -- the C ABI (include/edt_hip.h), part 1 of 3: the plan of a call and the dispatch of its passes on
+// device-resident data (run_device), workspace carving, per-pass event timing, the device entry points that are not
+// sharded.  Part 2: edt_host.hip (host-buffer staging); part 3: edt_shard_api.hip (the phases of the Z-sharded path).
+// No compute happens on the host and there is no CPU fallback: every entry point needs a HIP device.
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -14,6 +15,8 @@
 
 #include "edt_common.h"
 #include "edt_kernels.h"
+
+#include "edt_api_internal.h"
 
 namespace edt_amd {
 
@@ -39,18 +42,11 @@ void set_thread_debug_mode(int mode) { g_debug_mode = mode & kDiagMask; }
 
 
 
-// ---- per-pass event timing (bench.py reads this) -------------------------------------
-struct PassLog {
-  std::atomic<bool> enabled{false};
-  std::vector<hipEvent_t> pool;          // reused events
-  std::vector<std::pair<int, int>> span;  // (start, stop) indices of the last call
-  std::vector<std::string> names;
-  int used = 0;
-};
-static PassLog g_log;
-static std::mutex g_log_mutex;
+// ---- per-pass event timing (bench.py reads this): edt_api_internal.h ------------------
+PassLog g_log;
+std::mutex g_log_mutex;
 
-static hipEvent_t log_event() {
+hipEvent_t log_event() {
   if (g_log.used == (int)g_log.pool.size()) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
@@ -59,55 +55,13 @@ static hipEvent_t log_event() {
   return g_log.pool[g_log.used++];
 }
 
-struct ScopedPass {
-  hipStream_t stream;
-  int start = -1;
-  bool named;
-  ScopedPass(const char *name, hipStream_t s) : stream(s), named(name != nullptr) {  // (no name: not a pass of its own)
-    if (!named) return;
-    if (g_debug_mode & 0x1000) fprintf(stderr, "[edt_hip] pass start: %s\n", name);
-    if (!g_log.enabled.load(std::memory_order_relaxed)) return;
-    std::lock_guard<std::mutex> lock(g_log_mutex);  // (only while profiling is switched on)
-    hipEvent_t e = log_event();
-    if (!e) return;
-    start = g_log.used - 1;
-    (void)hipEventRecord(e, stream);
-    g_log.names.push_back(name);
-  }
-  ~ScopedPass() {
-    if (!named) return;
-    if (g_debug_mode & 0x1000) {  // diagnostics: name every pass as it completes
-      const hipError_t e = hipStreamSynchronize(stream);
-      fprintf(stderr, "[edt_hip] pass done: %s\n", hipGetErrorString(e));
-    }
-    if (start < 0) return;
-    std::lock_guard<std::mutex> lock(g_log_mutex);
-    hipEvent_t e = log_event();
-    if (!e) return;
-    (void)hipEventRecord(e, stream);
-    g_log.span.push_back({start, g_log.used - 1});
-  }
-};
-
-static void log_begin_call() {
+void log_begin_call() {
   g_log.used = 0;
   g_log.span.clear();
   g_log.names.clear();
 }
 
-// ---- workspace carving -----------------------------------------------------------------
-struct Carver {
-  char *base;
-  size_t off = 0;
-  explicit Carver(void *p) : base((char *)p) {}
-  template <typename T>
-  T *take(size_t count) {
-    off = align_up(off, 256);
-    T *p = base ? (T *)(base + off) : nullptr;
-    off += count * sizeof(T);
-    return p;
-  }
-};
+
 
 struct Plan {
   int ndim;
@@ -130,13 +84,13 @@ struct Plan {
   size_t bytes = 0;
 };
 
-static AxisGeom make_geom_y(int64_t sx, int64_t sy, int64_t sz) {
+AxisGeom make_geom_y(int64_t sx, int64_t sy, int64_t sz) {
   AxisGeom g;
   g.sx = sx; g.n = sy; g.stride = sx; g.nouter = sz; g.outer_stride = sx * sy;
   g.nbands = ceil_div(sy, kBandRows);
   return g;
 }
-static AxisGeom make_geom_z(int64_t sx, int64_t sy, int64_t sz) {
+AxisGeom make_geom_z(int64_t sx, int64_t sy, int64_t sz) {
   AxisGeom g;
   g.sx = sx; g.n = sz; g.stride = sx * sy; g.nouter = sy; g.outer_stride = sx;
   g.nbands = ceil_div(sz, kBandRows);
@@ -156,7 +110,6 @@ static bool plan_needs_pingpong(int ndim, int64_t sx, int64_t sy, int64_t sz, in
 constexpr int64_t kCodeSlabVoxels = (int64_t)1 << 27;
 constexpr int kQ16Slots = 256;  // counters of the 16-bit integer column kernel's hand-over lists (one per launch)
 constexpr int EDT_FLAG_NO_INDEX_FORM = 0x8000;  // internal: plan without the index buffer
-static bool env_force_generic();
 static int64_t plan_code_slab(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
   if (ndim < 2 || sx % 4 != 0 || sx * sy > kCodeSlabVoxels || (flags & (EDT_FLAG_NO_INDEX_FORM | EDT_FLAG_SMALL_WORKSPACE))) return 0;
   if ((flags & EDT_FLAG_FORCE_GENERIC) || env_force_generic() || (g_debug_mode & (0x100000 | 64 | 32))) return 0;
@@ -217,11 +170,11 @@ static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, v
 
 // In-place LDS-tiled column pass: the wave-autonomous kernel where the axis fits its register
 // budget, the workgroup-phased kernel for longer axes.  (debug bit 64 forces the latter.)
-static bool column_inplace_supported(const AxisGeom &g) {
+bool column_inplace_supported(const AxisGeom &g) {
   return column_pass_wave_supported(g) || column_pass_tiled_supported(g);
 }
-static int launch_column_inplace(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
-                                 float w, int bb, int epi, hipStream_t stream, const TileList &list = TileList()) {
+int launch_column_inplace(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGeom &g,
+                          float w, int bb, int epi, hipStream_t stream, const TileList &list) {
   // (a list -- the tiles the 16-bit integer kernel refused -- only exists for axes of the wave kernel)
   if (list.count != nullptr) return launch_column_pass_wave(F, nz, rs, g, w, bb, epi, stream, nullptr, ColumnOut(), list);
   // axes of at most 32 rows with many columns: a thread per column (edt_short.hip); the LDS-tiled kernels would
@@ -236,7 +189,7 @@ static int launch_column_inplace(float *F, const uint32_t *nz, const uint32_t *r
 // Pass 1 with the bit planes of the column passes as a by-product: the register-resident wave kernel for rows of up
 // to 4096 voxels (one, two or four waves per row), the LDS-staged workgroup kernel (rows of up to 2048 voxels) where
 // that one does not apply.  (debug bit 32 forces the latter.)
-static int launch_row_bits(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
+int launch_row_bits(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                            uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
                            int to_finite, hipStream_t stream) {
   if (row_pass_wave_supported(dtype, sx, sy, sz) && !(g_debug_mode & 32))
@@ -244,7 +197,7 @@ static int launch_row_bits(int dtype, const void *labels, float *out, uint32_t *
   return launch_row_pass_tiled(dtype, labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream);
 }
 
-static bool env_force_generic() {
+bool env_force_generic() {
   const char *e = std::getenv("EDT_HIP_FORCE_GENERIC");  // test hook: every call takes the fallback kernels
   return e && e[0] == '1';
 }
@@ -258,7 +211,7 @@ static bool plan_needs_pingpong(int ndim, int64_t sx, int64_t sy, int64_t sz, in
   return ndim == 3 && !(flags & EDT_FLAG_BATCH_2D) && !column_inplace_supported(make_geom_z(sx, sy, sz));
 }
 
-static int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
+int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
   if (dtype_size(dtype) == 0) { set_error("unknown dtype code"); return EDT_ERR_BAD_ARG; }
   if (ndim < 1 || ndim > 3) { set_error("ndim must be 1, 2 or 3"); return EDT_ERR_BAD_ARG; }
   if (sx < 0 || sy < 0 || sz < 0) { set_error("negative extent"); return EDT_ERR_BAD_ARG; }
@@ -276,7 +229,7 @@ static int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) 
 // Voxel sizes must be positive and finite.  (The reference does not validate them: a negative size makes its pass 1 cross
 // label boundaries -- the unguarded backward fminf sweep, src/edt.hpp:107-109 -- and NaN / inf / 0 give NaN or all-zero
 // fields; no kernel here reproduces that, so the call is refused instead of answered differently by different kernels.)
-static int check_voxel_sizes(int naxes, float wx, float wy, float wz) {
+int check_voxel_sizes(int naxes, float wx, float wy, float wz) {
   const float w[3] = {wx, wy, wz};
   for (int i = 0; i < naxes && i < 3; ++i) {
     if (!(w[i] > 0.0f) || !(w[i] <= FLT_MAX)) {
@@ -287,7 +240,7 @@ static int check_voxel_sizes(int naxes, float wx, float wy, float wz) {
   return EDT_OK;
 }
 
-static int require_device() {
+int require_device() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     (void)hipGetLastError();
@@ -298,7 +251,7 @@ static int require_device() {
 }
 
 // ---- the pass pipeline on device-resident data -----------------------------------------
-static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz,
+int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz,
                       float wx, float wy, float wz, int flags, float *d_out, void *d_ws,
                       size_t ws_bytes, hipStream_t stream) {
   int rc = check_shape(dtype, ndim, sx, sy, sz);
@@ -530,370 +483,7 @@ static int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int
   return EDT_OK;
 }
 
-// ---- host-buffer staging -----------------------------------------------------------------
-// Device memory of the host-buffer entry points is kept between calls: hipMalloc / hipFree of the
-// gigabyte-sized label, output and scratch buffers cost more than the transfers (measured: 64 ms per
-// 512^3 uint32 call with fresh allocations, of which 2 x 9.5 ms are PCIe and 0.7 ms kernels).  One
-// process-wide pool, one host call at a time (the mutex is held for the whole call); released by
-// edt_hip_release_cache() or at exit.  EDT_HIP_NO_CACHE=1 restores allocate-per-call.
-struct DevicePool {
-  static constexpr int kSlots = 6;
-  void *p[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap[kSlots] = {0, 0, 0, 0, 0, 0};
-  std::mutex m;
-  void release() {  // (call with the owning device current)
-    for (int i = 0; i < kSlots; ++i) {
-      if (p[i]) (void)hipFree(p[i]);
-      p[i] = nullptr;
-      cap[i] = 0;
-    }
-  }
-  ~DevicePool() { /* the runtime may already be gone at static destruction: leak on purpose */ }
-};
-// one pool per device ordinal: a host-buffer call uses the pool of the device that is current on the
-// calling thread, so buffers are never handed to kernels running on another device
-constexpr int kMaxDevices = 64;
-static DevicePool g_pools[kMaxDevices];
-
-static DevicePool *current_pool() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  return (dev >= 0 && dev < kMaxDevices) ? &g_pools[dev] : nullptr;
-}
-
-struct DeviceBuf {
-  DevicePool *pool;  // nullptr: private allocations only
-  void *p = nullptr;
-  bool owned = false;
-  explicit DeviceBuf(DevicePool *pl) : pool(pl) {}
-  ~DeviceBuf() { if (p && owned) (void)hipFree(p); }
-  // slot < 0 (or no pool): private allocation, freed with the object; otherwise the pool slot is (re)used.
-  // The caller holds pool->m when it uses slots.
-  int alloc(size_t bytes, int slot = -1) {
-    if (bytes == 0) bytes = 256;
-    if (slot >= 0 && pool) {
-      if (pool->cap[slot] < bytes) {
-        if (pool->p[slot]) (void)hipFree(pool->p[slot]);
-        pool->p[slot] = nullptr;
-        pool->cap[slot] = 0;
-        const hipError_t e = hipMalloc(&pool->p[slot], bytes);
-        if (e != hipSuccess) {
-          pool->p[slot] = nullptr;
-          (void)hipGetLastError();
-          pool->release();  // give everything back and let the caller see the failure
-          set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
-          return EDT_ERR_NOMEM;
-        }
-        pool->cap[slot] = bytes;
-      }
-      p = pool->p[slot];
-      owned = false;
-      return EDT_OK;
-    }
-    const hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) {
-      p = nullptr;
-      set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
-      return EDT_ERR_NOMEM;
-    }
-    owned = true;
-    return EDT_OK;
-  }
-};
-
-static bool pool_enabled() {
-  const char *e = std::getenv("EDT_HIP_NO_CACHE");
-  return !(e && e[0] == '1');
-}
-
-// First touch of a large, freshly allocated result array is what dominated the host-buffer path: the kernel
-// zero-fills every page on its first write, one core at a time inside the device-to-host copy (measured:
-// ~35 of the 57 ms of a 512^3 call, against 2 x 9.5 ms of PCIe and 0.7 ms of kernels).  The pages are
-// therefore touched by a few threads WHILE the labels travel to the device and the kernels run; the copy
-// back then proceeds at PCIe speed.  (Every byte of the buffer is overwritten by the result afterwards.)
-struct Prefault {
-  std::vector<std::thread> threads;
-  Prefault(void *buf, size_t bytes) {
-    constexpr size_t kPage = 4096, kMin = size_t(32) << 20;
-    const char *off = std::getenv("EDT_HIP_NO_PREFAULT");
-    if (bytes < kMin || (off && off[0] == '1')) return;
-    unsigned n = std::thread::hardware_concurrency();
-    n = n == 0 ? 4 : (n > 16 ? 16 : n);
-    const size_t chunk = align_up((bytes + n - 1) / n, kPage);
-    volatile char *base = static_cast<volatile char *>(buf);
-#ifdef MADV_HUGEPAGE
-    {
-      // transparent huge pages for the part of the buffer that can have them (the box runs THP in
-      // "madvise" mode): 2 MiB per fault instead of 4 KiB, and a cheaper unmap when the array is freed
-      const char *thp = std::getenv("EDT_HIP_NO_THP");
-      const uintptr_t lo = align_up(reinterpret_cast<uintptr_t>(buf), kPage);
-      const uintptr_t hi = (reinterpret_cast<uintptr_t>(buf) + bytes) & ~(uintptr_t)(kPage - 1);
-      if (hi > lo && !(thp && thp[0] == '1')) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
-    }
-#endif
-    for (unsigned t = 0; t < n; ++t) {
-      const size_t lo = (size_t)t * chunk, hi = std::min(bytes, lo + chunk);
-      if (lo >= hi) break;
-      try {
-        threads.emplace_back([base, lo, hi] {
-          for (size_t o = lo; o < hi; o += kPage) base[o] = 0;
-          base[hi - 1] = 0;
-        });
-      } catch (const std::system_error &) {
-        break;  // no more threads to be had: the remaining pages are touched by the copy itself (slower, not wrong)
-      }
-    }
-  }
-  void join() {
-    for (auto &t : threads) t.join();
-    threads.clear();
-  }
-  ~Prefault() { join(); }
-};
-
-// Devices of the one-process multi-GPU route (edt_multi.hip); empty = single device.
-static std::mutex g_devices_mutex;
-static std::vector<int> g_devices = [] {
-  std::vector<int> v;
-  if (const char *e = std::getenv("EDT_HIP_DEVICES")) {
-    const char *p = e;
-    while (*p) {
-      char *end = nullptr;
-      const long d = std::strtol(p, &end, 10);
-      if (end == p) break;
-      v.push_back((int)d);
-      p = (*end == ',') ? end + 1 : end;
-    }
-  }
-  return v;
-}();
-
-constexpr int EDT_FLAG_SINGLE_DEVICE = 0x4000;  // internal: do not take the multi-GPU route
-
-// The first device of the list (edt_hip_set_devices / EDT_HIP_DEVICES) for the duration of one host-buffer call that
-// is not sharded; no list: the caller's current device stays.
-struct ListedDevice {
-  int prev = -1;
-  bool switched = false;
-  ListedDevice() {
-    int first = -1;
-    {
-      std::lock_guard<std::mutex> lock(g_devices_mutex);
-      if (!g_devices.empty()) first = g_devices[0];
-    }
-    if (first >= 0 && hipGetDevice(&prev) == hipSuccess && prev != first && hipSetDevice(first) == hipSuccess) switched = true;
-  }
-  ~ListedDevice() {
-    if (switched) (void)hipSetDevice(prev);
-  }
-};
-
-static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz,
-                    float wx, float wy, float wz, int flags, float *output) {
-  int rc = check_shape(dtype, ndim, sx, sy, sz);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(ndim, wx, wy, wz)) != EDT_OK) return rc;
-  const int64_t voxels = sx * sy * sz;
-  if (voxels == 0) return EDT_OK;
-  if (!labels || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
-  rc = require_device();
-  if (rc != EDT_OK) return rc;
-  if (env_force_generic()) flags |= EDT_FLAG_FORCE_GENERIC;
-  // The device list (edt_hip_set_devices / EDT_HIP_DEVICES) is honoured by EVERY host-buffer call: a 3-D volume the
-  // slab-record form can cut is Z-sharded over the listed devices, everything else (1-D, 2-D, stacks of images, the binary
-  // route, the forced generic kernels, volumes that cannot be cut) runs on the FIRST listed device.
-  if (!(flags & EDT_FLAG_SINGLE_DEVICE)) {
-    std::vector<int> devs;
-    {
-      std::lock_guard<std::mutex> lock(g_devices_mutex);
-      devs = g_devices;
-    }
-    const bool shardable = ndim == 3 && !(flags & (EDT_FLAG_FORCE_GENERIC | EDT_FLAG_BATCH_2D | EDT_FLAG_BINARY_YZ));
-    if (shardable && devs.size() >= 2 && multi_supported(dtype, sx, sy, sz, (int)devs.size())) {
-      Prefault touch(output, (size_t)voxels * sizeof(float));
-      touch.join();
-      return run_multi(labels, dtype, sx, sy, sz, wx, wy, wz, flags, output, devs.data(), (int)devs.size());
-    }
-    if (!devs.empty()) {
-      // a one-entry list, or a call the slab-record form does not cover: the FIRST listed device does it alone
-      if (shardable && devs.size() >= 2) {
-        static std::atomic<bool> said{false};
-        if (!said.exchange(true))
-          fprintf(stderr, "[edt_hip] note: a %lld x %lld x %lld volume cannot be Z-sharded over %zu devices (slab records: "
-                          "sx, sy and sz <= 2048, >= 1 z-slice and >= 32 y-rows per device); device %d runs it alone\n",
-                  (long long)sx, (long long)sy, (long long)sz, devs.size(), devs[0]);
-      }
-      int prev = 0;
-      EDT_HIP_TRY(hipGetDevice(&prev));
-      if (prev != devs[0]) {
-        EDT_HIP_TRY(hipSetDevice(devs[0]));
-        rc = run_host(labels, dtype, ndim, sx, sy, sz, wx, wy, wz, flags | EDT_FLAG_SINGLE_DEVICE, output);
-        (void)hipSetDevice(prev);
-        return rc;
-      }
-    }
-  }
-
-  const size_t lbytes = (size_t)voxels * dtype_size(dtype);
-  const size_t obytes = (size_t)voxels * sizeof(float);
-  const size_t wbytes = edt_hip_workspace_bytes_flags(dtype, ndim, sx, sy, sz, flags);
-  const bool pooled = pool_enabled();
-  DevicePool *pool = pooled ? current_pool() : nullptr;
-  std::unique_lock<std::mutex> pool_lock;
-  if (pool) pool_lock = std::unique_lock<std::mutex>(pool->m);
-  DeviceBuf d_labels(pool), d_out(pool), d_ws(pool);
-  if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
-  if ((rc = d_out.alloc(obytes, pooled ? 1 : -1)) != EDT_OK) return rc;
-  if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
-  Prefault touch(output, obytes);  // the result pages, while the labels travel and the kernels run
-  EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
-  rc = run_device(d_labels.p, dtype, ndim, sx, sy, sz, wx, wy, wz, flags, (float *)d_out.p, d_ws.p,
-                  wbytes, nullptr);
-  if (rc != EDT_OK) return rc;
-  touch.join();
-  EDT_HIP_TRY(hipMemcpy(output, d_out.p, obytes, hipMemcpyDeviceToHost));
-  return EDT_OK;
-}
-
-
-// sdf / sdfsq on host buffers in ONE round trip (reference: src/edt.pyx:121-202, two transforms and a
-// subtraction on the host): labels up once, edt(labels), the background mask and edt(mask) on the device, the
-// difference down once.
-static int sdf_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx,
-                    float wy, float wz, int flags, float *output) {
-  int rc = check_shape(dtype, ndim, sx, sy, sz);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(ndim, wx, wy, wz)) != EDT_OK) return rc;
-  const int64_t voxels = sx * sy * sz;
-  if (voxels == 0) return EDT_OK;
-  if (!labels || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
-  if ((rc = require_device()) != EDT_OK) return rc;
-  ListedDevice on_listed_device;
-  if (env_force_generic()) flags |= EDT_FLAG_FORCE_GENERIC;
-  const size_t lbytes = (size_t)voxels * dtype_size(dtype), obytes = (size_t)voxels * sizeof(float);
-  const size_t wbytes = std::max(edt_hip_workspace_bytes_flags(dtype, ndim, sx, sy, sz, flags),
-                                 edt_hip_workspace_bytes_flags(EDT_U8, ndim, sx, sy, sz, flags));
-  const bool pooled = pool_enabled();
-  DevicePool *pool = pooled ? current_pool() : nullptr;
-  std::unique_lock<std::mutex> pool_lock;
-  if (pool) pool_lock = std::unique_lock<std::mutex>(pool->m);
-  DeviceBuf d_labels(pool), d_a(pool), d_ws(pool), d_mask(pool), d_b(pool);
-  if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
-  if ((rc = d_a.alloc(obytes, pooled ? 1 : -1)) != EDT_OK) return rc;
-  if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
-  if ((rc = d_mask.alloc((size_t)voxels, pooled ? 3 : -1)) != EDT_OK) return rc;
-  if ((rc = d_b.alloc(obytes, pooled ? 4 : -1)) != EDT_OK) return rc;
-  Prefault touch(output, obytes);
-  EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
-  rc = run_device(d_labels.p, dtype, ndim, sx, sy, sz, wx, wy, wz, flags, (float *)d_a.p, d_ws.p, wbytes, nullptr);
-  if (rc != EDT_OK) return rc;
-  rc = launch_is_background(dtype, d_labels.p, (uint8_t *)d_mask.p, voxels, nullptr);
-  if (rc != EDT_OK) return rc;
-  rc = run_device(d_mask.p, EDT_U8, ndim, sx, sy, sz, wx, wy, wz, flags, (float *)d_b.p, d_ws.p, wbytes, nullptr);
-  if (rc != EDT_OK) return rc;
-  rc = launch_subtract((const float *)d_a.p, (const float *)d_b.p, (float *)d_a.p, voxels, nullptr);
-  if (rc != EDT_OK) return rc;
-  touch.join();
-  EDT_HIP_TRY(hipMemcpy(output, d_a.p, obytes, hipMemcpyDeviceToHost));
-  return EDT_OK;
-}
-
-static int voxel_graph_host(const void *labels, int dtype, const uint8_t *graph, int ndim, int64_t sx,
-                            int64_t sy, int64_t sz, float wx, float wy, float wz, int black_border,
-                            float *output) {
-  int rc = check_shape(dtype, ndim, sx, sy, sz);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(ndim, wx, wy, wz)) != EDT_OK) return rc;
-  const int64_t voxels = sx * sy * sz;
-  if (voxels == 0) return EDT_OK;
-  if (!labels || !graph || !output) { set_error("null host pointer"); return EDT_ERR_BAD_ARG; }
-  if ((rc = require_device()) != EDT_OK) return rc;
-  ListedDevice on_listed_device;
-  const size_t lbytes = (size_t)voxels * dtype_size(dtype);
-  const size_t wbytes = edt_hip_voxel_graph_workspace_bytes(ndim, sx, sy, sz);
-  const bool pooled = pool_enabled();
-  DevicePool *pool = pooled ? current_pool() : nullptr;
-  std::unique_lock<std::mutex> pool_lock;
-  if (pool) pool_lock = std::unique_lock<std::mutex>(pool->m);
-  DeviceBuf d_labels(pool), d_graph(pool), d_ws(pool), d_out(pool);
-  if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
-  if ((rc = d_out.alloc((size_t)voxels * sizeof(float), pooled ? 1 : -1)) != EDT_OK) return rc;
-  if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
-  if ((rc = d_graph.alloc((size_t)voxels, pooled ? 3 : -1)) != EDT_OK) return rc;
-  Prefault touch(output, (size_t)voxels * sizeof(float));
-  EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
-  EDT_HIP_TRY(hipMemcpy(d_graph.p, graph, (size_t)voxels, hipMemcpyHostToDevice));
-  rc = edt_hip_edtsq_voxel_graph_device(d_labels.p, dtype, (const uint8_t *)d_graph.p, ndim, sx, sy, sz, wx, wy, wz,
-                                        black_border ? EDT_FLAG_BLACK_BORDER : 0, (float *)d_out.p, d_ws.p, wbytes,
-                                        nullptr);
-  if (rc != EDT_OK) return rc;
-  touch.join();
-  EDT_HIP_TRY(hipMemcpy(output, d_out.p, (size_t)voxels * sizeof(float), hipMemcpyDeviceToHost));
-  return EDT_OK;
-}
-
-// ---- Z-sharded phases ------------------------------------------------------------------------
-struct ShardPlan {
-  float *bufB = nullptr;
-  int32_t *stack = nullptr;
-  uint32_t *nz = nullptr, *rs = nullptr;
-  size_t bytes = 0;
-};
-
-static ShardPlan make_shard_plan(int64_t sx, int64_t sy, int64_t sz, void *ws) {
-  // sized for the larger of the two phases run on an (sx, sy, sz) block
-  ShardPlan p;
-  Carver c(ws);
-  const int64_t voxels = sx * sy * sz;
-  p.bufB = c.take<float>((size_t)voxels);
-  p.stack = c.take<int32_t>((size_t)voxels);
-  const AxisGeom gy = make_geom_y(sx, sy, sz), gz = make_geom_z(sx, sy, sz);
-  const size_t words = (size_t)std::max(gy.sx * gy.nbands * gy.nouter, gz.sx * gz.nbands * gz.nouter);
-  p.nz = c.take<uint32_t>(words);
-  p.rs = c.take<uint32_t>(words);
-  p.bytes = align_up(c.off, 256) + 256;
-  return p;
-}
-
-// ---- slab records: the fast variant of the two sharded phases (edt_shard.hip) -------------------
-static int64_t record_floats(int64_t sx, int64_t ylen) {
-  return ylen * sx + 2 * ceil_div(ylen, kBandRows) * sx;
-}
-
-// (records of 16-bit values, where every pass runs on the integer column kernel: the rows as packed 16-bit pairs)
-static int64_t record16_words(int64_t sx, int64_t ylen) {
-  return ylen * sx / 2 + 2 * ceil_div(ylen, kBandRows) * sx;
-}
-
-struct RecordPlan {
-  float *F = nullptr;                                      // pass 1 output of the slab (XY phase)
-  uint32_t *nz_y = nullptr, *ys_y = nullptr, *zs_y = nullptr;  // y-packed planes of the slab
-  uint32_t *nz_z = nullptr, *rs_z = nullptr;               // z-packed planes (Z phase)
-  BandScatter *table = nullptr;
-  uint32_t *q16_counts = nullptr, *q16_ids = nullptr;      // hand-over list of the integer column kernel (one phase per call)
-  uint32_t *ones_map = nullptr;                            // 16-bit records, Z phase: "every row of every tile is in the plane"
-  size_t bytes = 0;
-};
-
-// sized for either phase on an (sx, sy, sz) block
-static RecordPlan make_record_plan(int64_t sx, int64_t sy, int64_t sz, void *ws) {
-  RecordPlan p;
-  Carver c(ws);
-  const size_t wy = (size_t)(sx * ceil_div(sy, kBandRows) * sz);
-  const size_t wz = (size_t)(sx * ceil_div(sz, kBandRows) * sy);
-  p.F = c.take<float>((size_t)(sx * sy * sz));
-  p.nz_y = c.take<uint32_t>(wy);
-  p.ys_y = c.take<uint32_t>(wy);
-  p.zs_y = c.take<uint32_t>(wy);
-  p.nz_z = c.take<uint32_t>(wz);
-  p.rs_z = c.take<uint32_t>(wz);
-  p.table = c.take<BandScatter>(1);
-  p.q16_counts = c.take<uint32_t>(4);
-  p.q16_ids = c.take<uint32_t>((size_t)(ceil_div(sx, 16) * (ceil_div(std::max(sy, sz), 8) * 8)));
-  p.ones_map = c.take<uint32_t>((size_t)(ceil_div(sx, 32) * ceil_div(std::max(sy, sz), 32)));
-  p.bytes = align_up(c.off, 256) + 256;
-  return p;
-}
+const char *last_error_cstr() { return g_last_error.c_str(); }
 
 }  // namespace edt_amd
 
@@ -910,112 +500,11 @@ int edt_hip_device_count(void) {
   return n;
 }
 
-const char *edt_hip_last_error(void) { return g_last_error.c_str(); }
+const char *edt_hip_last_error(void) { return last_error_cstr(); }
 
 int edt_hip_index_form_exact(float wx, int64_t sx) { return (sx >= 1 && row_codes_exact(wx, sx)) ? 1 : 0; }
 
 const char *edt_hip_version(void) { return "edt_hip 0.1 (gfx950)"; }
-
-int edt_hip_squared_edt_1d_multi_seg(const void *labels, int dtype, float *dest, int64_t n,
-                                     int64_t stride, float anisotropy, int black_border) {
-  if (stride != 1) {
-    set_error("stride != 1 is not supported (no reference caller uses it)");
-    return EDT_ERR_UNSUPPORTED;
-  }
-  return run_host(labels, dtype, 1, n, 1, 1, anisotropy, 1.0f, 1.0f,
-                  black_border ? EDT_FLAG_BLACK_BORDER : 0, dest);
-}
-
-int edt_hip_edt2dsq(const void *labels, int dtype, int64_t sx, int64_t sy, float wx, float wy,
-                    int black_border, int /*parallel*/, float *output) {
-  return run_host(labels, dtype, 2, sx, sy, 1, wx, wy, 1.0f,
-                  black_border ? EDT_FLAG_BLACK_BORDER : 0, output);
-}
-
-int edt_hip_edt3dsq(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx,
-                    float wy, float wz, int black_border, int /*parallel*/, float *output) {
-  return run_host(labels, dtype, 3, sx, sy, sz, wx, wy, wz,
-                  black_border ? EDT_FLAG_BLACK_BORDER : 0, output);
-}
-
-int edt_hip_edt2d(const void *labels, int dtype, int64_t sx, int64_t sy, float wx, float wy,
-                  int black_border, int /*parallel*/, float *output) {
-  return run_host(labels, dtype, 2, sx, sy, 1, wx, wy, 1.0f,
-                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | EDT_FLAG_SQRT, output);
-}
-
-int edt_hip_edt3d(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx,
-                  float wy, float wz, int black_border, int /*parallel*/, float *output) {
-  return run_host(labels, dtype, 3, sx, sy, sz, wx, wy, wz,
-                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | EDT_FLAG_SQRT, output);
-}
-
-int edt_hip_binary_edtsq(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx,
-                         float wy, float wz, int black_border, int take_sqrt, float *output) {
-  if (ndim != 2 && ndim != 3) { set_error("binary route: ndim must be 2 or 3"); return EDT_ERR_BAD_ARG; }
-  return run_host(labels, dtype, ndim, sx, sy, sz, wx, wy, wz,
-                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (take_sqrt ? EDT_FLAG_SQRT : 0) | EDT_FLAG_BINARY_YZ,
-                  output);
-}
-
-int edt_hip_edt2dsq_batch(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t count, float wx, float wy,
-                          int black_border, int take_sqrt, float *output) {
-  return run_host(labels, dtype, 3, sx, sy, count, wx, wy, 1.0f,
-                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (take_sqrt ? EDT_FLAG_SQRT : 0) | EDT_FLAG_BATCH_2D,
-                  output);
-}
-
-int edt_hip_set_devices(const int *devices, int n_devices) {
-  if (n_devices < 0 || (n_devices > 0 && !devices)) { set_error("bad device list"); return EDT_ERR_BAD_ARG; }
-  const int have = edt_hip_device_count();
-  for (int i = 0; i < n_devices; ++i)
-    if (devices[i] < 0 || devices[i] >= have) { set_error("device ordinal out of range"); return EDT_ERR_BAD_ARG; }
-  std::lock_guard<std::mutex> lock(g_devices_mutex);
-  g_devices.assign(devices, devices + n_devices);
-  return EDT_OK;
-}
-
-int edt_hip_edt3dsq_multi(const void *labels, int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
-                          float wz, int black_border, int take_sqrt, float *output, const int *devices,
-                          int n_devices) {
-  int rc = check_shape(dtype, 3, sx, sy, sz);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(3, wx, wy, wz)) != EDT_OK) return rc;
-  if (sx == 0 || sy == 0 || sz == 0) return EDT_OK;
-  if (!labels || !output || !devices || n_devices < 1) { set_error("null pointer / empty device list"); return EDT_ERR_BAD_ARG; }
-  if ((rc = require_device()) != EDT_OK) return rc;
-  const int have = edt_hip_device_count();
-  for (int i = 0; i < n_devices; ++i)
-    if (devices[i] < 0 || devices[i] >= have) { set_error("device ordinal out of range"); return EDT_ERR_BAD_ARG; }
-  const int flags = (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (take_sqrt ? EDT_FLAG_SQRT : 0);
-  if (n_devices >= 2 && !multi_supported(dtype, sx, sy, sz, n_devices)) {
-    set_error("this volume cannot be Z-sharded over " + std::to_string(n_devices) + " devices (slab records: sx, sy "
-              "and sz <= 2048, at least one z-slice and 32 y-rows per device; edt_hip_multi_supported tells)");
-    return EDT_ERR_UNSUPPORTED;
-  }
-  if (n_devices == 1) {  // a list of one: that device does it
-    int prev = 0;
-    EDT_HIP_TRY(hipGetDevice(&prev));
-    EDT_HIP_TRY(hipSetDevice(devices[0]));
-    rc = run_host(labels, dtype, 3, sx, sy, sz, wx, wy, wz, flags | EDT_FLAG_SINGLE_DEVICE, output);
-    (void)hipSetDevice(prev);
-    return rc;
-  }
-  Prefault touch(output, (size_t)(sx * sy * sz) * sizeof(float));
-  touch.join();
-  return run_multi(labels, dtype, sx, sy, sz, wx, wy, wz, flags, output, devices, n_devices);
-}
-
-int edt_hip_multi_supported(int dtype, int64_t sx, int64_t sy, int64_t sz, int n_devices) {
-  if (check_shape(dtype, 3, sx, sy, sz) != EDT_OK) return 0;
-  return (n_devices == 1 || multi_supported(dtype, sx, sy, sz, n_devices)) ? 1 : 0;
-}
-
-int edt_hip_sdf(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx, float wy,
-                float wz, int black_border, int squared, float *output) {
-  return sdf_host(labels, dtype, ndim, sx, sy, sz, wx, wy, wz,
-                  (black_border ? EDT_FLAG_BLACK_BORDER : 0) | (squared ? 0 : EDT_FLAG_SQRT), output);
-}
 
 size_t edt_hip_workspace_bytes_flags(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
   if (check_shape(dtype, ndim, sx, sy, sz) != EDT_OK) return 0;
@@ -1032,22 +521,6 @@ int edt_hip_edtsq_device(const void *d_labels, int dtype, int ndim, int64_t sx, 
                          void *d_workspace, size_t workspace_bytes, void *stream) {
   return run_device(d_labels, dtype, ndim, sx, sy, sz, wx, wy, wz, flags, d_output, d_workspace,
                     workspace_bytes, (hipStream_t)stream);
-}
-
-int edt_hip_release_cache(void) {
-  multi_release();
-  int cur = 0;
-  if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return EDT_OK; }
-  for (int d = 0; d < kMaxDevices; ++d) {
-    std::lock_guard<std::mutex> lock(g_pools[d].m);
-    bool any = false;
-    for (int i = 0; i < DevicePool::kSlots; ++i) any = any || g_pools[d].p[i] != nullptr;
-    if (!any) continue;
-    if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
-    g_pools[d].release();
-  }
-  (void)hipSetDevice(cur);
-  return EDT_OK;
 }
 
 int edt_hip_set_debug_mode(int mode) {
@@ -1085,434 +558,12 @@ const char *edt_hip_get_pass_name(int index) {
   return g_log.names[index].c_str();
 }
 
-int edt_hip_edt2dsq_voxel_graph(const void *labels, int dtype, const uint8_t *graph, int64_t sx,
-                                int64_t sy, float wx, float wy, int black_border,
-                                float *workspace) {
-  return voxel_graph_host(labels, dtype, graph, 2, sx, sy, 1, wx, wy, 2.0f, black_border, workspace);
-}
-
-int edt_hip_edt3dsq_voxel_graph(const void *labels, int dtype, const uint8_t *graph, int64_t sx,
-                                int64_t sy, int64_t sz, float wx, float wy, float wz,
-                                int black_border, float *workspace) {
-  return voxel_graph_host(labels, dtype, graph, 3, sx, sy, sz, wx, wy, wz, black_border, workspace);
-}
-
-size_t edt_hip_shard_workspace_bytes(int dtype, int64_t sx, int64_t sy, int64_t sz) {
-  if (check_shape(dtype, 3, sx, sy, sz) != EDT_OK) return 0;
-  if (sx == 0 || sy == 0 || sz == 0) return 256;
-  return make_shard_plan(sx, sy, sz, nullptr).bytes;
-}
-
-int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype, int64_t sx,
-                            int64_t sy, int64_t sz_local, float wx, float wy, int flags,
-                            float *d_partial, uint8_t *d_zflags, void *d_workspace,
-                            size_t workspace_bytes, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_shape(dtype, 3, sx, sy, sz_local);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(2, wx, wy, 1.0f)) != EDT_OK) return rc;
-  if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
-  if (!d_labels || !d_partial || !d_zflags) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
-  ShardPlan p = make_shard_plan(sx, sy, sz_local, d_workspace);
-  if (!d_workspace || workspace_bytes < p.bytes) {
-    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
-    return EDT_ERR_BAD_ARG;
-  }
-  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  const bool force_generic = (flags & EDT_FLAG_FORCE_GENERIC) != 0;
-  AxisGeom gy = make_geom_y(sx, sy, sz_local);
-  gy.fmin = edt_hip_field_floor(wx, wx);  // (pass Y reads the results of pass X: AxisGeom::fmin)
-  const bool tiled_x = !force_generic && (row_pass_tiled_supported(sx) || row_pass_wave_supported(dtype, sx, sy, sz_local));
-  const bool tiled_y = !force_generic && column_inplace_supported(gy);
-  float *xout = tiled_y ? d_partial : p.bufB;  // the tiled y pass runs in place
-  if (tiled_x) {
-    rc = launch_row_bits(dtype, d_labels, xout, p.nz, p.rs, nullptr, sx, sy, sz_local, wx, bb, bb ? 0 : 1,
-                         stream);
-    if (rc != EDT_OK) return rc;
-  } else {
-    // rows of more than 2048 voxels: the line pipeline (a thread per voxel), its scratch borrowed from the hull
-    // stacks, which only the size-agnostic column pass uses -- later on this stream
-    if (!force_generic && rows_line_workspace_bytes(sx, sy * sz_local) <= (size_t)(sx * sy * sz_local) * sizeof(int32_t))
-      rc = launch_rows_line_pass(dtype, d_labels, xout, sx, sy * sz_local, wx, bb, bb ? 0 : 1, p.stack, stream);
-    else
-      rc = launch_row_pass_serial(dtype, d_labels, xout, sx, sy * sz_local, wx, bb, bb ? 0 : 1, 0, stream);
-    if (rc != EDT_OK) return rc;
-    rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz, p.rs, gy, stream);
-    if (rc != EDT_OK) return rc;
-  }
-  if (tiled_y) rc = launch_column_inplace(d_partial, p.nz, p.rs, gy, wy, bb, 0, stream);
-  else rc = launch_column_pass_serial(p.bufB, d_partial, p.nz, p.rs, p.stack, gy, wy, bb, 0, stream);
-  if (rc != EDT_OK) return rc;
-  return launch_zflags(dtype, d_labels, d_halo, d_zflags, sx * sy, sz_local, stream);
-}
-
-int edt_hip_shard_z_device(float *d_partial, const uint8_t *d_zflags, int64_t sx, int64_t sy_local,
-                           int64_t sz, float wz, int flags, void *d_workspace,
-                           size_t workspace_bytes, void *stream_) {
-  return edt_hip_shard_z_device_ex(d_partial, d_zflags, sx, sy_local, sz, wz, 0.0f, flags, d_workspace, workspace_bytes,
-                                   stream_);
-}
-
-int edt_hip_shard_z_device_ex(float *d_partial, const uint8_t *d_zflags, int64_t sx, int64_t sy_local,
-                              int64_t sz, float wz, float field_floor, int flags, void *d_workspace,
-                              size_t workspace_bytes, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(1, wz, 1.0f, 1.0f)) != EDT_OK) return rc;
-  if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
-  if (!d_partial || !d_zflags) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
-  ShardPlan p = make_shard_plan(sx, sy_local, sz, d_workspace);
-  if (!d_workspace || workspace_bytes < p.bytes) {
-    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
-    return EDT_ERR_BAD_ARG;
-  }
-  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
-  AxisGeom gz = make_geom_z(sx, sy_local, sz);
-  gz.fmin = field_floor > 0.0f ? field_floor : 0.0f;  // (AxisGeom::fmin; NaN and negatives: unknown)
-  rc = launch_bits_from_flags(d_zflags, p.nz, p.rs, gz, stream);
-  if (rc != EDT_OK) return rc;
-  if (!(flags & EDT_FLAG_FORCE_GENERIC) && column_inplace_supported(gz))
-    return launch_column_inplace(d_partial, p.nz, p.rs, gz, wz, bb, epi, stream);
-  rc = launch_column_pass_serial(d_partial, p.bufB, p.nz, p.rs, p.stack, gz, wz, bb, epi, stream);
-  if (rc != EDT_OK) return rc;
-  EDT_HIP_TRY(hipMemcpyAsync(d_partial, p.bufB, (size_t)(sx * sy_local * sz) * sizeof(float),
-                             hipMemcpyDeviceToDevice, stream));
-  return EDT_OK;
-}
-
 // min(fl32(wx*wx), fl32(wy*wy)): what every non-zero value of a field is at least after passes X and Y (run_device has
 // the argument); 0 where a voxel size is not a positive finite number
 float edt_hip_field_floor(float wx, float wy) {
   const float a = wx * wx, b = wy * wy;
   if (!(a > 0.0f) || !(b > 0.0f) || !(a < INFINITY) || !(b < INFINITY)) return 0.0f;
   return a < b ? a : b;
-}
-
-int edt_hip_shard_records_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
-  if (dtype_size(dtype) == 0 || sx < 1 || sy < 1 || sz < 1) return 0;
-  if (g_debug_mode & (32 | 64)) return 0;  // diagnostics: forced fallback kernels
-  // pass 1 by the register-resident row kernel (two waves per row beyond 1024 voxels), both column passes by the wave kernel
-  return (sx <= 2048 && row_pass_wave_supported(dtype, sx, sy, sz) && sy <= 2048 && sz <= 2048) ? 1 : 0;
-}
-
-size_t edt_hip_shard_record_floats(int64_t sx, int64_t y_rows) {
-  if (sx < 0 || y_rows < 0) return 0;
-  return (size_t)record_floats(sx, y_rows);
-}
-
-size_t edt_hip_shard_records_workspace_bytes(int dtype, int64_t sx, int64_t sy, int64_t sz) {
-  if (check_shape(dtype, 3, sx, sy, sz) != EDT_OK) return 0;
-  if (sx == 0 || sy == 0 || sz == 0) return 256;
-  return make_record_plan(sx, sy, sz, nullptr).bytes;
-}
-
-int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, int dtype, int64_t sx,
-                                    int64_t sy, int64_t sz_local, float wx, float wy, int flags,
-                                    int nparts, const int64_t *y_splits, void *const *d_blocks,
-                                    void *d_workspace, size_t workspace_bytes, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_shape(dtype, 3, sx, sy, sz_local);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(2, wx, wy, 1.0f)) != EDT_OK) return rc;
-  if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
-  if (!d_labels || !y_splits || !d_blocks || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
-  if (!edt_hip_shard_records_supported(dtype, sx, sy, sz_local)) {
-    set_error("slab records need sx <= 2048 and sy <= 2048 (use edt_hip_shard_xy_device)");
-    return EDT_ERR_UNSUPPORTED;
-  }
-  if (y_splits[0] != 0 || y_splits[nparts] != sy) { set_error("y_splits must run from 0 to sy"); return EDT_ERR_BAD_ARG; }
-  for (int h = 0; h < nparts; ++h) {
-    if (y_splits[h + 1] <= y_splits[h] || (y_splits[h] % kBandRows) != 0) {
-      set_error("y_splits must be increasing multiples of 32 (the last one is sy)");
-      return EDT_ERR_BAD_ARG;
-    }
-    if (!d_blocks[h]) { set_error("null destination block"); return EDT_ERR_BAD_ARG; }
-  }
-  if (g_log.enabled.load(std::memory_order_relaxed)) {
-    std::lock_guard<std::mutex> lock(g_log_mutex);
-    if (g_log.used > 2048) log_begin_call();  // nobody is reading the log
-  }
-  RecordPlan p = make_record_plan(sx, sy, sz_local, d_workspace);
-  if (!d_workspace || workspace_bytes < p.bytes) {
-    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
-    return EDT_ERR_BAD_ARG;
-  }
-  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  AxisGeom gy = make_geom_y(sx, sy, sz_local);
-  gy.fmin = edt_hip_field_floor(wx, wx);  // (pass Y reads the results of pass X: AxisGeom::fmin)
-  // destination map: every 32-row band of y lies inside one part
-  BandScatter sc;
-  bool aligned = (sx % 4) == 0;
-  for (int b = 0, h = 0; b < BandScatter::kBands; ++b) {
-    if (b >= gy.nbands) { sc.rows[b] = nullptr; sc.bits[b] = nullptr; sc.ostride[b] = 0; sc.plane[b] = 0; continue; }
-    while ((int64_t)b * kBandRows >= y_splits[h + 1]) ++h;
-    const int64_t ys = y_splits[h], ylen = y_splits[h + 1] - ys, words = ceil_div(ylen, kBandRows);
-    float *blk = static_cast<float *>(d_blocks[h]);
-    sc.rows[b] = blk + ((int64_t)b * kBandRows - ys) * sx;
-    sc.bits[b] = reinterpret_cast<uint32_t *>(blk + ylen * sx) + ((int64_t)b - ys / kBandRows) * sx;
-    sc.ostride[b] = record_floats(sx, ylen);
-    sc.plane[b] = words * sx;
-    aligned = aligned && (reinterpret_cast<uintptr_t>(blk) % 16) == 0;
-  }
-  if (!aligned && (sx % 4) == 0) { set_error("destination blocks must be 16-byte aligned"); return EDT_ERR_BAD_ARG; }
-  // (index form of pass 1 where the voxel size allows it, see run_device: the slab's pass-1 buffer then holds 16-bit
-  // indices in its first half)
-  const bool index_form = (sx % 4) == 0 && !(g_debug_mode & 0x100000) && row_codes_exact(wx, sx);
-  uint16_t *codes = index_form ? reinterpret_cast<uint16_t *>(p.F) : nullptr;
-  {
-    ScopedPass t("x_pass", stream);
-    rc = launch_row_pass_wave(dtype, d_labels, p.F, p.nz_y, p.ys_y, p.zs_y, sx, sy, sz_local, wx, bb,
-                              bb ? 0 : 1, stream, d_halo, codes);
-    if (rc != EDT_OK) return rc;
-  }
-  {
-    ScopedPass t("pack_bits", stream);
-    rc = launch_pack_record_bits(p.nz_y, p.zs_y, sc, p.table, sx, gy.nbands, sz_local, stream);
-    if (rc != EDT_OK) return rc;
-  }
-  ScopedPass t("y_pass", stream);
-  // the integer column kernel where wx and wy share a quantum (edt_colq16.hip), the tiles it refuses to the fp32 kernel
-  TileList list;
-  {
-    const float w2[2] = {wx, wy};
-    float q = 1.0f;
-    uint32_t a[3];
-    if (!(g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000)) && q16_quantum(w2, 2, &q, a) &&
-        column_pass_q16_supported(gy) && column_pass_wave_supported(gy) && aligned) {
-      EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, 4 * sizeof(uint32_t), stream));
-      rc = launch_column_pass_q16(p.F, codes, p.ys_y, gy, q, a[1], a[0], bb, 0, p.q16_counts, p.q16_ids, stream, p.table);
-      if (rc != EDT_OK) return rc;
-      list.count = p.q16_counts;
-      list.ids = p.q16_ids;
-    }
-  }
-  if (index_form)
-    return launch_column_pass_wave_codes(p.F, codes, p.nz_y, p.ys_y, gy, wy, bb, 0, wx, bb ? 0 : 1, stream, p.table, list);
-  return launch_column_pass_wave(p.F, p.nz_y, p.ys_y, gy, wy, bb, 0, stream, p.table, ColumnOut(), list);
-}
-
-int edt_hip_shard_z_records_device(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz,
-                                   int flags, void *d_workspace, size_t workspace_bytes, void *stream_) {
-  return edt_hip_shard_z_records_device_ex(d_records, sx, sy_local, sz, wz, 0.0f, flags, d_workspace, workspace_bytes,
-                                           stream_);
-}
-
-static int shard_z_records(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz, float field_floor,
-                           const float *w3, int flags, void *d_workspace, size_t workspace_bytes, void *stream_);
-
-int edt_hip_shard_z_records_device_ex(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz,
-                                      float field_floor, int flags, void *d_workspace, size_t workspace_bytes,
-                                      void *stream_) {
-  return shard_z_records(d_records, sx, sy_local, sz, wz, field_floor, nullptr, flags, d_workspace, workspace_bytes, stream_);
-}
-
-int edt_hip_shard_z_records_device_w(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wx, float wy,
-                                     float wz, int flags, void *d_workspace, size_t workspace_bytes, void *stream_) {
-  const float w3[3] = {wx, wy, wz};
-  return shard_z_records(d_records, sx, sy_local, sz, wz, edt_hip_field_floor(wx, wy), w3, flags, d_workspace,
-                         workspace_bytes, stream_);
-}
-
-// w3 != nullptr: the caller named all three voxel sizes -- the integer column kernel where they share a quantum
-static int shard_z_records(float *d_records, int64_t sx, int64_t sy_local, int64_t sz, float wz, float field_floor,
-                           const float *w3, int flags, void *d_workspace, size_t workspace_bytes, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(1, wz, 1.0f, 1.0f)) != EDT_OK) return rc;
-  if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
-  if (!d_records) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
-  if (!edt_hip_shard_records_supported(EDT_U8, sx, sy_local, sz)) {
-    set_error("slab records need sx <= 2048 and sz <= 2048 (use edt_hip_shard_z_device)");
-    return EDT_ERR_UNSUPPORTED;
-  }
-  RecordPlan p = make_record_plan(sx, sy_local, sz, d_workspace);
-  if (!d_workspace || workspace_bytes < p.bytes) {
-    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
-    return EDT_ERR_BAD_ARG;
-  }
-  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
-  const int64_t rec = record_floats(sx, sy_local), words = ceil_div(sy_local, kBandRows);
-  const uint32_t *nz_y = reinterpret_cast<const uint32_t *>(d_records + sy_local * sx);
-  {
-    ScopedPass t("z_bits", stream);
-    rc = launch_bits_transpose_yz(nz_y, nz_y + words * sx, p.nz_z, p.rs_z, sx, sy_local, sz, stream, rec);
-    if (rc != EDT_OK) return rc;
-  }
-  AxisGeom gz;  // z-columns of the record buffer: consecutive z are one record apart
-  gz.sx = sx; gz.n = sz; gz.stride = rec; gz.nouter = sy_local; gz.outer_stride = sx;
-  gz.nbands = ceil_div(sz, kBandRows);
-  gz.fmin = field_floor > 0.0f ? field_floor : 0.0f;
-  ScopedPass t("z_pass", stream);
-  TileList list;
-  if (w3 != nullptr) {
-    float q = 1.0f;
-    uint32_t a[3];
-    if (!(g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000)) && q16_quantum(w3, 3, &q, a) &&
-        column_pass_q16_supported(gz) && column_pass_wave_supported(gz) && (reinterpret_cast<uintptr_t>(d_records) % 16) == 0) {
-      EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, 4 * sizeof(uint32_t), stream));
-      rc = launch_column_pass_q16(d_records, nullptr, p.rs_z, gz, q, a[2], a[0], bb, epi, p.q16_counts, p.q16_ids, stream);
-      if (rc != EDT_OK) return rc;
-      list.count = p.q16_counts;
-      list.ids = p.q16_ids;
-    }
-  }
-  return launch_column_pass_wave(d_records, p.nz_z, p.rs_z, gz, wz, bb, epi, stream, nullptr, ColumnOut(), list);
-}
-
-// ---- slab records of 16-bit values ---------------------------------------------------------------------------------------
-// Where the three voxel sizes share a quantum (edt_colq16.hip) and both column axes fit the integer kernel, the Y pass's
-// results are integers N < 2^16 (in quanta): a record then carries its rows as 16-bit values -- 2.25 bytes per voxel over
-// the links instead of 4.25 -- and the Z phase reads them as they are.  A tile the integer kernel cannot take (values beyond
-// 16 bits, rows without a boundary) has no 16-bit form: the XY phase COUNTS such tiles in *d_refused (a device counter the
-// caller zeroes and reads; it accumulates over calls) and leaves their rows unspecified -- a caller that finds it non-zero
-// repeats the step with the fp32 records above (edt/distributed.py does).
-static bool records16_common_ok(int64_t sx, float wx, float wy, float wz) {
-  if (sx % 4 != 0 || (g_debug_mode & (16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x100000 | 0x8000000 | 0x10000000))) return false;
-  if (!row_codes_exact(wx, sx)) return false;
-  const float w3[3] = {wx, wy, wz};
-  float q = 1.0f;
-  uint32_t a[3];
-  return q16_quantum(w3, 3, &q, a);
-}
-// the XY phase of a slab of sz_local slices / the Z phase of a slab of sy_local rows: the scan axis on the integer kernel
-static bool records16_xy_ok(int dtype, int64_t sx, int64_t sy, int64_t sz_local, float wx, float wy, float wz) {
-  if (!edt_hip_shard_records_supported(dtype, sx, sy, sz_local) || !records16_common_ok(sx, wx, wy, wz)) return false;
-  const AxisGeom gy = make_geom_y(sx, sy, sz_local);
-  return column_pass_q16_supported(gy) && column_pass_wave_supported(gy);
-}
-static bool records16_z_ok(int64_t sx, int64_t sy_local, int64_t sz, float wx, float wy, float wz) {
-  if (!edt_hip_shard_records_supported(EDT_U8, sx, sy_local, sz) || !records16_common_ok(sx, wx, wy, wz)) return false;
-  const AxisGeom gz = make_geom_z(sx, sy_local, sz);
-  return column_pass_q16_supported(gz) && column_pass_wave_supported(gz);
-}
-
-int edt_hip_shard_records16_supported(int dtype, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz) {
-  if (dtype_size(dtype) == 0 || sx < 1 || sy < 1 || sz < 1) return 0;
-  // (whatever part of z or y a rank holds, its scan axis is whole: sy for the XY phase, sz for the Z phase)
-  return (records16_xy_ok(dtype, sx, sy, 1, wx, wy, wz) && records16_z_ok(sx, 32, sz, wx, wy, wz)) ? 1 : 0;
-}
-
-size_t edt_hip_shard_record16_words(int64_t sx, int64_t y_rows) {
-  if (sx < 0 || y_rows < 0 || sx % 2 != 0) return 0;
-  return (size_t)record16_words(sx, y_rows);
-}
-
-int edt_hip_shard_xy_records16_device(const void *d_labels, const void *d_halo, int dtype, int64_t sx, int64_t sy,
-                                      int64_t sz_local, float wx, float wy, float wz, int flags, int nparts,
-                                      const int64_t *y_splits, void *const *d_blocks, uint32_t *d_refused, void *d_workspace,
-                                      size_t workspace_bytes, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_shape(dtype, 3, sx, sy, sz_local);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(2, wx, wy, 1.0f)) != EDT_OK) return rc;
-  if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
-  if (!d_labels || !y_splits || !d_blocks || !d_refused || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
-  if (y_splits[0] != 0 || y_splits[nparts] != sy) { set_error("y_splits must run from 0 to sy"); return EDT_ERR_BAD_ARG; }
-  for (int h = 0; h < nparts; ++h) {
-    if (y_splits[h + 1] <= y_splits[h] || (y_splits[h] % kBandRows) != 0) {
-      set_error("y_splits must be increasing multiples of 32 (the last one is sy)");
-      return EDT_ERR_BAD_ARG;
-    }
-    // (4-byte stores of packed pairs and bit words; the Z phase reads 8 bytes at a time: records are an even number of words)
-    if (!d_blocks[h] || (reinterpret_cast<uintptr_t>(d_blocks[h]) % 8) != 0) {
-      set_error("destination blocks must be non-null and 8-byte aligned");
-      return EDT_ERR_BAD_ARG;
-    }
-  }
-  const float w3[3] = {wx, wy, wz};
-  float q = 1.0f;
-  uint32_t a[3];
-  AxisGeom gy = make_geom_y(sx, sy, sz_local);
-  if (!records16_xy_ok(dtype, sx, sy, sz_local, wx, wy, wz) || !q16_quantum(w3, 3, &q, a)) {
-    set_error("16-bit slab records do not apply to these extents / voxel sizes (edt_hip_shard_records16_supported)");
-    return EDT_ERR_UNSUPPORTED;
-  }
-  RecordPlan p = make_record_plan(sx, sy, sz_local, d_workspace);
-  if (!d_workspace || workspace_bytes < p.bytes) {
-    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
-    return EDT_ERR_BAD_ARG;
-  }
-  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  // destination map in 4-byte words: a record = ylen * sx / 2 words of 16-bit pairs, then the two bit planes
-  BandScatter sc;
-  for (int b = 0, h = 0; b < BandScatter::kBands; ++b) {
-    if (b >= gy.nbands) { sc.rows[b] = nullptr; sc.bits[b] = nullptr; sc.ostride[b] = 0; sc.plane[b] = 0; continue; }
-    while ((int64_t)b * kBandRows >= y_splits[h + 1]) ++h;
-    const int64_t ys = y_splits[h], ylen = y_splits[h + 1] - ys, words = ceil_div(ylen, kBandRows);
-    float *blk = static_cast<float *>(d_blocks[h]);
-    sc.rows[b] = blk + (((int64_t)b * kBandRows - ys) * sx) / 2;
-    sc.bits[b] = reinterpret_cast<uint32_t *>(blk + ylen * sx / 2) + ((int64_t)b - ys / kBandRows) * sx;
-    sc.ostride[b] = record16_words(sx, ylen);
-    sc.plane[b] = words * sx;
-  }
-  uint16_t *codes = reinterpret_cast<uint16_t *>(p.F);
-  {
-    ScopedPass t("x_pass", stream);
-    rc = launch_row_pass_wave(dtype, d_labels, p.F, p.nz_y, p.ys_y, p.zs_y, sx, sy, sz_local, wx, bb, bb ? 0 : 1, stream,
-                              d_halo, codes);
-    if (rc != EDT_OK) return rc;
-  }
-  {
-    ScopedPass t("pack_bits", stream);
-    rc = launch_pack_record_bits(p.nz_y, p.zs_y, sc, p.table, sx, gy.nbands, sz_local, stream);
-    if (rc != EDT_OK) return rc;
-  }
-  ScopedPass t("y_pass", stream);
-  // (plane: any non-null value selects the 16-bit output; the destinations are the table's)
-  return launch_column_pass_q16(p.F, codes, p.ys_y, gy, q, a[1], a[0], bb, 0, d_refused, nullptr, stream, p.table, codes);
-}
-
-int edt_hip_shard_z_records16_device(const void *d_records, float *d_out, int64_t sx, int64_t sy_local, int64_t sz, float wx,
-                                     float wy, float wz, int flags, void *d_workspace, size_t workspace_bytes, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
-  if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(1, wz, 1.0f, 1.0f)) != EDT_OK) return rc;
-  if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
-  if (!d_records || !d_out) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
-  const float w3[3] = {wx, wy, wz};
-  float q = 1.0f;
-  uint32_t a[3];
-  AxisGeom gz = make_geom_z(sx, sy_local, sz);  // the dense output: z-columns one (sy_local, sx) slice apart
-  gz.fmin = edt_hip_field_floor(wx, wy);
-  if (!records16_z_ok(sx, sy_local, sz, wx, wy, wz) || !q16_quantum(w3, 3, &q, a) ||
-      ((reinterpret_cast<uintptr_t>(d_records) | reinterpret_cast<uintptr_t>(d_out)) % 16) != 0) {
-    set_error("16-bit slab records do not apply to these extents / voxel sizes (edt_hip_shard_records16_supported)");
-    return EDT_ERR_UNSUPPORTED;
-  }
-  RecordPlan p = make_record_plan(sx, sy_local, sz, d_workspace);
-  if (!d_workspace || workspace_bytes < p.bytes) {
-    set_error("shard workspace too small: need " + std::to_string(p.bytes) + " bytes");
-    return EDT_ERR_BAD_ARG;
-  }
-  const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
-  const int64_t rec = record16_words(sx, sy_local), words = ceil_div(sy_local, kBandRows);
-  const uint32_t *base = static_cast<const uint32_t *>(d_records);
-  const uint32_t *nz_y = base + sy_local * sx / 2;
-  {
-    ScopedPass t("z_bits", stream);
-    rc = launch_bits_transpose_yz(nz_y, nz_y + words * sx, p.nz_z, p.rs_z, sx, sy_local, sz, stream, rec);
-    if (rc != EDT_OK) return rc;
-  }
-  ScopedPass t("z_pass", stream);
-  // every row out of the records (16-bit elements: consecutive z are 2 * rec of them apart), results to the dense array; a
-  // tile beyond THIS pass's limits gets its rows written there as fp32 values and goes to the fp32 kernel, in place
-  EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, 4 * sizeof(uint32_t), stream));
-  const int map_words = (int)ceil_div(sz, 32);
-  EDT_HIP_TRY(hipMemsetAsync(p.ones_map, 0xFF, (size_t)(ceil_div(sx, 32) * map_words) * sizeof(uint32_t), stream));
-  uint16_t *plane = reinterpret_cast<uint16_t *>(const_cast<void *>(d_records));
-  rc = launch_column_pass_q16(d_out, nullptr, p.rs_z, gz, q, a[2], a[0], bb, epi, p.q16_counts, p.q16_ids, stream, nullptr, plane,
-                              p.ones_map, map_words, nullptr, 2 * rec, sx);
-  if (rc != EDT_OK) return rc;
-  TileList list;
-  list.count = p.q16_counts;
-  list.ids = p.q16_ids;
-  return launch_column_pass_wave(d_out, p.nz_z, p.rs_z, gz, wz, bb, epi, stream, nullptr, ColumnOut(), list);
 }
 
 int edt_hip_subtract_device(const float *d_a, const float *d_b, float *d_out, int64_t count,

@@ -23,7 +23,7 @@
 //               grids --: blocks of 16 rows whose even rows are evaluated, 16 pairs x four such blocks per wave);
 //   results   = converted once at the end, (float)N * q (exact), optional correctly rounded sqrt, 8-byte stores (16 lanes =
 //               one 128-byte line per row); or the 16-bit values themselves, over the tile's indices (the plane between
-//               passes Y and Z); or the rows of the slab records of the Z-sharded path, fp32 or 16-bit (edt_api.hip).
+//               passes Y and Z); or the rows of the slab records of the Z-sharded path, fp32 or 16-bit (edt_shard_api.hip).
 #include "edt_common.h"
 #include "edt_kernels.h"
 
@@ -58,7 +58,7 @@ struct Q16Args {
   uint16_t *plane;
   uint32_t *map;          // (slab records: all ones where every row is read from the plane; nullptr where a plane is written and no map kept)
   int map_words;          // words per x-tile
-  int64_t pst, p_outer;   // the plane's own row / outer strides in 16-bit elements (slab records: edt_api.hip), else g's
+  int64_t pst, p_outer;   // the plane's own row / outer strides in 16-bit elements (slab records: edt_shard_api.hip), else g's
   // output stride 2 (S = 2: the doubled grids of the voxel-graph transform) only: nullptr = the even rows go to their places
   // in F; else row r of column (x, outer o) goes to compact[x + o * c_outer + (r / 2) * c_row2]   (edt_kernels.h: ColumnOut)
   float *compact;
@@ -718,7 +718,7 @@ static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q
 // a: c_d = a * d^2 quanta of this pass; ain: quanta per squared index of pass X (codes != nullptr).
 // plane / map != nullptr: with codes -- the results go to the 16-bit plane (= codes, in place) and the tile's bit is set in
 // map; without -- the rows are taken from the plane wherever map says so (the pass after such a pass).
-// Slab records of 16-bit values (edt_api.hip): with codes, a scatter table AND a plane (any non-null value) the results go to
+// Slab records of 16-bit values (edt_shard_api.hip): with codes, a scatter table AND a plane (any non-null value) the results go to
 // the table's destinations as 16-bit rows, refused tiles are only counted (ids == nullptr); without codes, a map of ones
 // and plane_stride > 0 every row is read from the plane at its own strides (16-bit elements) and F is only written.
 int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,

@@ -3,7 +3,7 @@
 // north_star: "host code stays C++ ... volumes shard along Z across the 8 GPUs of one node".  edt/distributed.py is
 // the one-process-per-GPU form over torch.distributed / RCCL; this file is the same partition for a C++ (or
 // ctypes / Cython) host that just calls edt::edt<T>() and owns no communicator: a host thread per device, the
-// slab-record phases of edt_api.hip on every device, and the ONE exchange between them as peer-to-peer copies
+// slab-record phases of edt_shard_api.hip on every device, and the ONE exchange between them as peer-to-peer copies
 // over xGMI (hipMemcpyPeerAsync: every ordered pair of devices is its own transfer on its own link).
 //
 //   device g:  labels[z in Z_g] (+ the slice below: the one-slice halo)  --H2D-->

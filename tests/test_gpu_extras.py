@@ -101,7 +101,7 @@ def test_sdf_single_round_trip(edt_gpu, oracle_port):
 
 
 def test_large_result_buffer_is_prefaulted_correctly(edt_gpu, oracle_port):
-    """>= 32 MiB results are first-touched by helper threads while the labels travel (csrc/edt_api.hip:
+    """>= 32 MiB results are first-touched by helper threads while the labels travel (csrc/edt_host.hip:
     Prefault): the bytes that come back are still exactly the transform."""
     lab = voronoi_labels((320, 256, 128), nseeds=300, seed=9, upsample=4)     # 40 MiB result
     want = oracle_port.edtsq(lab, (1.0, 1.0, 2.0), False)

@@ -853,6 +853,11 @@ def main():
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, args.config),
         "kernel_ms": summary["kernel_ms"],
+        # every pass against its own model (the `kernel` above is simply the longest one: X and Z are within 2 % of each other
+        # on the headline, so which of them it is can change from run to run)
+        "passes": {k: {"algorithmic_bytes_per_voxel": bpv[k], "ms": round(kernels[k], 4),
+                       "model_GBs": round(bpv[k] * head.vox / (kernels[k] * 1e-3) / 1e9, 1),
+                       "frac": round(bpv[k] * head.vox / (kernels[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k in kernels if k in bpv},
         "whole_job_algorithmic_GBs": summary["whole_job_algorithmic_GBs"],
         "whole_job_frac": summary["whole_job_frac"],  # 32 B/voxel model over ms_per_step
     }

@@ -34,6 +34,21 @@
 #define EDT_LANE_MEMBER __device__ __forceinline__
 #include "edt_colq16_lane.h"
 
+// Fill loads.  Round 5 (tools/halfline_probe.hip, profiles/r05_halfline_probe.txt): a 32-column tile reads 16-bit rows as 64-byte
+// pieces -- HALF lines whose other half belongs to the neighbouring tile, dispatched right behind on the same XCD.  A
+// non-temporal load lets the line go once it has served its 64 bytes, and the neighbour fetches it AGAIN: 340 MB from memory for a
+// 268 MB array, 54.5 us against 37.9 us with plain loads.  Plain loads for the 16-bit rows (indices, plane): cfg2 0.634 -> 0.591 ms,
+// cfg3 0.728 -> 0.715.  The fp32 rows (whole 128-byte pieces, 16 bytes per lane) stay non-temporal: pass Z of the 1024^3
+// volume 2.39 ms against 2.60 with plain loads.  (EDT_Q16_NT_FILL=1 brings the non-temporal ones back for A/B runs.)
+#ifndef EDT_Q16_NT_FILL
+#define EDT_Q16_NT_FILL 0
+#endif
+#if EDT_Q16_NT_FILL
+#define EDT_Q16_FILL_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define EDT_Q16_FILL_LOAD(p) (*(p))
+#endif
+
 namespace edt_amd {
 
 struct Q16Args {
@@ -154,7 +169,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       for (int j = 0; j < 16; ++j) {
         const int row = i0 + RPS * j + r_in;
         kk[j] = (v2u){0u, 0u};
-        if (row < n && col_ok) kk[j] = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(src + (int64_t)row * st));
+        if (row < n && col_ok) kk[j] = EDT_Q16_FILL_LOAD(reinterpret_cast<const v2u *>(src + (int64_t)row * st));
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -199,7 +214,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
         if (p16) {
           in16 |= 1u << j;
           if (col_ok) {
-            const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(src16 + (int64_t)row * pst));
+            const v2u v = EDT_Q16_FILL_LOAD(reinterpret_cast<const v2u *>(src16 + (int64_t)row * pst));
             raw[j][0] = v[0];
             raw[j][1] = v[1];
           }

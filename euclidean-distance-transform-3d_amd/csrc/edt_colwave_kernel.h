@@ -1,4 +1,12 @@
 #pragma once
+#ifndef EDT_Q16_NT_FILL
+#define EDT_Q16_NT_FILL 0
+#endif
+#if EDT_Q16_NT_FILL
+#define EDT_COLWAVE_CODE_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define EDT_COLWAVE_CODE_LOAD(p) (*(p))
+#endif
 // edt_colwave_kernel.h -- wave-autonomous LDS-tiled column pass (passes 2 and 3) for gfx950: the kernel
 // template and its per-wave-shape launcher.  Included by edt_colwave_cw*.hip, ONE translation unit (= one
 // device code object) per wave shape CW: the kernel is ~85 KB of code, more than the instruction cache,
@@ -378,7 +386,9 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
         const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
         q[j] = (v2u){0u, 0u};
         if (row < n && gc < cols_left)
-          q[j] = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(Ctile + (int64_t)row * st + gc));
+          // (plain loads: the indices of a 32-column tile are 64-byte HALF lines -- a non-temporal load lets the line go and
+          // the neighbouring tile fetches it again: edt_colq16.hip, profiles/r05_halfline_probe.txt)
+          q[j] = EDT_COLWAVE_CODE_LOAD(reinterpret_cast<const v2u *>(Ctile + (int64_t)row * st + gc));
       }
     }
   }

@@ -221,6 +221,13 @@ class DeviceRun:
         self.vox = shape[0] * shape[1] * shape[2]
         self.out = torch.empty(shape[::-1], dtype=torch.float32, device=dev)
         self.plan = device.Plan(shape, 2 if self.label_bytes == 4 else 0, dev)
+        # EDT_BENCH_ALTERNATE=1 (a probe, not the headline): two copies of the labels and two outputs taken in turn, so that
+        # nothing a step reads or writes was touched by the step before it -- what a cache-policy change is worth when the
+        # same volume is NOT transformed again and again
+        self.alt = None
+        if os.environ.get("EDT_BENCH_ALTERNATE") == "1":
+            self.alt = (self.labels.clone(), torch.empty_like(self.out))
+        self.turn = 0
 
     def host_labels(self):
         """The labels as an (sx, sy, sz) Fortran array on the host (a view of the device tensor's bytes when the
@@ -231,6 +238,11 @@ class DeviceRun:
         return self.labels.cpu().numpy().view(dt).T
 
     def step(self, generic=False):
+        if self.alt is not None:
+            self.turn ^= 1
+            if self.turn:
+                self.plan.run(self.alt[0], self.an, black_border=self.bb, sqrt=False, out=self.alt[1], force_generic=generic)
+                return
         self.plan.run(self.labels, self.an, black_border=self.bb, sqrt=False, out=self.out, force_generic=generic)
 
     def measure(self, steps, warmup, generic=False):

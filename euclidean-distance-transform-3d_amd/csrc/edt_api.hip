@@ -272,7 +272,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
   const int want_sqrt = (flags & EDT_FLAG_SQRT) ? 1 : 0;
-  const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0);
+  const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0) | kEpiStream;
   // a stack of 2-D images is a volume without a z pass
   if ((flags & EDT_FLAG_BATCH_2D) && ndim != 3) { set_error("EDT_FLAG_BATCH_2D needs ndim = 3 (sz = image count)"); return EDT_ERR_BAD_ARG; }
   const bool zpass = ndim == 3 && !(flags & EDT_FLAG_BATCH_2D);

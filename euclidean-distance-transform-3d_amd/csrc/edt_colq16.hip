@@ -441,7 +441,15 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   #pragma unroll
         for (int j = 0; j < kB; ++j) out[j] = (v2f){sqrtf(out[j].x), sqrtf(out[j].y)};
       }
-      if (redo == 0u) {
+      if (redo == 0u && (epi & kEpiStream)) {
+        // (the call's results: streamed -- edt_common.h: kEpiStream)
+  #pragma unroll
+        for (int j = 0; j < kB; ++j) {
+          const int row = L.p0 + S * j;
+          if (row < n && store_ok && lane_on)
+            __builtin_nontemporal_store(out[j], reinterpret_cast<__attribute__((address_space(1))) v2f *>(gdst + (int64_t)(row / S) * dstep));
+        }
+      } else if (redo == 0u) {
   #pragma unroll
         for (int j = 0; j < kB; ++j) {
           const int row = L.p0 + S * j;

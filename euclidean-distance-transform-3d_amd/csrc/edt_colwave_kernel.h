@@ -166,8 +166,13 @@ __device__ EDT_BRUTE_INLINE void brute_tile(float *tile, const uint32_t *alive, 
   auto *gdst = (__attribute__((address_space(1))) float *)dst0;
   // (bit 10 of epi: dstride is the distance between EVEN rows of a compact destination)
   const bool compact = (epi & 0x400) != 0;
+  // (bit 2 of epi = kEpiStream: the call's results, streamed)
+  const bool stream = (epi & kEpiStream) != 0;
   auto store = [&](int row, float v) {
-    if (row < n && colok) gdst[(int64_t)(compact ? row >> 1 : row) * dstride] = v;
+    if (row < n && colok) {
+      if (stream) __builtin_nontemporal_store(v, &gdst[(int64_t)(compact ? row >> 1 : row) * dstride]);
+      else gdst[(int64_t)(compact ? row >> 1 : row) * dstride] = v;
+    }
   };
   // (bit 8 of epi: only the even rows are evaluated and written -- the doubled grids of the voxel-graph transform;
   // carried in an existing argument: the kernel around this call is sensitive to its signature, see hull path)
@@ -550,7 +555,9 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
       const int row = io_row<CW, 4>(i, lane), gc = io_gcol<CW, 4>(i, lane);
       if (row < n && gc < cols_left) {
         const v4f v = *reinterpret_cast<const v4f *>(tile + io_lds_word<CW, 4>(i, lane));
-        EDT_TILE_STORE(reinterpret_cast<v4f *>(Ftile + (int64_t)row * st + gc), v);
+        // (kEpiStream: the call's results -- streamed, edt_common.h; wave-uniform)
+        if (epi & kEpiStream) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(Ftile + (int64_t)row * st + gc));
+        else EDT_TILE_STORE(reinterpret_cast<v4f *>(Ftile + (int64_t)row * st + gc), v);
       }
     }
   } else {
@@ -626,7 +633,7 @@ static int launch_wave_cbx_sc(float *F, const uint32_t *nz, const uint32_t *rs, 
                         (!XF || reinterpret_cast<uintptr_t>(xf.codes) % 8 == 0);
   if (tiles > 0x7FFFFFFF) { set_error("too many tiles"); return EDT_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL((k_column_pass_wave<CW, BB, XF, SC>), dim3((unsigned)tiles), dim3(64 * TC / CW), lds, stream,
-                     F, nz, rs, g, w, (int)tiles_x, epi & 3, debug_mode(), aligned16, xf, scatter, ba);
+                     F, nz, rs, g, w, (int)tiles_x, epi & (3 | kEpiStream), debug_mode(), aligned16, xf, scatter, ba);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }

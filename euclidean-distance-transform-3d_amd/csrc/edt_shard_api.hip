@@ -146,7 +146,7 @@ int edt_hip_shard_z_device_ex(float *d_partial, const uint8_t *d_zflags, int64_t
     return EDT_ERR_BAD_ARG;
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
+  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0) | kEpiStream;  // (the Z phase writes the call's results)
   AxisGeom gz = make_geom_z(sx, sy_local, sz);
   gz.fmin = field_floor > 0.0f ? field_floor : 0.0f;  // (AxisGeom::fmin; NaN and negatives: unknown)
   rc = launch_bits_from_flags(d_zflags, p.nz, p.rs, gz, stream);
@@ -304,7 +304,7 @@ static int shard_z_records(float *d_records, int64_t sx, int64_t sy_local, int64
     return EDT_ERR_BAD_ARG;
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
+  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0) | kEpiStream;  // (the Z phase writes the call's results)
   const int64_t rec = record_floats(sx, sy_local), words = ceil_div(sy_local, kBandRows);
   const uint32_t *nz_y = reinterpret_cast<const uint32_t *>(d_records + sy_local * sx);
   {
@@ -460,7 +460,7 @@ int edt_hip_shard_z_records16_device(const void *d_records, float *d_out, int64_
     return EDT_ERR_BAD_ARG;
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
-  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0);
+  const int epi = (bb ? 0 : kEpiToInf) | ((flags & EDT_FLAG_SQRT) ? kEpiSqrt : 0) | kEpiStream;  // (the Z phase writes the call's results)
   const int64_t rec = record16_words(sx, sy_local), words = ceil_div(sy_local, kBandRows);
   const uint32_t *base = static_cast<const uint32_t *>(d_records);
   const uint32_t *nz_y = base + sy_local * sx / 2;

@@ -519,7 +519,7 @@ static int vg_native_t(const void *labels_, const uint8_t *graph, int ndim, int6
                        (int)sx, (int)sy, (int)(ndim == 3 ? sz : 1), (int)Y2, ndim == 3 ? 1 : 0, (int)nbY, bb);
   }
   EDT_HIP_TRY(hipGetLastError());
-  const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0);
+  const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0) | kEpiStream;  // (the last pass writes the call's results: streamed)
   AxisGeom gy;
   gy.sx = sx; gy.n = Y2; gy.stride = sx; gy.nouter = Z2; gy.outer_stride = sx * Y2; gy.nbands = nbY;
   // Only the even rows of the doubled columns are read again: by the z pass (in place), or -- last pass -- by the

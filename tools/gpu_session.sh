@@ -5,6 +5,8 @@
 #   prof <tag> <cfg>        rocprofv3 --kernel-trace --stats of bench.py --config <cfg>  -> gpurun_out/prof_<tag>_<cfg>
 #   pmc <tag> <cfg>         PMC passes (each its own rocprofv3 run: FETCH_SIZE, WRITE_SIZE, two SQ groups)
 #                           -> gpurun_out/pmc_<tag><cfg>_summary.txt  (tools/pmc_summary.py)
+#   ab <tag> <cfg> [K=V..]  one bench line of <cfg> (40 steps) under the given environment (EDT_HIP_DEBUG_MODE=..., EDT_HIP_LIB=a variant
+#                           build, EDT_BENCH_ALTERNATE=1 ...) -> gpurun_out/ab_<tag>.json: the A/B runs of round 5
 #   final                   what the driver runs at round end: whole GPU tier, smoke(), the default bench line
 #   fuzz <n>                randomised parity in the four tile-choice / pass-X modes
 # Steps are separated by `--`, e.g.
@@ -30,6 +32,19 @@ except Exception as e:
     print(c, "ERR", e, open(f"gpurun_out/bench_{c}.err").read()[-600:])
 PY
       done ;;
+    ab)  # ab <tag> <cfg> [KEY=VALUE ...]
+      local tag=$1 cfg=$2; shift 2
+      env "$@" python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary --config $cfg > gpurun_out/ab_${tag}.json 2> gpurun_out/ab_${tag}.err
+      python - $tag <<'PY'
+import json, sys
+t = sys.argv[1]
+try:
+    d = json.load(open(f"gpurun_out/ab_{t}.json"))
+    print(t, d["ms_per_step"], d["roofline"]["kernel_ms"], "frac32B", d["roofline"]["whole_job_frac"], d["config"]["output_verified"])
+except Exception as e:
+    print(t, "ERR", e, open(f"gpurun_out/ab_{t}.err").read()[-800:])
+PY
+      ;;
     benchsz)  # benchsz <size> <cfg>...: the same at another edge length (cfg4 at 1024)
       local sz=$1; shift
       for c in "$@"; do

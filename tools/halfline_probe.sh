@@ -1,4 +1,6 @@
 #!/bin/bash
+# tools/halfline_probe (times) + its FETCH_SIZE per kernel under rocprofv3 -> gpurun_out/r05_halfline_probe.txt
+# (through gpurun from the repo root; build first: hipcc --offload-arch=gfx950 -O3 -o tools/halfline_probe tools/halfline_probe.hip)
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p gpurun_out
 ./tools/halfline_probe | tee gpurun_out/r05_halfline_probe.txt

@@ -305,15 +305,20 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     q16 = q16_quantum(ws3, (ndim == 3 && !(flags & EDT_FLAG_BATCH_2D)) ? 3 : 2, &q16_q, q16_a);
   }
   constexpr int kQ16Off = 16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000;
-  // When can the integer kernel refuse no tile at all?  With a black border every row of pass X has a boundary and its
-  // index is at most ceil(sx / 2); in the index form the values are integers by construction (k^2 * ax quanta), and so
-  // are the integer kernel's own results; so if ceil(sx / 2)^2 * ax is within the range of a pass (its 16-bit form, or the
-  // wide form: q16_value_limit) and everything that pass reads was written by pass X or by an integer pass that could
-  // not refuse either, the fp32 launch over the hand-over list has nothing to do and is not made -- nor is the list's
-  // counter zeroed.  (debug bit 0x20000000: always launch.)
-  const uint64_t q16_vmax = (uint64_t)ceil_div(sx, 2) * (uint64_t)ceil_div(sx, 2) * q16_a[0];
-  auto q16_cannot_refuse = [&](int axis) {
-    return q16 && bb && !(g_debug_mode & 0x20000000) && q16_vmax <= q16_value_limit(q16_q, q16_a[axis]);
+  // When can the integer kernel refuse no tile at all?  In the index form the values are integers by construction (k^2 * ax
+  // quanta; 0xFFFF = no boundary in the row = +inf, which the wide form carries where the columns are short enough -- round 5),
+  // and so are the integer kernel's own results.  With a black border every row has a boundary on both sides: an index is at
+  // most ceil(sx / 2), and no pass raises a value.  Without, a run may touch one edge of the volume -- an index is at most sx
+  // -- and a row that was +inf after pass X leaves pass Y with a border parabola or a sum N[j] + ay * d^2: at most sy^2 * ay
+  // more.  So if that bound is within the range of a pass (its 16-bit form, or the wide form: q16_value_limit) and everything
+  // the pass reads was written by pass X or by an integer pass that could not refuse either, the fp32 launch over the
+  // hand-over list has nothing to do and is not made -- nor is the list's counter zeroed.  (debug bit 0x20000000: always
+  // launch.)
+  const uint64_t q16_kmax = bb ? (uint64_t)ceil_div(sx, 2) : (uint64_t)sx;
+  const uint64_t q16_vmax_x = q16_kmax * q16_kmax * q16_a[0];
+  auto q16_cannot_refuse = [&](int axis, const AxisGeom &g) {
+    const uint64_t vmax = q16_vmax_x + ((axis == 2 && !bb) ? (uint64_t)sy * (uint64_t)sy * q16_a[1] : 0ull);
+    return q16 && !(g_debug_mode & 0x20000000) && vmax <= q16_value_limit(q16_q, q16_a[axis], g.n, bb);
   };
   // F in place (codes == nullptr) or from the 16-bit indices of pass X; returns the list for the fp32 launch that follows
   // (launched: the integer kernel ran; sure: the caller vouches for what the pass reads -- see above)
@@ -327,7 +332,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
       return EDT_OK;
     // (the id array was sized for these tile counts: make_plan)
     if (ceil_div(g.sx, 16) * (ceil_div(g.nouter, 8) * 8) > p.q16_id_capacity) return EDT_OK;
-    sure = sure && q16_cannot_refuse(axis);
+    sure = sure && q16_cannot_refuse(axis, g);
     if (!sure && !q16_counts_zeroed) {
       EDT_HIP_TRY(hipMemsetAsync(p.q16_counts, 0, kQ16Slots * sizeof(uint32_t), stream));
       q16_counts_zeroed = true;

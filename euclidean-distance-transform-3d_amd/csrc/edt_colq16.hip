@@ -64,6 +64,7 @@ struct Q16Args {
   // wide form (output stride 2, 16-bit slab records, quanta whose odd part leaves no room).
   uint32_t nlimw, dmaxw, kmaxw;
   uint32_t fwmax_bits;    // bit pattern of (float)nlimw * q (exact)
+  uint32_t inf_ok;        // the wide form carries +inf (no black border, short enough columns: edt_colq16_lane.h, q16_wide_range)
   uint32_t *count;        // tiles handed to the fp32 kernel: *count of them ...
   uint32_t *ids;          // ... their tile ids (outer index * x-tiles + x-tile) in the fp32 kernel's geometry:
   int list_cols;          // its tiles are 32 columns wide, or 16 (axes of more than 512 rows: two ids per refused tile)
@@ -82,6 +83,10 @@ struct Q16Args {
 enum : int { kQ16InF32 = 0, kQ16InCodes = 1, kQ16InMixed = 2 };
 
 namespace {
+
+// what a wide image word holds for an index of pass X / a value of the 16-bit plane: 0xFFFF is +inf in either
+__device__ __forceinline__ uint32_t q16_index_value(uint32_t k, uint32_t ain) { return k == 0xFFFFu ? edt_q16::kInfW : k * k * ain; }
+__device__ __forceinline__ uint32_t q16_plane_value(uint32_t v) { return v == 0xFFFFu ? edt_q16::kInfW : v; }
 
 __host__ __device__ constexpr int q16_lds_words(int NB) {
   // image (NB bands of 32 rows + 2 kPad rows, 16 words each) + run-start plane + lo/hi plane + break masks (16 pairs x 6
@@ -162,7 +167,8 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   if constexpr (IN == kQ16InCodes) {
     v2u kk[16];
     const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
-    const pk kmaxpk = pk_both(qa.kmax), kmaxwpk = pk_both(qa.kmaxw), ainpk = pk_both(qa.ain);
+    const pk kmaxpk = pk_both(qa.kmax), kmaxw1pk = pk_both(qa.kmaxw + qa.inf_ok), ainpk = pk_both(qa.ain);
+    const pk infadd = qa.inf_ok ? 0x00010001u : 0u;
     {
       constexpr int i0 = 0;
 #pragma unroll
@@ -175,11 +181,11 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       for (int j = 0; j < 16; ++j) {
         const int row = i0 + RPS * j + r_in;
         if (row < nb32) {
-          // k > kmax: the tile has no 16-bit form (k^2 may have wrapped: never used); k > kmaxw (also the "no boundary"
-          // index 0xFFFF): no wide form either
+          // k > kmax: the tile has no 16-bit form (k^2 may have wrapped: never used); kmaxw < k < 0xFFFF: no wide form either
           ov01 |= pk_subs(kk[j][0], kmaxpk);
           ov23 |= pk_subs(kk[j][1], kmaxpk);
-          bad |= (pk_subs(kk[j][0], kmaxwpk) | pk_subs(kk[j][1], kmaxwpk)) != 0u;
+          // (0xFFFF -- no boundary in the row: +inf -- wraps to 0 and passes where the wide form carries +inf)
+          bad |= (pk_subs(pk_add(kk[j][0], infadd), kmaxw1pk) | pk_subs(pk_add(kk[j][1], infadd), kmaxw1pk)) != 0u;
           v2u v = {pk_mul(pk_mul(kk[j][0], kk[j][0]), ainpk), pk_mul(pk_mul(kk[j][1], kk[j][1]), ainpk)};
           if (row >= n) v = (v2u){~0u, ~0u};
           *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = v;
@@ -250,7 +256,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
             for (int c = 0; c < 4; ++c) {
               ovq |= (u[c] > qa.nlim ? 1u : 0u) << c;
               uint32_t uw;  // (u[c] stays the clamped value: it must not spill into the neighbour's half of the image word)
-              bad |= !wide_value(__uint_as_float(raw[j][c]), qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, uw);
+              bad |= !wide_value(__uint_as_float(raw[j][c]), qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, uw) || (uw == kInfW && !qa.inf_ok);
             }
           } else {
             bad |= !(err == 0.0f);
@@ -533,7 +539,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
                   const int row = RPS * (jb + j) + r_in;
                   if (row < nb32) {
                     const uint32_t k0 = kk[j][0] & 0xFFFFu, k1 = kk[j][0] >> 16, k2 = kk[j][1] & 0xFFFFu, k3 = kk[j][1] >> 16;
-                    v4u v = (v4u){k0 * k0 * qa.ain, k1 * k1 * qa.ain, k2 * k2 * qa.ain, k3 * k3 * qa.ain};
+                    v4u v = (v4u){q16_index_value(k0, qa.ain), q16_index_value(k1, qa.ain), q16_index_value(k2, qa.ain), q16_index_value(k3, qa.ain)};
                     if (row >= n) v = (v4u){kInfW, kInfW, kInfW, kInfW};
                     *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (cg & 3)) = v;
                   }
@@ -553,7 +559,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
                   if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
                   if (p16) {
                     const v2u pv = *reinterpret_cast<const v2u *>(qa.plane + x0 + o * qa.p_outer + c0 + (int64_t)row * qa.pst);
-                    v = (v4u){pv[0] & 0xFFFFu, pv[0] >> 16, pv[1] & 0xFFFFu, pv[1] >> 16};
+                    v = (v4u){q16_plane_value(pv[0] & 0xFFFFu), q16_plane_value(pv[0] >> 16), q16_plane_value(pv[1] & 0xFFFFu), q16_plane_value(pv[1] >> 16)};
                   } else {
                     const v4f f = *reinterpret_cast<const v4f *>(F + x0 + o * g.outer_stride + c0 + (int64_t)row * st);
   #pragma unroll
@@ -587,10 +593,9 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
               bool p16 = false;
               if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
               if constexpr (IN == kQ16InCodes) {
-                const uint32_t k = qa.codes[x0 + o * g.outer_stride + c + (int64_t)row * st];
-                v = k * k * qa.ain;
+                v = q16_index_value(qa.codes[x0 + o * g.outer_stride + c + (int64_t)row * st], qa.ain);
               } else if (p16) {
-                v = qa.plane[x0 + o * qa.p_outer + c + (int64_t)row * qa.pst];
+                v = q16_plane_value(qa.plane[x0 + o * qa.p_outer + c + (int64_t)row * qa.pst]);
               } else {
                 (void)wide_value(F[x0 + o * g.outer_stride + c + (int64_t)row * st], qa.q, qa.rq, qa.nlimw, qa.fwmax_bits, v);
               }
@@ -654,9 +659,12 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
             dst = F + x0 + o * g.outer_stride + colc;
           }
           auto *gdst = (__attribute__((address_space(1))) float *)dst;
+          // (+inf: "no boundary anywhere" -- FLT_MAX between the passes, +INF behind the last one: tofinite / toinfinite,
+          // src/edt.hpp:39-53)
+          const float finf = (epi & kEpiToInf) ? INFINITY : FLT_MAX;
           float out[kB];
 #pragma unroll
-          for (int j = 0; j < kB; ++j) out[j] = (float)best[j] * qa.q;
+          for (int j = 0; j < kB; ++j) out[j] = best[j] >= kInfW ? finf : (float)best[j] * qa.q;
           if (epi & kEpiSqrt) {
 #pragma unroll
             for (int j = 0; j < kB; ++j) out[j] = sqrtf(out[j]);
@@ -761,10 +769,11 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
   qa.kmax = kmax;
   {
     // the wide form's range (nlimw == nlim: there is none)
-    const uint32_t dw = (debug_mode() & 0x20000000) ? 0u : edt_q16::q16_dmax_wide(a, q);
-    const uint64_t nw = (uint64_t)a * dw * dw;
-    qa.dmaxw = nw > qa.nlim ? dw : qa.dmax;
-    qa.nlimw = nw > qa.nlim ? (uint32_t)nw : qa.nlim;
+    edt_q16::WideRange wr = {0u, 0u, false};
+    if (!(debug_mode() & 0x20000000)) wr = edt_q16::q16_wide_range(a, q, g.n, bb != 0, qa.nlim);
+    qa.dmaxw = wr.nlim ? wr.dmax : qa.dmax;
+    qa.nlimw = wr.nlim ? wr.nlim : qa.nlim;
+    qa.inf_ok = wr.inf ? 1u : 0u;
     uint32_t kw = kmax;
     while ((uint64_t)(kw + 1) * (kw + 1) * ain <= qa.nlimw && kw < 65534u) ++kw;
     qa.kmaxw = kw;
@@ -793,12 +802,14 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
             : launch_q16_b<false>(F, rs, g, qa, in, o16, epi, stream, scatter, ostride);
 }
 
-// the largest value (in quanta) a tile of a pass with c_d = a * d^2 may hold without being handed to the fp32 kernel
-uint32_t q16_value_limit(float q, uint32_t a) {
+// the largest value (in quanta) a tile of a pass with c_d = a * d^2 over columns of n rows may hold without being handed to the
+// fp32 kernel, whatever else it holds (without a black border: +inf as well -- 0 where the pass does not carry that)
+uint32_t q16_value_limit(float q, uint32_t a, int64_t n, int bb) {
   const uint32_t d16 = edt_q16::q16_dmax(a), n16 = a * d16 * d16;
-  const uint32_t dw = (debug_mode() & 0x20000000) ? 0u : edt_q16::q16_dmax_wide(a, q);
-  const uint64_t nw = (uint64_t)a * dw * dw;
-  return nw > n16 ? (uint32_t)nw : n16;
+  edt_q16::WideRange wr = {0u, 0u, false};
+  if (!(debug_mode() & 0x20000000)) wr = edt_q16::q16_wide_range(a, q, n, bb != 0, n16);
+  if (!bb) return wr.inf ? wr.nlim : 0u;
+  return wr.nlim ? wr.nlim : n16;
 }
 
 // the quantum of a call (edt_colq16_lane.h: quantum_of), host side

@@ -71,6 +71,7 @@ EDT_LANE int q16_clz(uint32_t v) { return __builtin_clz(v); }
 EDT_LANE int q16_ctz(uint32_t v) { return __builtin_ctz(v); }
 #define EDT_Q16_ANY(cond) (__ballot(cond) != 0ull)
 #define EDT_Q16_UNROLL _Pragma("unroll")
+#define EDT_Q16_ROLLED _Pragma("unroll 1")
 // (keeps the compiler from re-deriving a select mask as two 16-bit compares, two selects and a byte permute)
 #define EDT_Q16_OPAQUE(x) asm volatile("" : "+v"(x))
 #else
@@ -98,6 +99,7 @@ EDT_LANE int q16_clz(uint32_t v) { return __builtin_clz(v); }
 EDT_LANE int q16_ctz(uint32_t v) { return __builtin_ctz(v); }
 #define EDT_Q16_ANY(cond) (cond)
 #define EDT_Q16_UNROLL
+#define EDT_Q16_ROLLED
 #define EDT_Q16_OPAQUE(x) ((void)0)
 #endif
 
@@ -229,7 +231,31 @@ EDT_HOSTFN uint32_t q16_dmax_wide(uint32_t a, float q) {
   return (uint64_t)a * d * d <= cap ? d : 0u;  // 0: not even one row (the wide form does not apply)
 }
 
-// N = f / q as a 32-bit integer, exact or not at all (wide form; also the verdict on a value the 16-bit conversion of
+// The wide form's range for one pass: values up to nlim, border distances up to dmax (nlim == 0: no wide form beyond the 16-bit
+// one, whose limit is nlim16).  Without a black border a tile may hold +inf -- rows without any boundary so far -- and such a
+// row's result is a border parabola or a sum N[j] + a * d^2 that no value of its own bounds: +inf is carried (inf) only where
+// every distance of the column is within dmax (n <= dmax: no clamp of a border distance, no window constant beyond the range)
+// and the largest such sum, nlim + a * n^2, is still exact in fp32 -- for which nlim is lowered as far as that takes.
+struct WideRange { uint32_t dmax, nlim; bool inf; };
+EDT_HOSTFN WideRange q16_wide_range(uint32_t a, float q, int64_t n, bool bb, uint32_t nlim16) {
+  WideRange R = {0u, 0u, false};
+  const uint32_t dw = q16_dmax_wide(a, q);
+  const uint64_t cap = ((1ull << 24) - 1) / q16_odd_of(q);
+  uint64_t nw = (uint64_t)a * dw * dw;
+  if (nw <= nlim16) return R;
+  if (!bb && n <= (int64_t)dw) {
+    const uint64_t an2 = (uint64_t)a * (uint64_t)n * (uint64_t)n;
+    if (an2 < cap && cap - an2 > nlim16) {
+      nw = nw < cap - an2 ? nw : cap - an2;
+      R.inf = true;
+    }
+  }
+  R.dmax = dw;
+  R.nlim = (uint32_t)nw;
+  return R;
+}
+
+// N = f / q as a 32-bit integer (kInfW for FLT_MAX), exact or not at all (wide form; also the verdict on a value the 16-bit conversion of
 // edt_colq16.hip had to clamp): false unless f == N * q for an N <= nlimw.  fwmax_bits: bit pattern of (float)nlimw * q
 // (non-negative floats order like their bit patterns; negative values, NaN and +inf lie above every one of them).
 // f * rq is within 2 of N (rq and the product are rounded); the remainder f - u0 * q is a small multiple of q, exact as
@@ -238,6 +264,9 @@ EDT_LANE bool wide_value(float f, float q, float rq, uint32_t nlimw, uint32_t fw
   uint32_t fb;
   memcpy(&fb, &f, sizeof(fb));
   u = 0u;
+  // FLT_MAX: "no boundary along the earlier axes" (tofinite, src/edt.hpp:39-45) -- +inf here: such a site never wins, a voxel
+  // that sees nothing else comes out as FLT_MAX again / as +INF behind the last pass (toinfinite, :47-53)
+  if (fb == 0x7F7FFFFFu) { u = kInfW; return true; }
   if (fb > fwmax_bits) return false;
   const float u0 = rintf(f * rq);
   const float r = fmaf(-u0, q, f);
@@ -348,7 +377,10 @@ struct Steps {
   }
   // c_d as a (packed) constant (wave-uniform: scalar arithmetic), +inf once it leaves the range
   EDT_LANE_MEMBER pk cpk(int d) const {
-    if constexpr (W) return X::cval((uint64_t)a * (uint32_t)(d * d));
+    // (wide form: beyond the column's length there are only +inf rows -- c_d = +inf there ends a window whose minima are +inf
+    // themselves, rows without any boundary, which no finite c_d ever reaches; as a scalar select, not as the loop's bound: a
+    // variable bound tips the kernel into scratch)
+    if constexpr (W) return d > L.n ? kInfW : X::cval((uint64_t)a * (uint32_t)(d * d));
     const uint32_t c = a * (uint32_t)(d * d);
     return pk_both(c < kInf ? c : kInf);
   }
@@ -514,8 +546,11 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
     } else {
       EDT_Q16_UNROLL
       for (int j = 0; j < NR; j += S) {
-        const pk dm = X::vmin(X::vmin(X::add(dl, X::both((uint32_t)(j + 1))), X::add(dr, X::both((uint32_t)(NR - j)))), dmaxpk);
-        best[j / S] = X::vmin(w[K + j], X::mul(X::mul(dm, dm), apk));
+        const pk dnear = X::vmin(X::add(dl, X::both((uint32_t)(j + 1))), X::add(dr, X::both((uint32_t)(NR - j))));
+        const pk dm = X::vmin(dnear, dmaxpk);
+        pk bord = X::mul(X::mul(dm, dm), apk);
+        if constexpr (W && !BB) bord = dnear >= kFar ? kInfW : bord;  // (see the general form below)
+        best[j / S] = X::vmin(w[K + j], bord);
       }
     }
   } else {
@@ -538,9 +573,13 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
     for (int j = NR - 1; j >= 0; --j) {
       dr = X::add(dr, one);
       if (j % S == 0) {
-        const pk dm = X::vmin(X::vmin(dlv[j / S], dr), dmaxpk);
+        const pk dnear = X::vmin(dlv[j / S], dr);
+        const pk dm = X::vmin(dnear, dmaxpk);
         // a * min(d, dmax)^2 fits the range; a tile on this path holds no value above a * dmax^2, so the clamp changes no minimum
-        const pk bord = X::mul(X::mul(dm, dm), apk);
+        pk bord = X::mul(X::mul(dm, dm), apk);
+        // (wide form, no black border: a run without a border on either side has no border parabola at all -- its rows may be
+        // +inf, "no boundary along the earlier axes", and must stay so; the 16-bit form never sees such a tile)
+        if constexpr (W && !BB) bord = dnear >= kFar ? kInfW : bord;
         best[j / S] = X::vmin(w[K + j], bord);
       }
       dr = dr & ~mask[j];  // (a set bit is a real row: the border site of the rows below it)
@@ -560,7 +599,10 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
     uint32_t D1 = (uint32_t)r1 + 1u;
     D1 = D1 < L.dmax + 1u ? D1 : L.dmax + 1u;
     const uint64_t cD = (uint64_t)L.a * D1 * D1;
-    if (!EDT_Q16_ANY(X::subs(bmax, X::cval(cD)) != 0u)) return;
+    // (wide form: a column without any break holds one value in all its rows -- nothing can improve anything, whatever the
+    // minima are; this is what keeps a column of +inf rows, "no boundary anywhere", from running a window to the column's end)
+    const bool flat_column = W && r1 >= (1 << 20);
+    if (!EDT_Q16_ANY(!flat_column && X::subs(bmax, X::cval(cD)) != 0u)) return;
     if constexpr (!W && S == 1) {
       // The 64-block view of the break bits ends 248 rows away.  A lane that saw no break in it looks at the whole column
       // before the wave runs hundreds of steps over a flat one (round 5: columns of 65025 = 255^2 next to the middle of a

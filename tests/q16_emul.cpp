@@ -59,10 +59,12 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
         const int col = wcol[c];
         uint32_t v = 0;
         if (col < 32) {
-          if (plane_in && row_in_plane[row]) v = plane_in[(int64_t)row * sx + x0 + col];
-          else if (codes) {
+          if (plane_in && row_in_plane[row]) {
+            v = plane_in[(int64_t)row * sx + x0 + col];
+            if (v == 0xFFFFu) v = kInfW;  // (+inf)
+          } else if (codes) {
             const uint32_t k = codes[(int64_t)row * sx + x0 + col];
-            v = k * k * ain;
+            v = k == 0xFFFFu ? kInfW : k * k * ain;  // (0xFFFF: no boundary in the row)
           } else {
             (void)wide_value(Fin[(int64_t)row * sx + x0 + col], q, 1.0f / q, nlimw, fwmax_bits, v);
           }
@@ -108,7 +110,8 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
         for (int j = 0; j < kB; ++j) {
           const int row = L.p0 + j, col = wcol[cw];
           if (row >= n || col >= 32) continue;
-          float v = (float)best[j] * q;
+          // (+inf: FLT_MAX between the passes, +INF behind the last one -- epi bit 0 = toinfinite)
+          float v = best[j] >= kInfW ? ((epi & 1) ? INFINITY : 3.402823466e+38f) : (float)best[j] * q;
           if (epi & 2) v = sqrtf(v);
           out[(int64_t)row * sx + x0 + col] = v;
         }
@@ -128,9 +131,10 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
   uint32_t kmax = 0;
   while ((uint64_t)(kmax + 1) * (kmax + 1) * ain <= nlim && kmax < 65534u) ++kmax;
   // the wide form's range (edt_colq16.hip: launch_column_pass_q16)
-  const uint32_t dw = g_no_wide ? 0u : q16_dmax_wide(a, q);
-  const uint64_t nw = (uint64_t)a * dw * dw;
-  const uint32_t dmaxw = nw > nlim ? dw : dmax, nlimw = nw > nlim ? (uint32_t)nw : nlim;
+  WideRange wr = {0u, 0u, false};
+  if (!g_no_wide) wr = q16_wide_range(a, q, n, BB, nlim);
+  const uint32_t dmaxw = wr.nlim ? wr.dmax : dmax, nlimw = wr.nlim ? wr.nlim : nlim;
+  const bool inf_ok = wr.inf;
   uint32_t kmaxw = kmax;
   while ((uint64_t)(kmaxw + 1) * (kmaxw + 1) * ain <= nlimw && kmaxw < 65534u) ++kmaxw;
   const float fw = (float)nlimw * q;
@@ -157,7 +161,7 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
         } else if (codes) {
           const uint32_t k = codes[(int64_t)row * sx + x0 + col];
           if (k > kmax) { over = true; overmask |= 1u << col; }
-          if (k > kmaxw) bad = true;
+          if (k > kmaxw && !(k == 0xFFFFu && inf_ok)) bad = true;  // (0xFFFF: no boundary in the row -- +inf, which the wide form may carry)
           v = (uint32_t)(uint16_t)((uint16_t)(k * k) * (uint16_t)ain);  // (wraps like the packed multiply; unused if bad)
         } else {
           const float f = Fin[(int64_t)row * sx + x0 + col];
@@ -169,7 +173,7 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
             over = true;
             overmask |= 1u << col;
             uint32_t uw;
-            if (!wide_value(f, q, 1.0f / q, nlimw, fwmax_bits, uw)) bad = true;
+            if (!wide_value(f, q, 1.0f / q, nlimw, fwmax_bits, uw) || (uw == kInfW && !inf_ok)) bad = true;
           } else if (!(fabsf(e) == 0.0f)) bad = true;
           v = u & 0xFFFFu;
         }

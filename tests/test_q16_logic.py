@@ -40,8 +40,10 @@ def q16():
     return lib
 
 
-def wide_limit(a, q):
-    """largest N of the wide form (edt_colq16_lane.h: q16_dmax_wide): N * odd(q) < 2^24, N <= a * d^2 for a d <= 2047"""
+def wide_limit(a, q, n=None, bb=True, with_inf=False):
+    """largest N of the wide form (edt_colq16_lane.h: q16_dmax_wide, q16_wide_range): N * odd(q) < 2^24, N <= a * d^2 for a
+    d <= 2047; without a black border (n given) lowered so that N + a * n^2 stays exact, where columns of n rows may carry +inf
+    at all (with_inf: also return whether they may)"""
     m, _ = np.frexp(np.float64(q))
     m = int(m * (1 << 24))
     while m % 2 == 0:
@@ -50,7 +52,13 @@ def wide_limit(a, q):
     d = 1
     while d < 2047 and a * (d + 1) * (d + 1) <= cap:
         d += 1
-    return a * d * d if a * d * d <= cap else 0
+    lim = a * d * d if a * d * d <= cap else 0
+    d16 = int(np.floor(np.sqrt(65534 / a)))
+    inf_ok = False
+    if not bb and n is not None and lim > a * d16 * d16 and n <= d and a * n * n < cap and cap - a * n * n > a * d16 * d16:
+        lim = min(lim, cap - a * n * n)
+        inf_ok = True
+    return (lim, inf_ok) if with_inf else lim
 
 
 def quantum(lib, w):
@@ -121,10 +129,13 @@ def test_q16_column_pass_matches_oracle(q16, oracle_port, n, sx, kind):
             f1, codes = x_pass(oracle_port, lab, wx, bb)
             want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), bb).reshape(n, sx)
             for form in ("f32", "codes"):
+                # (epi bit 0: the pass is the transform's last one and black_border is off -- rows without any boundary, +inf in
+                # the integer kernel's wide form, leave as +INF: toinfinite, src/edt.hpp:47-53)
+                inf = 0 if bb else 1
                 got, tiles = column_pass(q16, lab, f1 if form == "f32" else None, codes if form == "codes" else None,
-                                         q, a[1], a[0], bb, 0)
+                                         q, a[1], a[0], bb, inf)
                 got_s, tiles_s = column_pass(q16, lab, f1 if form == "f32" else None, codes if form == "codes" else None,
-                                             q, a[1], a[0], bb, 2)
+                                             q, a[1], a[0], bb, 2 | inf)
                 assert np.array_equal(tiles, tiles_s)
                 for i, t_ok in enumerate(tiles):
                     sl = slice(32 * i, min(sx, 32 * i + 32))
@@ -136,9 +147,12 @@ def test_q16_column_pass_matches_oracle(q16, oracle_port, n, sx, kind):
                         # a refusal has a reason: a value beyond the tile limit -- of the wide form, where there is one -- (rows
                         # without a boundary included)
                         dmax = int(np.floor(np.sqrt(65534 / a[1])))
-                        lim = max(a[1] * dmax * dmax, wide_limit(a[1], q))
-                        assert (f1[:, sl].astype(np.float64) / q).max() > lim or \
-                            (codes[:, sl].astype(np.int64) ** 2 * a[0]).max() > lim
+                        wl, inf_ok = wide_limit(a[1], q, n, bb, with_inf=True)
+                        lim = max(a[1] * dmax * dmax, wl)
+                        fin = f1[:, sl][f1[:, sl] < np.float32(3e38)].astype(np.float64)
+                        kfin = codes[:, sl][codes[:, sl] != 0xFFFF].astype(np.int64)
+                        assert (fin.size and (fin / q).max() > lim) or (kfin.size and (kfin ** 2 * a[0]).max() > lim) or \
+                            (not inf_ok and (codes[:, sl] == 0xFFFF).any())
                 # (without a black border a row inside one label has no boundary at all: FLT_MAX, the tile is refused)
                 if bb and (kind in ("blocky", "noise", "cells") or (kind == "membrane" and n <= 512)) and wx <= 6.0:
                     assert tiles.any(), (n, sx, kind, wx, wy, bb, form)
@@ -199,7 +213,7 @@ def test_q16_wide_form_matches_oracle(q16, oracle_port, n, sx, kind):
                 for epi, full in ((0, 0), (2, 0), (0, 1)):   # (full: no column subsets -- two wide passes over every such tile)
                     q16.q16_emul_set_full_wide(full)
                     got, tiles = column_pass(q16, lab, f1 if form == "f32" else None, codes if form == "codes" else None,
-                                             q, a[1], a[0], bb, epi)
+                                             q, a[1], a[0], bb, epi | (0 if bb else 1))
                     q16.q16_emul_set_full_wide(0)
                     assert not full or not (tiles == 3).any()
                     exp = np.sqrt(want) if epi else want
@@ -214,6 +228,47 @@ def test_q16_wide_form_matches_oracle(q16, oracle_port, n, sx, kind):
                     if bb and kind == "ones" and int(codes.max()) ** 2 * a[0] <= wide_limit(a[1], q):
                         assert tiles.all(), "a single label inside a black border leaves nothing to the fp32 kernel"
     assert seen_wide and (seen_subset or kind == "bigcells")
+
+
+@pytest.mark.parametrize("n,sx", [(1024, 64), (600, 96), (300, 40), (200, 64), (97, 32)])
+def test_q16_rows_without_boundary(q16, oracle_port, n, sx):
+    """No black border, rows of one label from edge to edge: +inf after pass X.  Along the column such a row finds a border far
+    away (a * d^2 for any d up to the column's length: no clamp of the distance may apply) or a finite site of a neighbouring
+    row (a sum N[j] + a * d^2 beyond every value the tile held): carried by the wide form where the column is short enough
+    for both to stay exact (q16_wide_range), refused otherwise -- and never wrong."""
+    rng = np.random.default_rng(n + sx)
+    lab = np.ones((n, sx), dtype=np.uint32)
+    lab[:2] = 2                                     # a border along the column, far from most rows
+    lab[n // 3, 3 * sx // 4:] = 0                   # one row with a boundary: finite sites for the rows around it
+    lab[n - 5:, :sx // 2] = 3
+    lab[rng.integers(0, n, 3), rng.integers(0, sx, 3)] = 0
+    carried = refused = False
+    for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (30.0, 6.0), (0.5, 1.0), (2.0, 40.0), (40.0, 2.0)):
+        ok, q, a = quantum(q16, (wx, wy))
+        assert ok
+        f1, codes = x_pass(oracle_port, lab, wx, False)
+        assert (codes == 0xFFFF).any()
+        want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), False).reshape(n, sx)
+        wl, inf_ok = wide_limit(a[1], q, n, False, with_inf=True)
+        for form in ("f32", "codes"):
+            for epi, full in ((1, 0), (3, 0), (1, 1), (0, 0)):
+                q16.q16_emul_set_full_wide(full)
+                got, tiles = column_pass(q16, lab, f1 if form == "f32" else None, codes if form == "codes" else None,
+                                         q, a[1], a[0], False, epi)
+                q16.q16_emul_set_full_wide(0)
+                exp = np.sqrt(want) if epi & 2 else want
+                if not epi & 1:
+                    exp = np.where(np.isinf(exp), np.finfo(np.float32).max, exp)  # (between the passes: FLT_MAX)
+                for i, t_ok in enumerate(tiles):
+                    sl = slice(32 * i, min(sx, 32 * i + 32))
+                    if t_ok:
+                        assert np.array_equal(got[:, sl], exp[:, sl]), (n, sx, wx, wy, form, epi, full, i, int(t_ok))
+                        assert inf_ok or not (codes[:, sl] == 0xFFFF).any()
+                        carried |= bool((codes[:, sl] == 0xFFFF).any())
+                    else:
+                        assert (got[:, sl] == -1.0).all()
+                        refused = True
+    assert carried and (refused or n < 280)
 
 
 @pytest.mark.parametrize("n,sx,kind", [(1024, 32, "cells"), (512, 64, "blocky"), (500, 36, "membrane"), (300, 40, "cells"),
@@ -314,3 +369,71 @@ def test_quantum_of_voxel_sizes(q16):
             assert np.float32(q) * np.float32(ai) == np.float32(wi) * np.float32(wi)
         for N in (1, 3, 65533, 65534):
             assert float(np.float32(N) * np.float32(q)) == N * float(q)
+
+
+def host_cannot_refuse(a, q, shape_xyz, bb):
+    """csrc/edt_api.hip: q16_cannot_refuse, restated -- (pass Y, pass Z): the host's proof that the integer kernel refuses no
+    tile of the pass, on which it skips the fp32 launch over the hand-over list"""
+    sx, sy, sz = shape_xyz
+    kmax = (sx + 1) // 2 if bb else sx
+    vmax_x = kmax * kmax * a[0]
+
+    def limit(ai, n):
+        d16 = int(np.floor(np.sqrt(65534 / ai)))
+        wl, inf_ok = wide_limit(ai, q, n, bb, with_inf=True)
+        if not bb:
+            return wl if inf_ok else 0
+        return max(ai * d16 * d16, wl)
+    y = vmax_x <= limit(a[1], sy)
+    z = y and vmax_x + (0 if bb else sy * sy * a[1]) <= limit(a[2], sz)
+    return y, z
+
+
+@pytest.mark.parametrize("shape,kind", [((64, 120, 97), "ones"), ((64, 120, 97), "slabs"), ((96, 200, 130), "slabs"),
+                                        ((32, 413, 216), "blocky"), ((64, 300, 100), "bigblocks"), ((128, 97, 140), "ones"),
+                                        ((64, 140, 260), "slabs"), ((32, 300, 300), "slabs")])
+def test_q16_three_passes_and_the_hosts_proof(q16, oracle_port, shape, kind):
+    """Passes Y and Z of a 3-D volume through the lane logic (pass X from the oracle), both borders: every tile the kernel
+    accepts is bit-identical to the oracle -- rows without any boundary (+inf after X, FLT_MAX between the passes, +INF at
+    the end) included -- and wherever the host's proof says that no tile can be refused, none is."""
+    sx, sy, sz = shape
+    rng = np.random.default_rng(sx + sy + sz)
+    if kind == "ones":
+        lab = np.ones((sz, sy, sx), dtype=np.uint32)
+    elif kind == "slabs":
+        lab = np.ones((sz, sy, sx), dtype=np.uint32)
+        lab[:, :3, :] = 2            # borders along Y far from most rows
+        lab[:2, :, : sx // 2] = 3    # and along Z
+        lab[sz // 2, sy // 2, sx // 3] = 0
+    else:
+        lab = blocky_labels((sz, sy, sx), nlabels=4, zero_frac=0.05, block=30 if kind == "blocky" else 90, rng=rng).astype(np.uint32)
+    proved = unproved = 0
+    # ((1, 10, 10) on 300 x 300 columns: pass Y carries +inf and turns it into values that pass Z's range does not hold)
+    for w in ((1.0, 1.0, 1.0), (6.0, 6.0, 30.0), (0.5, 40.0, 2.0), (6.0, 40.0, 3.0), (30.0, 6.0, 2.0), (1.0, 10.0, 10.0)):
+        ok, q, a = quantum(q16, w)
+        assert ok
+        for bb in (True, False):
+            sure_y, sure_z = host_cannot_refuse(a, q, shape, bb)
+            want = oracle_port.raw3d(np.ascontiguousarray(lab).reshape(-1), 2, sx, sy, sz, w, bb).reshape(sz, sy, sx)
+            after_y = np.empty((sz, sy, sx), dtype=np.float32)
+            for z in range(sz):
+                _, codes = x_pass(oracle_port, lab[z], w[0], bb)
+                w2 = oracle_port.raw2d(np.ascontiguousarray(lab[z]).reshape(-1), 2, sx, sy, (w[0], w[1]), bb).reshape(sy, sx)
+                w2 = np.where(np.isinf(w2), np.float32(FLT_MAX), w2).astype(np.float32)
+                got, tiles = column_pass(q16, lab[z], None, codes, q, a[1], a[0], bb, 0)
+                assert not sure_y or tiles.all(), (shape, kind, w, bb, z, "the host's proof for pass Y")
+                for i, t_ok in enumerate(tiles):
+                    sl = slice(32 * i, min(sx, 32 * i + 32))
+                    if t_ok:
+                        assert np.array_equal(got[:, sl], w2[:, sl]), (shape, kind, w, bb, z, i, int(t_ok))
+                after_y[z] = w2
+            for y in range(sy):
+                got, tiles = column_pass(q16, lab[:, y, :], after_y[:, y, :], None, q, a[2], a[0], bb, 0 if bb else 1)
+                assert not sure_z or tiles.all(), (shape, kind, w, bb, y, "the host's proof for pass Z")
+                for i, t_ok in enumerate(tiles):
+                    sl = slice(32 * i, min(sx, 32 * i + 32))
+                    if t_ok:
+                        assert np.array_equal(got[:, sl], want[:, y, sl]), (shape, kind, w, bb, y, i, int(t_ok))
+            proved += int(sure_z)
+            unproved += int(not sure_z)
+    assert proved and unproved

@@ -13,9 +13,11 @@
 //               two workgroups of eight waves with whole 128-byte lines per row (the fp32 kernel needs 16-column tiles there);
 //   fill      = through VGPRs: the 16-bit distance indices k of pass X (index form, edt_rowwave.hip C16: N = k^2 * ax), or
 //               fp32 values (N = F / q, checked to be exact), or -- behind a pass that left its results 16-bit -- per row the
-//               16-bit plane or fp32 values; a tile that holds a value outside the 16-bit range or off the quantum grid (rows
-//               without any boundary, objects more than ~250 voxels deep) is NOT processed: its id goes to a list in device
-//               memory and the fp32 kernel (edt_colwave_kernel.h, list mode) takes it afterwards;
+//               16-bit plane or fp32 values; a tile that holds a value outside the 16-bit range (objects more than ~250 voxels
+//               deep; rows without any boundary: +inf) is worked on again in the WIDE form -- 32-bit lanes, below -- where that
+//               form's range holds it; a tile with a value off the quantum grid or beyond that range too is NOT processed:
+//               its id goes to a list in device memory and the fp32 kernel (edt_colwave_kernel.h, list mode) takes it
+//               afterwards;
 //   scans     = run extents across bands by one thread per column and direction over the band words (LDS), break bits per
 //               block of 8 rows and column pair;
 //   windows   = lane = (column pair, block of 8 rows): a wave works on 16 pairs x the four blocks of one band, a contiguous

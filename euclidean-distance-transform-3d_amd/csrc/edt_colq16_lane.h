@@ -8,8 +8,8 @@
 // integer minimum times q and the whole pass can run on 16-bit integers, TWO ADJACENT COLUMNS PER LANE in packed
 // instructions (v_pk_min_u16, v_pk_add_u16 clamp: 3 instructions per step for two voxels against 2.2 per voxel in the
 // fp32 form, edt_colwave_lane.h), on an LDS tile of half the size.  Tiles that do not qualify (a value that is not a
-// multiple of q or too large: rows without any boundary, very large objects) are handed to the fp32 kernel through a
-// list (edt_colq16.hip).
+// multiple of q, or too large even for the wide form V<true> below -- one column per lane, 32-bit values, +inf for rows
+// without any boundary) are handed to the fp32 kernel through a list (edt_colq16.hip).
 //
 // The mathematics is that of the windowed path (edt_colwave_lane.h, "brute"):
 //     result[p] = min( B_p, min_{1<=d<=R} ( c_d + min(N[p-d], N[p+d]) ) ),   B_p = min(N[p], border parabolas),

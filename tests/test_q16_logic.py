@@ -409,7 +409,12 @@ def test_q16_three_passes_and_the_hosts_proof(q16, oracle_port, shape, kind):
         lab = blocky_labels((sz, sy, sx), nlabels=4, zero_frac=0.05, block=30 if kind == "blocky" else 90, rng=rng).astype(np.uint32)
     proved = unproved = 0
     # ((1, 10, 10) on 300 x 300 columns: pass Y carries +inf and turns it into values that pass Z's range does not hold)
-    for w in ((1.0, 1.0, 1.0), (6.0, 6.0, 30.0), (0.5, 40.0, 2.0), (6.0, 40.0, 3.0), (30.0, 6.0, 2.0), (1.0, 10.0, 10.0)):
+    sizes = ((1.0, 1.0, 1.0), (6.0, 6.0, 30.0), (0.5, 40.0, 2.0), (6.0, 40.0, 3.0), (30.0, 6.0, 2.0), (1.0, 10.0, 10.0))
+    if shape == (32, 300, 300):
+        sizes = ((1.0, 1.0, 1.0), (1.0, 10.0, 10.0))
+    elif shape == (32, 413, 216):   # (the two mismatches of the GPU fuzz on the first version of "+inf in the wide form")
+        sizes = ((1.0, 1.0, 1.0), (0.5, 40.0, 2.0), (6.0, 40.0, 3.0))
+    for w in sizes:
         ok, q, a = quantum(q16, w)
         assert ok
         for bb in (True, False):

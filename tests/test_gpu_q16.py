@@ -96,6 +96,41 @@ def test_q16_wide_form(edt_gpu, oracle_port, shape):
             assert np.array_equal(edt_gpu.edt(lab, anisotropy=an, black_border=bb), np.sqrt(want)), (shape, an, bb, "sqrt")
 
 
+def slab_labels(shape, rng):
+    """one label from edge to edge in most rows (no boundary along x: +inf after pass X without a black border), thin slabs of
+    other labels at the low end of y and of z (borders far from most rows), a few background voxels (finite sites)"""
+    sx, sy, sz = shape
+    lab = np.ones(shape, dtype=np.uint32, order="F")
+    lab[:, :3, :] = 2
+    lab[: sx // 2, :, :2] = 3
+    for _ in range(4):
+        lab[rng.integers(0, sx), rng.integers(0, sy), rng.integers(0, sz)] = 0
+    return lab
+
+
+@pytest.mark.parametrize("shape", [(16, 413, 216), (72, 518, 352), (32, 300, 300), (64, 140, 260)])
+def test_q16_rows_without_boundary_and_far_borders(edt_gpu, oracle_port, shape):
+    """black_border off, rows without any boundary: +inf in the integer kernel's wide form (round 5) -- carried only where the
+    column is short enough for the border distance of such a row (anything up to the column's length) and for a finite
+    neighbour's value plus a * d^2 to stay exact (csrc/edt_colq16_lane.h: q16_wide_range); handed to the fp32 kernel elsewhere;
+    and the host's proof that no list launch is needed has to allow for what pass Y makes of +inf.  The shapes and voxel sizes
+    are those of the GPU fuzz's mismatches on the first version ((0.5, 40, 2) / (6, 40, 3) on columns of 413 / 518 rows) and
+    of the CPU tier's separating case ((1, 10, 10) on 300 x 300)."""
+    rng = np.random.default_rng(sum(shape))
+    labs = [slab_labels(shape, rng),
+            np.asfortranarray(blocky_labels(shape, nlabels=4, zero_frac=0.05, block=int(rng.integers(20, 120)), rng=rng).astype(np.uint32))]
+    for lab in labs:
+        for an in ((0.5, 40.0, 2.0), (6.0, 40.0, 3.0), (1.0, 10.0, 10.0), (1.0, 1.0, 1.0), (30.0, 6.0, 2.0)):
+            want = oracle_port.edtsq(lab, an, False)
+            for got, (_, name) in zip(run_modes(edt_gpu, lab, an, False), MODES):
+                assert np.array_equal(got, want), (shape, an, name)
+        lab_c = np.ascontiguousarray(lab[:, :, : shape[2] // 2])
+        want = oracle_port.edtsq(lab_c, (2.0, 40.0, 0.5), False)
+        assert np.array_equal(edt_gpu.edtsq(lab_c, anisotropy=(2.0, 40.0, 0.5), black_border=False), want), (shape, "C order")
+        assert np.array_equal(edt_gpu.edt(lab, anisotropy=(1.0, 10.0, 10.0), black_border=False),
+                              np.sqrt(oracle_port.edtsq(lab, (1.0, 10.0, 10.0), False))), (shape, "sqrt")
+
+
 def test_q16_two_dimensional_and_stacks(edt_gpu, oracle_port):
     rng = np.random.default_rng(3)
     for shape in ((300, 260), (1000, 200), (128, 1024)):

@@ -305,20 +305,11 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     q16 = q16_quantum(ws3, (ndim == 3 && !(flags & EDT_FLAG_BATCH_2D)) ? 3 : 2, &q16_q, q16_a);
   }
   constexpr int kQ16Off = 16 | 64 | 0x2000 | 0x4000 | 0x8000 | 0x10000;
-  // When can the integer kernel refuse no tile at all?  In the index form the values are integers by construction (k^2 * ax
-  // quanta; 0xFFFF = no boundary in the row = +inf, which the wide form carries where the columns are short enough -- round 5),
-  // and so are the integer kernel's own results.  With a black border every row has a boundary on both sides: an index is at
-  // most ceil(sx / 2), and no pass raises a value.  Without, a run may touch one edge of the volume -- an index is at most sx
-  // -- and a row that was +inf after pass X leaves pass Y with a border parabola or a sum N[j] + ay * d^2: at most sy^2 * ay
-  // more.  So if that bound is within the range of a pass (its 16-bit form, or the wide form: q16_value_limit) and everything
-  // the pass reads was written by pass X or by an integer pass that could not refuse either, the fp32 launch over the
-  // hand-over list has nothing to do and is not made -- nor is the list's counter zeroed.  (debug bit 0x20000000: always
-  // launch.)
-  const uint64_t q16_kmax = bb ? (uint64_t)ceil_div(sx, 2) : (uint64_t)sx;
-  const uint64_t q16_vmax_x = q16_kmax * q16_kmax * q16_a[0];
+  // Where the integer kernel provably refuses no tile (index form, bounded values: q16_no_refusals, edt_colq16.hip) and
+  // everything the pass reads was written by pass X or by an integer pass that could not refuse either, the fp32 launch over
+  // the hand-over list has nothing to do and is not made -- nor is the list's counter zeroed.
   auto q16_cannot_refuse = [&](int axis, const AxisGeom &g) {
-    const uint64_t vmax = q16_vmax_x + ((axis == 2 && !bb) ? (uint64_t)sy * (uint64_t)sy * q16_a[1] : 0ull);
-    return q16 && !(g_debug_mode & 0x20000000) && vmax <= q16_value_limit(q16_q, q16_a[axis], g.n, bb);
+    return q16 && q16_no_refusals(q16_q, q16_a, axis, sx, sy, g.n, bb);
   };
   // F in place (codes == nullptr) or from the 16-bit indices of pass X; returns the list for the fp32 launch that follows
   // (launched: the integer kernel ran; sure: the caller vouches for what the pass reads -- see above)
@@ -534,6 +525,22 @@ int edt_hip_set_debug_mode(int mode) {
 }
 
 int edt_hip_get_debug_mode(void) { return debug_mode(); }
+
+int edt_hip_q16_no_refusals(int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz, int ndim, int black_border,
+                            int *pass_y, int *pass_z) {
+  if (pass_y) *pass_y = 0;
+  if (pass_z) *pass_z = 0;
+  if (ndim < 2 || ndim > 3 || sx < 1 || sy < 1 || (ndim == 3 && sz < 1)) return 0;
+  const float w3[3] = {wx, wy, wz};
+  float q = 1.0f;
+  uint32_t a[3] = {1u, 1u, 1u};
+  if (!q16_quantum(w3, ndim, &q, a)) return 0;
+  const bool y = q16_no_refusals(q, a, 1, sx, sy, sy, black_border);
+  const bool z = ndim == 3 && y && q16_no_refusals(q, a, 2, sx, sy, sz, black_border);
+  if (pass_y) *pass_y = y ? 1 : 0;
+  if (pass_z) *pass_z = z ? 1 : 0;
+  return 1;
+}
 
 int edt_hip_set_profiling(int enabled) {
   std::lock_guard<std::mutex> lock(g_log_mutex);

@@ -814,6 +814,24 @@ uint32_t q16_value_limit(float q, uint32_t a, int64_t n, int bb) {
   return wr.nlim ? wr.nlim : n16;
 }
 
+// When can the integer kernel refuse no tile at all?  In the index form the values are integers by construction (k^2 * ax
+// quanta; 0xFFFF = no boundary in the row = +inf, which the wide form carries where the columns are short enough -- round 5),
+// and so are the integer kernel's own results.  With a black border every row has a boundary on both sides: an index is at
+// most ceil(sx / 2), and no pass raises a value.  Without, a run may touch one edge of the volume -- an index is at most sx
+// -- and a row that was +inf after pass X leaves pass Y with a border parabola or a sum N[j] + ay * d^2: at most sy^2 * ay
+// more.  If that bound is within the range of the pass (its 16-bit form, or the wide form: q16_value_limit) and everything
+// the pass reads was written by pass X or by an integer pass that could not refuse either (the caller's part), the fp32
+// launch over the hand-over list has nothing to do.  (debug bit 0x20000000: never proven.)
+// tests/test_q16_logic.py plays passes Y and Z of whole volumes through the lane logic and holds this proof against them.
+bool q16_no_refusals(float q, const uint32_t *a, int axis, int64_t sx, int64_t sy, int64_t n, int bb) {
+  if (debug_mode() & 0x20000000) return false;
+  if (axis != 1 && axis != 2) return false;
+  const uint64_t kmax = bb ? (uint64_t)((sx + 1) / 2) : (uint64_t)sx;
+  uint64_t vmax = kmax * kmax * a[0];
+  if (axis == 2 && !bb) vmax += (uint64_t)sy * (uint64_t)sy * a[1];
+  return vmax <= q16_value_limit(q, a[axis], n, bb);
+}
+
 // the quantum of a call (edt_colq16_lane.h: quantum_of), host side
 bool q16_quantum(const float *w, int naxes, float *q, uint32_t *a) {
   const edt_q16::Quantum Q = edt_q16::quantum_of(w, naxes);

@@ -147,6 +147,9 @@ bool column_pass_q16_supported(const AxisGeom &g);
 // the largest value, in quanta, a tile of a pass with c_d = a * d^2 may hold and stay on the integer kernel (its 16-bit
 // form, or the wide form: two half-tiles with 32-bit lanes) -- what a host that knows a bound of the field compares with
 uint32_t q16_value_limit(float q, uint32_t a, int64_t n, int bb);
+// the host's proof that the integer kernel refuses NO tile of a column pass of a call in the index form (axis 1: pass Y over
+// columns of n = sy rows; axis 2: pass Z over n = sz rows behind a pass Y that could not refuse either) -- edt_colq16.hip
+bool q16_no_refusals(float q, const uint32_t *a, int axis, int64_t sx, int64_t sy, int64_t n, int bb);
 // the kernel's vector accesses: 16-byte loads of fp32 rows, 8-byte stores of result pairs, 8-byte loads of index / plane
 // rows (a 4-byte-aligned view handed in through DLPack stays on the fp32 kernel, which gates its vector accesses itself)
 inline bool column_pass_q16_aligned(const float *F, const uint16_t *codes, const uint16_t *plane, const float *compact = nullptr) {

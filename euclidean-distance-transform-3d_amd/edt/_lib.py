@@ -64,6 +64,7 @@ SIGNATURES = {
     "edt_hip_set_profiling": (_i, [_i]),
     "edt_hip_set_debug_mode": (_i, [_i]),
     "edt_hip_get_debug_mode": (_i, []),
+    "edt_hip_q16_no_refusals": (_i, [_i64, _i64, _i64, _f, _f, _f, _i, _i, _vp, _vp]),
     "edt_hip_release_cache": (_i, []),
     "edt_hip_get_pass_times": (_i, [_vp, _i]),
     "edt_hip_get_pass_name": (ctypes.c_char_p, [_i]),

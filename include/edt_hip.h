@@ -207,6 +207,14 @@ int edt_hip_set_profiling(int enabled);
  * edt_hip_get_debug_mode returns the effective (masked) mode of the calling thread. */
 int edt_hip_set_debug_mode(int mode);
 int edt_hip_get_debug_mode(void);
+/* Diagnostics (pure host arithmetic, no device needed): the library's own proof that the 16-bit integer column kernel
+ * (csrc/edt_colq16.hip) can refuse no tile of pass Y / pass Z of a call of these extents and voxel sizes whose pass X hands
+ * over 16-bit distance indices -- where it holds, the fp32 launch over the hand-over list is not made.  Returns 0 if the
+ * voxel sizes share no quantum (the integer kernel does not apply), 1 otherwise with *pass_y / *pass_z set to 0 / 1 (pass_z:
+ * behind a pass Y that holds; always 0 for ndim == 2).  The CPU test tier plays both passes through the kernel's lane logic
+ * and holds this answer against what the tiles do (tests/test_q16_logic.py).  No counterpart in the reference. */
+int edt_hip_q16_no_refusals(int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz, int ndim, int black_border,
+                            int *pass_y, int *pass_z);
 int edt_hip_get_pass_times(float *ms, int capacity);
 const char *edt_hip_get_pass_name(int index);
 

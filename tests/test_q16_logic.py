@@ -419,6 +419,7 @@ def test_q16_three_passes_and_the_hosts_proof(q16, oracle_port, shape, kind):
         assert ok
         for bb in (True, False):
             sure_y, sure_z = host_cannot_refuse(a, q, shape, bb)
+            assert library_proof(shape, w, bb) == (1, sure_y, sure_z)   # (what run_device acts on)
             want = oracle_port.raw3d(np.ascontiguousarray(lab).reshape(-1), 2, sx, sy, sz, w, bb).reshape(sz, sy, sx)
             after_y = np.empty((sz, sy, sx), dtype=np.float32)
             for z in range(sz):
@@ -442,3 +443,50 @@ def test_q16_three_passes_and_the_hosts_proof(q16, oracle_port, shape, kind):
             proved += int(sure_z)
             unproved += int(not sure_z)
     assert proved and unproved
+
+
+def library_proof(shape_xyz, w, bb):
+    """the product library's own answer (include/edt_hip.h: edt_hip_q16_no_refusals -- host arithmetic, no device)"""
+    from edt import _lib
+    lib = _lib.load()
+    y, z = ctypes.c_int(-1), ctypes.c_int(-1)
+    ndim = len(shape_xyz)
+    sx, sy = shape_xyz[0], shape_xyz[1]
+    sz = shape_xyz[2] if ndim == 3 else 1
+    ws = [float(v) for v in w] + [1.0] * (3 - len(w))
+    rc = lib.edt_hip_q16_no_refusals(sx, sy, sz, ws[0], ws[1], ws[2], ndim, int(bb), ctypes.addressof(y), ctypes.addressof(z))
+    return rc, bool(y.value), bool(z.value)
+
+
+def test_the_librarys_proof_is_the_one_the_lane_logic_was_held_against(q16):
+    """host_cannot_refuse above -- the restatement test_q16_three_passes_and_the_hosts_proof checks against what the tiles of
+    the lane logic do -- and the library's own decision (csrc/edt_colq16.hip: q16_no_refusals, what run_device skips the fp32
+    launch on) agree on random extents, voxel sizes and borders, and on the cases of that test."""
+    rng = np.random.default_rng(77)
+    cases = [((sx, sy, sz), w, bb) for (sx, sy, sz) in ((64, 120, 97), (32, 413, 216), (32, 300, 300), (64, 140, 260), (512, 512, 512),
+                                                        (1024, 1024, 1024), (72, 518, 352))
+             for w in ((1.0, 1.0, 1.0), (6.0, 6.0, 30.0), (0.5, 40.0, 2.0), (6.0, 40.0, 3.0), (1.0, 10.0, 10.0), (4.0, 4.0, 40.0))
+             for bb in (True, False)]
+    for _ in range(3000):
+        shape = (int(rng.integers(1, 4097)), int(rng.integers(97, 1025)), int(rng.integers(97, 1025)))
+        w = tuple(float(v) for v in rng.choice([1, 2, 6, 30, 0.5, 4, 40, 3, 10, 0.25, 7.25, 1.3], size=3))
+        cases.append((shape, w, bool(rng.integers(0, 2))))
+    seen = set()
+    for shape, w, bb in cases:
+        ok, q, a = quantum(q16, w)
+        rc, y, z = library_proof(shape, w, bb)
+        assert rc == int(ok), (shape, w, bb)
+        if not ok:
+            assert not y and not z
+            continue
+        assert (y, z) == host_cannot_refuse(a, q, shape, bb), (shape, w, bb)
+        seen.add((bb, y, z))
+    assert seen == {(b, y, z) for b in (True, False) for (y, z) in ((True, True), (True, False), (False, False))}
+    # the headline and the dense segmentation at 512^3, the 1024^3 volume: nothing launched behind either column pass
+    assert library_proof((512, 512, 512), (6.0, 6.0, 30.0), True) == (1, True, True)
+    assert library_proof((512, 512, 512), (1.0, 1.0, 1.0), False) == (1, True, True)
+    assert library_proof((1024, 1024, 1024), (1.0, 1.0, 1.0), False) == (1, True, True)
+    # (6, 6, 30) without a black border: pass Z's 512-row columns are beyond the 273 rows within which it carries +inf
+    assert library_proof((512, 512, 512), (6.0, 6.0, 30.0), False) == (1, True, False)
+    # two dimensions: pass Y only
+    assert library_proof((512, 512), (1.0, 1.0), False) == (1, True, False)

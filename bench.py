@@ -81,6 +81,16 @@ def measured_traffic(kernel=None, config="cfg2"):
     return None
 
 
+def whole_step_traffic(config):
+    """HBM bytes of ONE whole step (all its kernels; PMC of the committed profile, see measured_traffic), or None."""
+    t = measured_traffic(None, config)
+    if t is None:
+        return None
+    return {"total": int(sum(v["total"] for v in t["kernels"].values())),
+            "read": int(sum(v.get("read", 0) for v in t["kernels"].values())),
+            "write": int(sum(v.get("write", 0) for v in t["kernels"].values())), "source": t["source"]}
+
+
 def real_traffic_fields(ms_per_step, kernel_ms, dom, config):
     """The honest companions of the 32 B/voxel model: bytes the kernels REALLY move (PMC, from a committed profile of
     the same configuration -- not re-measured in this run), over this run's times, against the 8 TB/s spec and the
@@ -260,8 +270,9 @@ class DeviceRun:
         for _ in range(warmup):
             self.step(generic)
         torch.cuda.synchronize()
-        # EXACTLY `steps` timed steps, as at most five batches between synchronisations: the figure is the MEDIAN of the
-        # batch means (a stray batch -- another process's burst, a clock dip -- does not move it), the mean is kept beside it
+        # EXACTLY `steps` timed steps, as at most five batches between synchronisations.  The figure (`ms_per_step`, `value`) is
+        # the MEAN over all timed steps -- the contract's statistic, and the one BENCH_r01..r04 carry (round 5
+        # reported the median of the batch means, which reads lower); the median is kept beside it in `timing`.
         nb = max(1, min(5, steps))
         sizes = [steps // nb + (1 if i < steps % nb else 0) for i in range(nb)]
         batch_ms = []
@@ -271,9 +282,9 @@ class DeviceRun:
                 self.step(generic)
             torch.cuda.synchronize()
             batch_ms.append((time.perf_counter() - t0) / k * 1e3)
-        ms = float(np.median(batch_ms))
-        self.timing = {"statistic": "median of the batch means", "batches": sizes, "batch_ms": [round(b, 4) for b in batch_ms],
-                       "mean_ms": round(float(np.dot(batch_ms, sizes) / steps), 4),
+        ms = float(np.dot(batch_ms, sizes) / steps)
+        self.timing = {"statistic": "mean over all timed steps", "batches": sizes, "batch_ms": [round(b, 4) for b in batch_ms],
+                       "mean_ms": round(ms, 4), "median_of_batch_means_ms": round(float(np.median(batch_ms)), 4),
                        "untimed_steps_before": extra + warmup, "warm_ms": WARM_MS}
         # per-kernel durations with hipEvents on the launch stream (separate profiled steps)
         device.set_profiling(True)
@@ -334,6 +345,42 @@ def voxel_graph_secondary(n, dev, steps, warmup, ref=None):
         dt = time.perf_counter() - t0
         entry["output_verified"] = bool(np.array_equal(got, want))
         entry["verified_by"] = "compiled CPU reference (_edt3dsq_voxel_graph, 1 thread), %.1f s = %.1f Mvox/s" % (dt, n ** 3 / dt / 1e6)
+    return entry
+
+
+def sdf_secondary(n, dev, steps, warmup, ref=None):
+    """The sdf leg of BASELINE configs[4]: sdf = edt(x) - edt(x == 0) (src/edt.pyx:121-158) of the n^3 uint8 blob volume,
+    device-resident in and out.  Byte model of SURVEY 8(d): two transforms of 1-byte labels (3 x 1 + 5 x 4 = 23 B/voxel each)
+    + the combine (two fields read, one written: 12 B/voxel) = 58 B/voxel.  Full-size parity of this path:
+    tests/test_gpu_fullsize.py::test_cfg5_512_sdf_against_compiled_reference."""
+    from edt import device
+    from synth import config_volume
+    lab_np, _, _ = config_volume("cfg5", n)
+    an, bb = (6.0, 6.0, 30.0), True
+    lab = torch.from_numpy(np.ascontiguousarray(lab_np.T)).to(dev)
+    for _ in range(max(2, warmup // 2)):
+        device.sdf(lab, anisotropy=an[::-1], black_border=bb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        got_t = device.sdf(lab, anisotropy=an[::-1], black_border=bb)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    bpv = 2 * sum(algorithmic_bytes_per_voxel(1).values()) + 12
+    model = bpv * n ** 3 / (ms * 1e-3) / 1e9
+    entry = {"config": "cfg5_sdf", "workload": f"{n}^3 uint8 blobs: sdf = edt(x) - edt(x == 0), anisotropy {an}, black_border={bb}, "
+                                               "device-resident in/out, 1 GPU",
+             "ms_per_step": round(ms, 4), "mvox_per_s": round(n ** 3 / (ms * 1e-3) / 1e6, 1),
+             "model_bytes_per_voxel": bpv, "whole_job_algorithmic_GBs": round(model, 1), "whole_job_frac": round(model / HBM_PEAK_GBS, 4),
+             "model_note": "SURVEY 8(d): 2 x (3 x 1 + 5 x 4) B/voxel for the two transforms of 1-byte labels + 12 B/voxel combine",
+             "output_verified": None}
+    if ref is not None and os.environ.get("EDT_BENCH_VERIFY", "1") != "0":
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        want = ref.sdf(lab_np, an, bb, parallel=cores)
+        dt = time.perf_counter() - t0
+        entry["output_verified"] = bool(np.array_equal(got_t.cpu().numpy().T, want))
+        entry["verified_by"] = "compiled CPU reference (edt(x) - edt(x == 0), %d threads), %.2f s = %.1f Mvox/s" % (cores, dt, n ** 3 / dt / 1e6)
     return entry
 
 
@@ -812,8 +859,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)   # 0.65 s of timed kernels: long enough for a busy-sampler to see
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=512, help="edge length of the per-GPU volume")
+    from synth import SWEEP
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg3f", "cfg3m", "cfg4", "cfg5", "cfg3L", "cfg3La",
-                                                        "cfg3M", "cfg3Ma"])
+                                                        "cfg3M", "cfg3Ma"] + sorted(SWEEP))
     ap.add_argument("--secondary", default="", help="comma-separated subset of the secondary configurations")
     ap.add_argument("--labels", default="", choices=["", "cfg4", "ones"],
                     help="--gpus N > 1: the workload of the sharded leg -- cfg4 (default: the multi-label segmentation of "
@@ -861,9 +909,14 @@ def main():
     summary, kernels, bpv = head.measure(args.steps, args.warmup, args.generic)
     dom = max((k for k in kernels if k in bpv), key=lambda k: kernels[k])
     achieved = bpv[dom] * head.vox / (kernels[dom] * 1e-3) / 1e9
+    # `achieved` / `frac`: the WHOLE JOB against SURVEY 8(d)'s 32 B/voxel -- the only fraction of this line that is bounded by 1
+    # whatever the kernels do (VERDICT r5 "What's weak" 4: the dominant pass against its own 12 B/voxel model can read above 1,
+    # because that pass moves fewer bytes than the model charges it -- those per-pass model figures live under `passes` only).
     roofline = {
-        "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, args.config),
+        "bound": "hbm", "kernel": "whole step (x_pass + y_pass + z_bits + z_pass)", "dominant_kernel": dom,
+        "achieved": summary["whole_job_algorithmic_GBs"], "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": summary["whole_job_frac"], "traffic": whole_step_traffic(args.config),
+        "dominant_kernel_traffic": measured_traffic(dom, args.config), "dominant_kernel_model_GBs": round(achieved, 1),
         "kernel_ms": summary["kernel_ms"],
         # every pass against its own model (the `kernel` above is simply the longest one: X and Z are within 2 % of each other
         # on the headline, so which of them it is can change from run to run)
@@ -951,6 +1004,12 @@ def main():
                                                        lib if kind == "reference" else None))
             except Exception as e:  # pragma: no cover
                 secondary.append({"config": "cfg5", "error": repr(e)})
+        if not only or "cfg5_sdf" in only:
+            try:
+                secondary.append(sdf_secondary(n, dev, max(5, min(args.steps, 200) // 4), args.warmup,
+                                               lib if kind == "reference" else None))
+            except Exception as e:  # pragma: no cover
+                secondary.append({"config": "cfg5_sdf", "error": repr(e)})
         if not only or "snemi_like" in only:
             try:
                 secondary.append(snemi_like_secondary(dev, lib, kind))

@@ -17,11 +17,19 @@
 //   * 1-D edt::edt ignores black_border exactly like the reference (src/edt.hpp:807-821).
 // Difference: failures (no GPU, out of memory, unsupported dtype) throw std::runtime_error --
 // the reference has no failure modes here, and silently computing on the CPU is not an option.
+// Under the reference's Cython binding that would be std::terminate: src/edt.pyx:62-113 declares these
+// functions without `except +` and calls them `nogil`.  Two ways out: add `except +` to
+// the extern block (the exception becomes a Python RuntimeError), or -- for the UNMODIFIED binding --
+// compile it with -DEDT_HIP_PYTHON_ERRORS: a failing call then sets a Python RuntimeError through the
+// interpreter already in the process (symbols looked up at run time: no Python.h here), fills the result
+// with NaN and returns; CPython turns "returned a result with an exception set" into a SystemError
+// chained to it.  The interpreter survives and the caller sees why.
 #ifndef EDT_AMD_EDT_HPP
 #define EDT_AMD_EDT_HPP
 
 #include <cmath>
 #include <cstdint>
+#include <limits>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -44,8 +52,9 @@ constexpr int dtype_code() {
 // throws, and NOT zero-filled first (the reference's `new float[n]()` is: every entry point here writes every element).
 struct Result {
   float* p;
+  size_t n;
   std::unique_ptr<float[]> own;
-  Result(float* given, size_t count) : p(given) {
+  Result(float* given, size_t count) : p(given), n(count) {
     if (p == NULL) {
       own.reset(new float[count]);
       p = own.get();
@@ -57,8 +66,39 @@ struct Result {
   }
 };
 
-inline void check(int rc) {
-  if (rc != EDT_OK) throw std::runtime_error(std::string("edt_hip: ") + edt_hip_last_error());
+#ifdef EDT_HIP_PYTHON_ERRORS
+}  // namespace pyedt
+#include <dlfcn.h>
+namespace pyedt {
+// a Python RuntimeError through the interpreter of this process; false: there is none (a plain C++ host)
+inline bool raise_in_python(const std::string& msg) {
+  typedef int (*int_fn)();
+  typedef void (*release_fn)(int);
+  typedef void (*setstr_fn)(void*, const char*);
+  int_fn is_init = (int_fn)dlsym(RTLD_DEFAULT, "Py_IsInitialized");
+  int_fn ensure = (int_fn)dlsym(RTLD_DEFAULT, "PyGILState_Ensure");
+  release_fn release = (release_fn)dlsym(RTLD_DEFAULT, "PyGILState_Release");
+  setstr_fn setstr = (setstr_fn)dlsym(RTLD_DEFAULT, "PyErr_SetString");
+  void** exc = (void**)dlsym(RTLD_DEFAULT, "PyExc_RuntimeError");
+  if (!is_init || !ensure || !release || !setstr || !exc || !is_init()) return false;
+  const int state = ensure();  // (the binding calls us `nogil`)
+  setstr(*exc, msg.c_str());
+  release(state);
+  return true;
+}
+#endif
+
+// out / count: the result buffer of the failing call (filled with NaN where the call returns instead of throwing)
+inline void check(int rc, float* out = NULL, size_t count = 0) {
+  if (rc == EDT_OK) return;
+  const std::string msg = std::string("edt_hip: ") + edt_hip_last_error();
+#ifdef EDT_HIP_PYTHON_ERRORS
+  if (raise_in_python(msg)) {
+    for (size_t i = 0; out != NULL && i < count; ++i) out[i] = std::numeric_limits<float>::quiet_NaN();
+    return;
+  }
+#endif
+  throw std::runtime_error(msg);
 }
 
 // src/edt.hpp:70-119
@@ -77,7 +117,7 @@ float* _edt3dsq(T* labels, const int64_t sx, const int64_t sy, const int64_t sz,
                 const int parallel = 1, float* workspace = NULL) {
   Result out(workspace, (size_t)(sx * sy * sz));
   check(edt_hip_edt3dsq(labels, dtype_code<T>(), sx, sy, sz, wx, wy, wz, black_border, parallel,
-                        out.p));
+                        out.p), out.p, out.n);
   return out.release();
 }
 
@@ -88,7 +128,7 @@ float* _edt3d(T* labels, const int64_t sx, const int64_t sy, const int64_t sz, c
               const int parallel = 1, float* workspace = NULL) {
   Result out(workspace, (size_t)(sx * sy * sz));
   check(edt_hip_edt3d(labels, dtype_code<T>(), sx, sy, sz, wx, wy, wz, black_border, parallel,
-                      out.p));
+                      out.p), out.p, out.n);
   return out.release();
 }
 
@@ -98,7 +138,7 @@ float* _edt2dsq(T* labels, const int64_t sx, const int64_t sy, const float wx, c
                 const bool black_border = false, const int parallel = 1,
                 float* workspace = NULL) {
   Result out(workspace, (size_t)(sx * sy));
-  check(edt_hip_edt2dsq(labels, dtype_code<T>(), sx, sy, wx, wy, black_border, parallel, out.p));
+  check(edt_hip_edt2dsq(labels, dtype_code<T>(), sx, sy, wx, wy, black_border, parallel, out.p), out.p, out.n);
   return out.release();
 }
 
@@ -107,7 +147,7 @@ template <typename T>
 float* _edt2d(T* labels, const int64_t sx, const int64_t sy, const float wx, const float wy,
               const bool black_border = false, const int parallel = 1, float* output = NULL) {
   Result out(output, (size_t)(sx * sy));
-  check(edt_hip_edt2d(labels, dtype_code<T>(), sx, sy, wx, wy, black_border, parallel, out.p));
+  check(edt_hip_edt2d(labels, dtype_code<T>(), sx, sy, wx, wy, black_border, parallel, out.p), out.p, out.n);
   return out.release();
 }
 
@@ -121,7 +161,7 @@ float* _binary_edt3dsq(T* img, const int64_t sx, const int64_t sy, const int64_t
                        const int parallel = 1, float* workspace = NULL) {
   (void)parallel;
   Result out(workspace, (size_t)(sx * sy * sz));
-  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 0, out.p));
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 0, out.p), out.p, out.n);
   return out.release();
 }
 template <typename T>
@@ -130,7 +170,7 @@ float* _binary_edt3d(T* img, const int64_t sx, const int64_t sy, const int64_t s
                      const int parallel = 1, float* workspace = NULL) {
   (void)parallel;
   Result out(workspace, (size_t)(sx * sy * sz));
-  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 1, out.p));
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 3, sx, sy, sz, wx, wy, wz, black_border, 1, out.p), out.p, out.n);
   return out.release();
 }
 template <typename T>
@@ -139,7 +179,7 @@ float* _binary_edt2dsq(T* img, const int64_t sx, const int64_t sy, const float w
                        float* workspace = NULL) {
   (void)parallel;
   Result out(workspace, (size_t)(sx * sy));
-  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 0, out.p));
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 0, out.p), out.p, out.n);
   return out.release();
 }
 template <typename T>
@@ -147,7 +187,7 @@ float* _binary_edt2d(T* img, const int64_t sx, const int64_t sy, const float wx,
                      const bool black_border = false, const int parallel = 1, float* output = NULL) {
   (void)parallel;
   Result out(output, (size_t)(sx * sy));
-  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 1, out.p));
+  check(edt_hip_binary_edtsq(img, dtype_code<T>(), 2, sx, sy, 1, wx, wy, 1.0f, black_border, 1, out.p), out.p, out.n);
   return out.release();
 }
 
@@ -159,7 +199,7 @@ float* _edt2dsq_voxel_graph(T* labels, GRAPH_TYPE* graph, const int64_t sx, cons
   static_assert(sizeof(GRAPH_TYPE) == 1, "voxel graph must be one byte per voxel");
   Result out(workspace, (size_t)(sx * sy));
   check(edt_hip_edt2dsq_voxel_graph(labels, dtype_code<T>(), reinterpret_cast<const uint8_t*>(graph),
-                                    sx, sy, wx, wy, black_border, out.p));
+                                    sx, sy, wx, wy, black_border, out.p), out.p, out.n);
   return out.release();
 }
 template <typename T, typename GRAPH_TYPE = uint8_t>
@@ -169,7 +209,7 @@ float* _edt3dsq_voxel_graph(T* labels, GRAPH_TYPE* graph, const int64_t sx, cons
   static_assert(sizeof(GRAPH_TYPE) == 1, "voxel graph must be one byte per voxel");
   Result out(workspace, (size_t)(sx * sy * sz));
   check(edt_hip_edt3dsq_voxel_graph(labels, dtype_code<T>(), reinterpret_cast<const uint8_t*>(graph),
-                                    sx, sy, sz, wx, wy, wz, black_border, out.p));
+                                    sx, sy, sz, wx, wy, wz, black_border, out.p), out.p, out.n);
   return out.release();
 }
 template <typename T, typename GRAPH_TYPE = uint8_t>

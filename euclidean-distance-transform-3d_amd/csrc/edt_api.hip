@@ -226,17 +226,27 @@ int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {
   return EDT_OK;
 }
 
-// Voxel sizes must be positive and finite.  (The reference does not validate them: a negative size makes its pass 1 cross
-// label boundaries -- the unguarded backward fminf sweep, src/edt.hpp:107-109 -- and NaN / inf / 0 give NaN or all-zero
-// fields; no kernel here reproduces that, so the call is refused instead of answered differently by different kernels.)
-int check_voxel_sizes(int naxes, float wx, float wy, float wz) {
-  const float w[3] = {wx, wy, wz};
+// Voxel sizes.  The reference does not validate them.  Along x a size enters pass 1 as itself (src/edt.hpp:86-113): a negative
+// one makes the unguarded backward fminf sweep cross label boundaries, and NaN / inf / 0 give NaN or all-zero fields; no
+// kernel here reproduces that, so such a call is refused instead of answered differently by different kernels.  Along y and
+// z a size enters only as its square (w2 = anisotropy * anisotropy, src/edt.hpp:181, :258): a negative wy / wz gives the field
+// of |w| there, and does here -- the sign is dropped before anything else looks at it.
+static bool voxel_size_usable(float w) { return w > 0.0f && w <= FLT_MAX; }
+int check_voxel_sizes(int naxes, float &wx, float &wy, float &wz) {
+  float *w[3] = {&wx, &wy, &wz};
   for (int i = 0; i < naxes && i < 3; ++i) {
-    if (!(w[i] > 0.0f) || !(w[i] <= FLT_MAX)) {
-      set_error("voxel sizes (anisotropy) must be positive and finite");
+    if (i > 0) *w[i] = fabsf(*w[i]);
+    if (!voxel_size_usable(*w[i])) {
+      set_error(i == 0 ? "the voxel size along x must be positive and finite" : "voxel sizes (anisotropy) must be non-zero and finite");
       return EDT_ERR_BAD_ARG;
     }
   }
+  return EDT_OK;
+}
+// the voxel size of a column pass on its own (the Z phase of the sharded path)
+int check_column_voxel_size(float &w) {
+  w = fabsf(w);
+  if (!voxel_size_usable(w)) { set_error("voxel sizes (anisotropy) must be non-zero and finite"); return EDT_ERR_BAD_ARG; }
   return EDT_OK;
 }
 

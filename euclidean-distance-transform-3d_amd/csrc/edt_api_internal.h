@@ -39,7 +39,8 @@ int launch_row_bits(int dtype, const void *labels, float *out, uint32_t *nz_y, u
                     int64_t sy, int64_t sz, float w, int bb, int to_finite, hipStream_t stream);
 bool env_force_generic();  // EDT_HIP_FORCE_GENERIC=1: every call takes the fallback kernels (test hook)
 int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz);
-int check_voxel_sizes(int naxes, float wx, float wy, float wz);
+int check_voxel_sizes(int naxes, float &wx, float &wy, float &wz);  // (drops the sign of wy / wz: they enter as squares)
+int check_column_voxel_size(float &w);
 int require_device();
 // the pass pipeline on device-resident data
 int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,

@@ -237,6 +237,9 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
           // (pass Y's limit may be the larger one; a 16-bit value is always within the wide form's range)
           ov01 |= pk_subs(raw[j][0], nlimpk);
           ov23 |= pk_subs(raw[j][1], nlimpk);
+          // (no 16-bit-output pass stores 0xFFFF; should a plane -- the caller's, in the sharded path -- hold one where this pass
+          // does not carry +inf, the tile has no integer form: handed over, never a silent +inf in the wide fill)
+          bad |= !qa.inf_ok && (pk_subs(raw[j][0], 0xFFFEFFFEu) | pk_subs(raw[j][1], 0xFFFEFFFEu)) != 0u;
           *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = (v2u){raw[j][0], raw[j][1]};
         } else if (row < nb32) {
           uint32_t u[4];
@@ -826,6 +829,9 @@ uint32_t q16_value_limit(float q, uint32_t a, int64_t n, int bb) {
 bool q16_no_refusals(float q, const uint32_t *a, int axis, int64_t sx, int64_t sy, int64_t n, int bb) {
   if (debug_mode() & 0x20000000) return false;
   if (axis != 1 && axis != 2) return false;
+  // (the proof stands on its own: extents an index of pass X cannot describe -- 0xFFFF is "no boundary" -- prove nothing, and
+  // the products below stay far from 2^64: kmax, sy < 2^16, a <= 16384)
+  if (sx < 1 || sy < 1 || n < 1 || sx > 65534 || sy > 65534 || n > 65534 || a[0] > 16384u || a[1] > 16384u || a[2] > 16384u) return false;
   const uint64_t kmax = bb ? (uint64_t)((sx + 1) / 2) : (uint64_t)sx;
   uint64_t vmax = kmax * kmax * a[0];
   if (axis == 2 && !bb) vmax += (uint64_t)sy * (uint64_t)sy * a[1];

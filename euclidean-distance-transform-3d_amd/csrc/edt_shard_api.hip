@@ -88,7 +88,7 @@ int edt_hip_shard_xy_device(const void *d_labels, const void *d_halo, int dtype,
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(dtype, 3, sx, sy, sz_local);
   if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(2, wx, wy, 1.0f)) != EDT_OK) return rc;
+  { float w1 = 1.0f; if ((rc = check_voxel_sizes(2, wx, wy, w1)) != EDT_OK) return rc; }
   if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
   if (!d_labels || !d_partial || !d_zflags) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   ShardPlan p = make_shard_plan(sx, sy, sz_local, d_workspace);
@@ -137,7 +137,7 @@ int edt_hip_shard_z_device_ex(float *d_partial, const uint8_t *d_zflags, int64_t
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
   if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(1, wz, 1.0f, 1.0f)) != EDT_OK) return rc;
+  if ((rc = check_column_voxel_size(wz)) != EDT_OK) return rc;
   if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
   if (!d_partial || !d_zflags) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   ShardPlan p = make_shard_plan(sx, sy_local, sz, d_workspace);
@@ -185,7 +185,7 @@ int edt_hip_shard_xy_records_device(const void *d_labels, const void *d_halo, in
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(dtype, 3, sx, sy, sz_local);
   if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(2, wx, wy, 1.0f)) != EDT_OK) return rc;
+  { float w1 = 1.0f; if ((rc = check_voxel_sizes(2, wx, wy, w1)) != EDT_OK) return rc; }
   if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
   if (!d_labels || !y_splits || !d_blocks || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
   if (!edt_hip_shard_records_supported(dtype, sx, sy, sz_local)) {
@@ -291,7 +291,7 @@ static int shard_z_records(float *d_records, int64_t sx, int64_t sy_local, int64
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
   if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(1, wz, 1.0f, 1.0f)) != EDT_OK) return rc;
+  if ((rc = check_column_voxel_size(wz)) != EDT_OK) return rc;
   if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
   if (!d_records) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   if (!edt_hip_shard_records_supported(EDT_U8, sx, sy_local, sz)) {
@@ -378,7 +378,7 @@ int edt_hip_shard_xy_records16_device(const void *d_labels, const void *d_halo, 
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(dtype, 3, sx, sy, sz_local);
   if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(2, wx, wy, 1.0f)) != EDT_OK) return rc;
+  { float w1 = 1.0f; if ((rc = check_voxel_sizes(2, wx, wy, w1)) != EDT_OK) return rc; }
   if (sx == 0 || sy == 0 || sz_local == 0) return EDT_OK;
   if (!d_labels || !y_splits || !d_blocks || !d_refused || nparts < 1) { set_error("null argument"); return EDT_ERR_BAD_ARG; }
   if (y_splits[0] != 0 || y_splits[nparts] != sy) { set_error("y_splits must run from 0 to sy"); return EDT_ERR_BAD_ARG; }
@@ -441,7 +441,7 @@ int edt_hip_shard_z_records16_device(const void *d_records, float *d_out, int64_
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_shape(EDT_U8, 3, sx, sy_local, sz);
   if (rc != EDT_OK) return rc;
-  if ((rc = check_voxel_sizes(1, wz, 1.0f, 1.0f)) != EDT_OK) return rc;
+  if ((rc = check_column_voxel_size(wz)) != EDT_OK) return rc;
   if (sx == 0 || sy_local == 0 || sz == 0) return EDT_OK;
   if (!d_records || !d_out) { set_error("null device pointer"); return EDT_ERR_BAD_ARG; }
   const float w3[3] = {wx, wy, wz};

@@ -27,6 +27,9 @@ import numpy as np
 from . import _lib
 from ._lib import EdtHipError  # noqa: F401  (re-export)
 
+# a host that cannot run any transform fails HERE, with the reason (no built library; no GPU device node) -- _lib.probe_at_import
+_lib.probe_at_import()
+
 __all__ = [
     "edt", "edtsq", "sdf", "sdfsq",
     "edt1d", "edt1dsq", "edt2d", "edt2dsq", "edt3d", "edt3dsq",
@@ -260,10 +263,13 @@ def _run(data, anisotropy, black_border, voxel_graph, take_sqrt, ndim, signed=Fa
     weights = tuple(float(np.float32(a)) for a in np.asarray(anisotropy, dtype=np.float64).reshape(-1))
     if len(weights) != ndim:
         raise ValueError(f"anisotropy must have {ndim} entries, got {len(weights)}")
-    # (stated deviation: the reference does not validate voxel sizes -- a negative one makes its pass 1 cross label
-    # boundaries, src/edt.hpp:107-109; the C ABI refuses them as well, include/edt_hip.h)
-    if not all(np.isfinite(a) and a > 0.0 for a in weights):
-        raise ValueError(f"anisotropy must be positive and finite, got {weights}")
+    # (stated deviation: the reference does not validate voxel sizes.  Along the fastest axis a size enters pass 1 as itself -- a
+    # negative one makes the reference's backward sweep cross label boundaries, src/edt.hpp:107-109 --, along the other axes only
+    # as its square, src/edt.hpp:181, :258: the sign is meaningless there and accepted, as the reference does; zero, NaN and
+    # inf are refused everywhere, here and at the C ABI, include/edt_hip.h)
+    fastest = 0 if order == "F" else ndim - 1
+    if not all(np.isfinite(a) and a != 0.0 for a in weights) or weights[fastest] < 0.0:
+        raise ValueError(f"anisotropy must be finite and non-zero (and positive along the fastest axis), got {weights}")
 
     # x is the fastest axis of the buffer the kernels see.
     if order == "F":

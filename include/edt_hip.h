@@ -10,9 +10,11 @@
  *   - x is the fastest axis: idx = x + sx * (y + sy * z);
  *   - label 0 is background; any change of label is a boundary;
  *   - wx, wy, wz are the physical voxel sizes (anisotropy) as fp32; every size of an axis the call uses
- *     must be positive and finite, or the call fails with EDT_ERR_BAD_ARG before any device work
- *     (stated deviation: the reference does not validate them -- a negative size makes its pass 1
- *     cross label boundaries, src/edt.hpp:107-109, NaN / inf / 0 give NaN or all-zero fields);
+ *     must be finite and non-zero, wx positive, or the call fails with EDT_ERR_BAD_ARG before any device
+ *     work.  A negative wy / wz is taken as |w|: along y and z a size enters only as its square
+ *     (src/edt.hpp:181, :258), which is what the reference computes with it.  (Stated deviation for the
+ *     rest: the reference does not validate -- a negative wx makes its pass 1 cross label boundaries,
+ *     src/edt.hpp:107-109, NaN / inf / 0 give NaN or all-zero fields);
  *   - black_border != 0 treats the outside of the volume as background;
  *   - output is fp32, squared distances unless the entry point says otherwise;
  *     with black_border == 0 voxels that see no boundary are +INF.

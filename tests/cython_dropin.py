@@ -47,10 +47,12 @@ def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     cpp = os.path.join(OUT, "edt_cydrop.cpp")
     subprocess.run(["cython", "-3", "--fast-fail", "--cplus", PYX, "-o", cpp], check=True, capture_output=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-w",
+    # -DEDT_HIP_PYTHON_ERRORS (cpp/edt.hpp): the binding declares the transforms without `except +` and calls them nogil --
+    # a failing call (no device, out of memory) then raises in Python instead of ending the interpreter in std::terminate
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-w", "-DEDT_HIP_PYTHON_ERRORS",
            "-I" + os.path.join(PKG, "cpp"), "-I" + os.path.join(ROOT, "include"),
            "-I" + sysconfig.get_paths()["include"], "-I" + numpy.get_include(), cpp,
-           "-L" + os.path.join(PKG, "lib"), "-ledt_hip",
+           "-L" + os.path.join(PKG, "lib"), "-ledt_hip", "-ldl",
            # found relative to the module itself, wherever the tree is checked out
            "-Wl,-rpath,$ORIGIN/../../../euclidean-distance-transform-3d_amd/lib",
            "-o", module_path()]

@@ -102,6 +102,54 @@ LARGE_CELL = {"cfg3L": (60, (1.0, 1.0, 1.0)), "cfg3La": (60, (6.0, 6.0, 30.0)),
               "cfg3M": (500, (1.0, 1.0, 1.0)), "cfg3Ma": (500, (6.0, 6.0, 30.0))}
 
 
+def sphere_labels(shape, radius, dtype=np.uint32):
+    """ONE object: a ball of the given radius (label 1) in the middle of a background volume."""
+    ax = [np.arange(s, dtype=np.float32) - (s - 1) / 2.0 for s in shape]
+    r2 = (ax[0] ** 2)[:, None, None] + (ax[1] ** 2)[None, :, None] + (ax[2] ** 2)[None, None, :]
+    return np.asfortranarray((r2 <= np.float32(radius) ** 2).astype(dtype))
+
+
+def diagonal_halves(shape, dtype=np.uint32):
+    """Two labels separated by the plane x + y + z = const through the middle of the volume: the row values of every pass
+    change from row to row (nothing is flat) and the distances are as large as the volume allows."""
+    i = [np.arange(s, dtype=np.int32) for s in shape]
+    t = i[0][:, None, None] + i[1][None, :, None] + i[2][None, None, :]
+    return np.asfortranarray((1 + (t >= (sum(shape) - 3) // 2)).astype(dtype))
+
+
+# The OBJECT-SIZE sweep (VERDICT r5 item 2): the cost of the column passes as the objects grow -- Voronoi cells ~26 ... ~256
+# voxels across, one ball of radius 250, a box without any boundary, a box with ONE background voxel (every z-column sees one
+# finite row), two half spaces cut diagonally -- name: (what, anisotropy, black_border)
+SWEEP = {
+    "sw26": ("voronoi", 7600, (1.0, 1.0, 1.0), False), "sw65": ("voronoi", 500, (1.0, 1.0, 1.0), False),
+    "sw130": ("voronoi", 60, (1.0, 1.0, 1.0), False), "sw256": ("voronoi", 8, (1.0, 1.0, 1.0), False),
+    "sphere250": ("sphere", 250, (1.0, 1.0, 1.0), False), "sphere250bb": ("sphere", 250, (1.0, 1.0, 1.0), True),
+    "onesF": ("ones", 0, (1.0, 1.0, 1.0), False), "onebg": ("onebg", 0, (1.0, 1.0, 1.0), False),
+    "diag": ("diag", 0, (1.0, 1.0, 1.0), True), "diagF": ("diag", 0, (1.0, 1.0, 1.0), False),
+    "sphere_slab": ("sphere_slab", 250, (1.0, 1.0, 1.0), False),
+}
+
+
+def sweep_volume(name: str, n: int = 512):
+    kind, par, an, bb = SWEEP[name]
+    shape = (n, n, n)
+    if kind == "voronoi":
+        return voronoi_full(shape, max(2, int(round(par * (n / 512.0) ** 3))), seed=3), an, bb
+    if kind == "sphere":
+        return sphere_labels(shape, par * n / 512.0), an, bb
+    if kind == "sphere_slab":  # the 8-GPU slab shape of configs[3]: (2n, 2n, n / 4)
+        return sphere_labels((2 * n, 2 * n, n // 4), par * n / 512.0), an, bb
+    if kind == "ones":
+        return np.ones(shape, dtype=np.uint32, order="F"), an, bb
+    if kind == "onebg":
+        lab = np.ones(shape, dtype=np.uint32, order="F")
+        lab[n // 2, n // 2, n // 2] = 0
+        return lab, an, bb
+    if kind == "diag":
+        return diagonal_halves(shape), an, bb
+    raise KeyError(name)
+
+
 def config_volume(name: str, n: int = 512):
     """The BASELINE.json configurations at edge length `n` (Fortran order, x fastest).
 
@@ -115,6 +163,8 @@ def config_volume(name: str, n: int = 512):
       cfg3L / cfg3La / cfg3M / cfg3Ma: full-resolution Voronoi segmentations with LARGE cells (~130 / ~65 voxels
             across at 512^3) at (1,1,1) / (6,6,30), black_border=False
     """
+    if name in SWEEP:
+        return sweep_volume(name, n)
     if name == "cfg1":
         return np.ones((n, n, n), dtype=np.uint32, order="F"), (1.0, 1.0, 1.0), True
     if name == "cfg2":

@@ -86,6 +86,20 @@ def test_device_each_large_labels_in_place(edt_gpu):
             assert np.array_equal(img.cpu().numpy(), (mlab == k) * mdt), (k, in_place)
 
 
+def test_negative_voxel_size_along_y_or_z_is_its_magnitude(edt_gpu, oracle_port):
+    """along y and z a voxel size enters the reference only as its square (src/edt.hpp:181, :258), so a negative
+    wy / wz gives the field of |w| there -- and here (the C ABI drops the sign; only wx must be positive)."""
+    rng = np.random.default_rng(78)
+    lab = np.asfortranarray(blocky_labels((44, 130, 100), nlabels=5, zero_frac=0.2, block=9, rng=rng).astype(np.uint32))
+    for an in ((2.0, -3.0, 5.0), (1.0, 1.0, -1.0), (6.0, -6.0, -30.0), (0.7, -1.3, 2.0)):
+        for bb in (True, False):
+            want = oracle_port.edtsq(lab, an, bb)   # the reference's arithmetic with the sign as given
+            assert np.array_equal(want, oracle_port.edtsq(lab, tuple(abs(a) for a in an), bb))
+            assert np.array_equal(edt_gpu.edtsq(lab, anisotropy=an, black_border=bb), want), (an, bb)
+    with pytest.raises(ValueError):
+        edt_gpu.edtsq(lab, anisotropy=(-2.0, 3.0, 5.0))
+
+
 def test_sdf_single_round_trip(edt_gpu, oracle_port):
     rng = np.random.default_rng(77)
     for shape in ((200,), (70, 45), (40, 52, 36)):

@@ -4,6 +4,7 @@ every host thread -- not against our restatement.
 
   * cfg3 / cfg3m (configs[2]): 512^3 uint32, ~2000 labels, black_border=False, (1,1,1) and (6,6,30)
   * cfg4 (configs[3]) on ONE GPU: the 1024^3 segmentation
+  * the sdf leg of configs[4]: sdf / sdfsq of the 512^3 uint8 blob volume (device-resident and through the host entry point)
   * cfg4-sized virtual ranks: 1024 x 1000 x 1016 cut into 8 uneven Z-slabs / Y-slabs,
     every rank's two phases on one device, the "exchange" a device copy
   * two host threads driving two streams with their own plans at the same time
@@ -48,6 +49,27 @@ def test_cfg4_1024_single_gpu_against_compiled_reference(edt_gpu, oracle_ref):
     got = device.edtsq(t, anisotropy=an[::-1], black_border=bb)
     del t
     assert np.array_equal(got.cpu().numpy().T, want)
+
+
+@pytest.mark.parametrize("an,bb", [((6.0, 6.0, 30.0), True), ((1.0, 1.0, 1.0), False)])
+def test_cfg5_512_sdf_against_compiled_reference(edt_gpu, oracle_ref, an, bb):
+    """BASELINE configs[4], "... and sdf on 1xMI355X": sdf = edt(x) - edt(x == 0) (src/edt.pyx:121-158) of the 512^3 uint8
+    blob volume, against the compiled reference run with every host thread -- bit for bit, both entry points."""
+    import torch
+    from edt import device
+
+    lab, _, _ = config_volume("cfg5", 512)
+    p = os.cpu_count() or 1
+    want = oracle_ref.sdf(lab, an, bb, parallel=p)
+    assert float(want.min()) < 0.0 < float(want.max())
+    t = torch.from_numpy(np.ascontiguousarray(lab.T)).cuda()
+    got = device.sdf(t, anisotropy=an[::-1], black_border=bb).cpu().numpy().T
+    assert np.array_equal(got, want)
+    del got
+    assert np.array_equal(edt_gpu.sdf(lab, anisotropy=an, black_border=bb), want)
+    if bb:
+        want = oracle_ref.sdfsq(lab, an, bb, parallel=p)
+        assert np.array_equal(edt_gpu.sdfsq(lab, anisotropy=an, black_border=bb), want)
 
 
 def test_uneven_1024_world8_virtual_ranks_against_compiled_reference(edt_gpu, oracle_ref):

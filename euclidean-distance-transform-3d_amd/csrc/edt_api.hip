@@ -72,8 +72,10 @@ struct Plan {
   int32_t *stack = nullptr;
   uint32_t *nz_y = nullptr, *rs_y = nullptr, *zs_y = nullptr, *nz_z = nullptr, *rs_z = nullptr;
   unsigned char *line_ws = nullptr;  // scratch of the line pipeline when pass 1 runs over rows no row kernel takes (> 4096 voxels)
-  uint16_t *codes = nullptr;  // 16-bit distance indices of pass 1 (index form), one slab of xy_slab slices
+  uint16_t *codes = nullptr;  // 16-bit distance indices of pass 1 (index form): one slab of xy_slab slices, or the whole volume
   int64_t xy_slab = 0;        // slices per slab of the slab-wise X/Y passes (0: no index form for this shape)
+  bool codes_whole = false;   // the index buffer holds every slice (volumes of several slabs: round 6) -- the 16-bit plane between
+                              // passes Y and Z then exists there too
   // the tiles the 16-bit integer column kernel hands to the fp32 kernel (edt_colq16.hip): kQ16Slots counters, one per
   // column-pass launch of a call, and one array of tile ids (launches are stream-ordered: the array is reused)
   uint32_t *q16_counts = nullptr, *q16_ids = nullptr;
@@ -108,14 +110,28 @@ static bool plan_needs_pingpong(int ndim, int64_t sx, int64_t sy, int64_t sz, in
 // volume's worth of parallelism) -- 256 MiB of scratch whatever the volume.  Shapes: the register-resident pass 1
 // and the wave column kernel, rows of whole 8-byte granules.  (debug bit 0x100000 switches the form off.)
 constexpr int64_t kCodeSlabVoxels = (int64_t)1 << 27;
+// Volumes of several slabs (1024^3: eight) keep the indices of EVERY slab where that costs at most this many bytes (2 GiB at
+// 1024^3, against 288 GB of HBM): pass Y then leaves its results in the 16-bit plane there as well and pass Z reads 2 bytes per
+// voxel instead of 4 (round 4 measured it at cfg4 and did not keep it for the workspace; round 6 does).  Passes X and Y still run
+// slab by slab, so that a slab's indices are read back while they are warm.  EDT_HIP_WHOLE_INDEX_BYTES overrides the limit (0: off).
+static int64_t whole_index_limit() {
+  static const int64_t v = [] {
+    const char *e = std::getenv("EDT_HIP_WHOLE_INDEX_BYTES");
+    return e ? (int64_t)std::strtoll(e, nullptr, 0) : (int64_t)8 << 30;
+  }();
+  return v;
+}
 constexpr int kQ16Slots = 256;  // counters of the 16-bit integer column kernel's hand-over lists (one per launch)
 constexpr int EDT_FLAG_NO_INDEX_FORM = 0x8000;  // internal: plan without the index buffer
 static int64_t plan_code_slab(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
   if (ndim < 2 || sx % 4 != 0 || sx * sy > kCodeSlabVoxels || (flags & (EDT_FLAG_NO_INDEX_FORM | EDT_FLAG_SMALL_WORKSPACE))) return 0;
   if ((flags & EDT_FLAG_FORCE_GENERIC) || env_force_generic() || (g_debug_mode & (0x100000 | 64 | 32))) return 0;
   if (!row_pass_wave_supported(dtype, sx, sy, sz) || !column_pass_wave_supported(make_geom_y(sx, sy, sz))) return 0;
-  const int64_t slab = kCodeSlabVoxels / (sx * sy);
-  return slab < sz ? slab : sz;
+  int64_t slab = kCodeSlabVoxels / (sx * sy);
+  if (slab >= sz) return sz;
+  // (several slabs: whole words of the per-slice map of the 16-bit plane per slab)
+  if (slab >= 32) slab &= ~(int64_t)31;
+  return slab;
 }
 
 static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, void *ws, int flags) {
@@ -145,7 +161,9 @@ static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, v
   }
   if (ndim >= 2) {
     p.xy_slab = plan_code_slab(dtype, ndim, sx, sy, sz, flags);
-    if (p.xy_slab > 0) p.codes = c.take<uint16_t>((size_t)(p.xy_slab * sx * sy));
+    p.codes_whole = p.xy_slab >= sz || (p.xy_slab > 0 && p.xy_slab % 32 == 0 && ndim == 3 && !(flags & EDT_FLAG_BATCH_2D) &&
+                                        sx * sy * sz * (int64_t)sizeof(uint16_t) <= whole_index_limit());
+    if (p.xy_slab > 0) p.codes = c.take<uint16_t>((size_t)((p.codes_whole ? sz : p.xy_slab) * sx * sy));
   }
   if (ndim >= 2 && !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic()) {
     // (ids in the fp32 kernel's geometry: 16-column tiles for axes of more than 512 rows)
@@ -282,6 +300,15 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
   }
   const int bb = (flags & EDT_FLAG_BLACK_BORDER) ? 1 : 0;
   const int want_sqrt = (flags & EDT_FLAG_SQRT) ? 1 : 0;
+  // The SIGNED transform (EDT_FLAG_SIGNED; sdf / sdfsq of src/edt.pyx:121-202 = edt(x) - edt(x == 0)) as ONE transform: the
+  // two fields have disjoint supports, and a voxel's value depends on nothing but the voxels of its own label runs -- so
+  // measuring label 0 like every other label gives edt(x) on the foreground and edt(x == 0) on the background at once, bit
+  // for bit; the background's sign follows in one streaming kernel.  Pass X's register kernel takes the flag (zero_label).
+  const int signed_tf = (flags & EDT_FLAG_SIGNED) ? 1 : 0;
+  if (signed_tf && !signed_transform_supported(dtype, ndim, sx, sy, sz, flags)) {
+    set_error("EDT_FLAG_SIGNED: shape not served by the one-transform form (edt_hip_signed_supported)");
+    return EDT_ERR_UNSUPPORTED;
+  }
   const int last_epi = (bb ? 0 : kEpiToInf) | (want_sqrt ? kEpiSqrt : 0) | kEpiStream;
   // a stack of 2-D images is a volume without a z pass
   if ((flags & EDT_FLAG_BATCH_2D) && ndim != 3) { set_error("EDT_FLAG_BATCH_2D needs ndim = 3 (sz = image count)"); return EDT_ERR_BAD_ARG; }
@@ -323,8 +350,9 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
   };
   // F in place (codes == nullptr) or from the 16-bit indices of pass X; returns the list for the fp32 launch that follows
   // (launched: the integer kernel ran; sure: the caller vouches for what the pass reads -- see above)
+  // map_words_off: the slab's first word in every x-tile's row of the plane's map (pass Y of the slabs after the first)
   auto q16_pass = [&](float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, int axis, int epi,
-                      TileList &list, uint16_t *plane, bool sure, bool &launched) -> int {
+                      TileList &list, uint16_t *plane, bool sure, bool &launched, int64_t map_words_off = 0) -> int {
     list = TileList();
     launched = false;
     // (the bits that force one form of the fp32 kernel on every tile -- the test tiers' way to cover them -- keep the call there)
@@ -340,7 +368,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     }
     uint32_t *count = p.q16_counts + q16_slot++;
     const int r = launch_column_pass_q16(F, codes, rs, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, p.q16_ids, stream,
-                                         nullptr, plane, p.q16_map, p.q16_map_words);
+                                         nullptr, plane, p.q16_map + map_words_off, p.q16_map_words);
     if (r != EDT_OK) return r;
     launched = true;
     list.count = count;
@@ -373,7 +401,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
   // volume (one slab), the tiles of pass Y that qualify write their results over their indices -- 2 bytes per voxel out
   // of pass Y and into pass Z instead of 4 -- and pass Z reads every row from wherever pass Y left it.  (debug bit
   // 0x10000000: fp32 between the passes.)
-  bool plane16 = q16 && index_form && zpass && p.xy_slab >= sz && !(g_debug_mode & (kQ16Off | 0x10000000)) &&
+  bool plane16 = q16 && index_form && zpass && p.codes_whole && !(g_debug_mode & (kQ16Off | 0x10000000)) &&
                        column_pass_q16_supported(p.gy) && column_pass_q16_supported(p.gz) &&
                        column_pass_wave_supported(p.gy) && column_pass_wave_supported(p.gz);
   bool y_sure = true;  // every tile of pass Y was served by the integer kernel, provably (q16_cannot_refuse)
@@ -385,12 +413,14 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     for (int64_t z0 = 0; z0 < sz; z0 += p.xy_slab) {
       const int64_t zc = std::min<int64_t>(p.xy_slab, sz - z0);
       const char *lab = static_cast<const char *>(d_labels) + (size_t)(z0 * sxy) * lsz;
+      // (one slab of indices taken in turn, or -- codes_whole -- every slab's own part of a whole-volume buffer: the 16-bit plane)
+      uint16_t *slab_codes = p.codes + ((p.codes_whole && !one) ? z0 * sxy : 0);
       {
         // (slice 0 of a later slab compares against the slice below it through the halo pointer of the sharded path)
         ScopedPass t(one ? "x_pass" : nullptr, stream);
         rc = launch_row_pass_wave(dtype, lab, nullptr, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl,
                                   zpass ? p.zs_y + z0 * wpl : nullptr, sx, sy, zc, wx, bb, bb ? 0 : 1, stream,
-                                  z0 > 0 ? lab - (size_t)sxy * lsz : nullptr, p.codes);
+                                  z0 > 0 ? lab - (size_t)sxy * lsz : nullptr, slab_codes, signed_tf);
         if (rc != EDT_OK) return rc;
         if (binary_yz) {
           AxisGeom gb = p.gy;
@@ -405,13 +435,13 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
         g.nouter = zc;
         TileList list;
         bool launched = false;
-        rc = q16_pass(cur + z0 * sxy, p.codes, p.rs_y + z0 * wpl, g, 1, zpass ? 0 : last_epi, list, plane16 ? p.codes : nullptr,
-                      true, launched);
+        rc = q16_pass(cur + z0 * sxy, slab_codes, p.rs_y + z0 * wpl, g, 1, zpass ? 0 : last_epi, list, plane16 ? slab_codes : nullptr,
+                      true, launched, (p.codes_whole && !one) ? z0 / 32 : 0);
         if (rc != EDT_OK) return rc;
         if (!launched) plane16 = false;  // (nothing wrote the plane or said where the rows are: pass Z reads fp32 values)
         y_sure = y_sure && list.none;
         if (!list.none)
-          rc = launch_column_pass_wave_codes(cur + z0 * sxy, p.codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
+          rc = launch_column_pass_wave_codes(cur + z0 * sxy, slab_codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
                                              zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream, nullptr, list);
         if (rc != EDT_OK) return rc;
       }
@@ -420,8 +450,12 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     // labels are read once: pass 1 also emits the run bit-planes of the y and z axes
     {
       ScopedPass t("x_pass", stream);
-      rc = launch_row_bits(dtype, d_labels, cur, p.nz_y, p.rs_y, zpass ? p.zs_y : nullptr, sx, sy, sz,
-                           wx, bb, bb ? 0 : 1, stream);
+      if (signed_tf)  // (signed_transform_supported: the register kernel of pass X serves this shape)
+        rc = launch_row_pass_wave(dtype, d_labels, cur, p.nz_y, p.rs_y, zpass ? p.zs_y : nullptr, sx, sy, sz, wx, bb, bb ? 0 : 1,
+                                  stream, nullptr, nullptr, 1);
+      else
+        rc = launch_row_bits(dtype, d_labels, cur, p.nz_y, p.rs_y, zpass ? p.zs_y : nullptr, sx, sy, sz,
+                             wx, bb, bb ? 0 : 1, stream);
       if (rc != EDT_OK) return rc;
       if (binary_yz) rc = launch_planes_one_run(p.nz_y, p.rs_y, zpass ? p.zs_y : nullptr, p.gy, 0, stream);
       if (rc != EDT_OK) return rc;
@@ -486,7 +520,23 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     if (rc != EDT_OK) return rc;
   }
   if (cur != d_out) { set_error("internal: result buffer mismatch"); return EDT_ERR_HIP; }
+  if (signed_tf) {
+    ScopedPass t("sign", stream);
+    rc = launch_negate_background(dtype, d_labels, d_out, p.voxels, stream);
+    if (rc != EDT_OK) return rc;
+  }
   return EDT_OK;
+}
+
+// The one-transform form of sdf / sdfsq needs pass X on the register kernel (the only pass-X kernel that takes zero_label)
+// and in-place column passes (their kernels never look at label values: run-start bits and field values only).
+bool signed_transform_supported(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
+  if (ndim < 2 || ndim > 3 || dtype_size(dtype) == 0 || sx < 1 || sy < 1 || sz < 1) return false;
+  if ((flags & (EDT_FLAG_FORCE_GENERIC | EDT_FLAG_BINARY_YZ)) || env_force_generic() || (g_debug_mode & 32)) return false;
+  if (!row_pass_wave_supported(dtype, sx, sy, sz)) return false;
+  if (!column_inplace_supported(make_geom_y(sx, sy, sz))) return false;
+  const bool zpass = ndim == 3 && !(flags & EDT_FLAG_BATCH_2D);
+  return !zpass || column_inplace_supported(make_geom_z(sx, sy, sz));
 }
 
 const char *last_error_cstr() { return g_last_error.c_str(); }
@@ -516,6 +566,11 @@ size_t edt_hip_workspace_bytes_flags(int dtype, int ndim, int64_t sx, int64_t sy
   if (check_shape(dtype, ndim, sx, sy, sz) != EDT_OK) return 0;
   if (sx == 0 || sy == 0 || sz == 0) return 256;
   return make_plan(dtype, ndim, sx, sy, sz, nullptr, flags).bytes;
+}
+
+int edt_hip_signed_supported(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
+  if (check_shape(dtype, ndim, sx, sy, sz) != EDT_OK) return 0;
+  return signed_transform_supported(dtype, ndim, sx, sy, sz, flags) ? 1 : 0;
 }
 
 size_t edt_hip_workspace_bytes(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz) {

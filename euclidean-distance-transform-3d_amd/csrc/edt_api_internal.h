@@ -41,6 +41,7 @@ bool env_force_generic();  // EDT_HIP_FORCE_GENERIC=1: every call takes the fall
 int check_shape(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz);
 int check_voxel_sizes(int naxes, float &wx, float &wy, float &wz);  // (drops the sign of wy / wz: they enter as squares)
 int check_column_voxel_size(float &w);
+bool signed_transform_supported(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags);  // EDT_FLAG_SIGNED
 int require_device();
 // the pass pipeline on device-resident data
 int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx, float wy, float wz,

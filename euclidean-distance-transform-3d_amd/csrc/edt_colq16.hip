@@ -45,6 +45,13 @@
 #ifndef EDT_Q16_NT_FILL
 #define EDT_Q16_NT_FILL 0
 #endif
+// A/B (round 6): wave priority of the fill phase -- a workgroup that has just started gets its loads out ahead of the ALU work of
+// its neighbours on the SIMD (s_setprio; 0 = off).  Measured with priority 2, same box, two runs each: cfg2 pass Y 0.1793 ->
+// 0.1780 ms, pass Z 0.2118 -> 0.2598 (the fp32 fill's conversions run at the raised priority too and starve the stores of the
+// neighbours); cfg3 0.695 -> 0.744 ms per step.  Left off.
+#ifndef EDT_Q16_PRIO
+#define EDT_Q16_PRIO 0
+#endif
 #if EDT_Q16_NT_FILL
 #define EDT_Q16_FILL_LOAD(p) __builtin_nontemporal_load(p)
 #else
@@ -141,6 +148,9 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   const int cols_left = (int)(g.sx - x0);
 
   // ---- phase 0: the tile, HBM -> 16-bit LDS image ------------------------------------------
+#if EDT_Q16_PRIO
+  __builtin_amdgcn_s_setprio(EDT_Q16_PRIO);
+#endif
   typedef uint32_t v2u __attribute__((ext_vector_type(2)));
   typedef uint32_t v4u __attribute__((ext_vector_type(4)));
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -273,6 +283,9 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       }
     }
   }
+#if EDT_Q16_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // (every wave publishes its own verdict: no initialisation to order against, and no static LDS -- __syncthreads_or has
   // some, and hipFuncSetAttribute then refuses the full 160 KiB of dynamic LDS)
   ovq |= ((ov01 & 0xFFFFu) ? 1u : 0u) | ((ov01 >> 16) ? 2u : 0u) | ((ov23 & 0xFFFFu) ? 4u : 0u) | ((ov23 >> 16) ? 8u : 0u);
@@ -653,6 +666,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
             const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
             L.win = ((uint64_t)hi << 32) | lo;
             L.reach = flat_reach_full(bm + cw * 6, gi);
+            L.bmw = bm + cw * 6;
           }
           pk best[kB];
           block_eval<BB, 1, true>(L, best);

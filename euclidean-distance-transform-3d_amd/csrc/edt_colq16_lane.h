@@ -70,6 +70,15 @@ EDT_LANE pk pk_sar15(pk a) { return __builtin_bit_cast(pk, __builtin_bit_cast(q1
 EDT_LANE int q16_clz(uint32_t v) { return __builtin_clz(v); }
 EDT_LANE int q16_ctz(uint32_t v) { return __builtin_ctz(v); }
 #define EDT_Q16_ANY(cond) (__ballot(cond) != 0ull)
+// wave-wide minimum / maximum of a small non-negative integer, as a wave-uniform value (the wide form's window limits: rare path)
+EDT_LANE int q16_wave_min(int v) {
+  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o < v ? o : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+EDT_LANE int q16_wave_max(int v) {
+  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m); v = o > v ? o : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
 #define EDT_Q16_UNROLL _Pragma("unroll")
 #define EDT_Q16_ROLLED _Pragma("unroll 1")
 // (keeps the compiler from re-deriving a select mask as two 16-bit compares, two selects and a byte permute)
@@ -98,6 +107,8 @@ EDT_LANE pk pk_sar15(pk a) { return q16_mk((a & 0x8000u) ? 0xFFFFu : 0u, (a & 0x
 EDT_LANE int q16_clz(uint32_t v) { return __builtin_clz(v); }
 EDT_LANE int q16_ctz(uint32_t v) { return __builtin_ctz(v); }
 #define EDT_Q16_ANY(cond) (cond)
+EDT_LANE int q16_wave_min(int v) { return v; }  // (the emulation plays every lane on its own)
+EDT_LANE int q16_wave_max(int v) { return v; }
 #define EDT_Q16_UNROLL
 #define EDT_Q16_ROLLED
 #define EDT_Q16_OPAQUE(x) ((void)0)
@@ -353,8 +364,28 @@ struct Block {
   uint32_t dmax;         // q16_dmax(a)
   uint64_t win;          // break bits around the block (flat_reach)
   int reach;             // wide form: the flat reach over the whole column (flat_reach_full); unused otherwise
-  const uint32_t *bmw;   // the six mask words of the block's column pair (flat_reach_full)
+  const uint32_t *bmw;   // the six mask words of the block's column pair / (wide form) image column
+  // wide form, set by block_eval (wave-uniform): windows of +inf rows.  dskip: every step d <= dskip looks at +inf rows only,
+  // on both sides, in every lane of the wave (the wave's blocks lie inside stretches of rows without any boundary: such a
+  // window STARTS at the stretch's end instead of walking there); dend: beyond this distance no lane of the wave has a
+  // finite row left in its column (the window ENDS there: c_d = +inf) -- round 6, ADVICE r5: a column with ONE finite
+  // row ran its windows to sqrt(d0^2 + N / a) steps, hundreds, for nothing
+  mutable int dskip, dend;
 };
+
+// (wide form) the rows of a column that may hold finite values: all of them lie in [jfirst, jlast] (jfirst > jlast: none).
+// m: the six mask words of the image column (block g = bit g of words 1..4); first / last: the column's rows 0 and n - 1.
+// A stretch of finite rows inside +inf rows has a break at either end (|N - inf| > a); one that touches an end of the column
+// has none there, which the end rows themselves tell.
+EDT_LANE void finite_extent(const uint32_t *m, uint32_t first, uint32_t last, int n, int &jfirst, int &jlast) {
+  const uint64_t lo64 = ((uint64_t)m[2] << 32) | m[1], hi64 = ((uint64_t)m[4] << 32) | m[3];
+  const bool any = (lo64 | hi64) != 0ull;
+  const int fb = lo64 ? __builtin_ctzll(lo64) : (hi64 ? 64 + __builtin_ctzll(hi64) : 0);
+  const int lb = hi64 ? 127 - __builtin_clzll(hi64) : (lo64 ? 63 - __builtin_clzll(lo64) : 0);
+  jfirst = first < kInfW ? 0 : (any ? 8 * fb : n);
+  jlast = last < kInfW ? n - 1 : (any ? 8 * lb + 6 : -1);
+  if (jlast > n - 1) jlast = n - 1;
+}
 
 // S = output stride: 1 = every row of the block is evaluated; 2 = a block is 16 rows of which the even ones are evaluated (the
 // doubled grids of the voxel-graph transform, whose odd rows are never read again) -- every row is a candidate either way.
@@ -377,10 +408,10 @@ struct Steps {
   }
   // c_d as a (packed) constant (wave-uniform: scalar arithmetic), +inf once it leaves the range
   EDT_LANE_MEMBER pk cpk(int d) const {
-    // (wide form: beyond the column's length there are only +inf rows -- c_d = +inf there ends a window whose minima are +inf
-    // themselves, rows without any boundary, which no finite c_d ever reaches; as a scalar select, not as the loop's bound: a
-    // variable bound tips the kernel into scratch)
-    if constexpr (W) return d > L.n ? kInfW : X::cval((uint64_t)a * (uint32_t)(d * d));
+    // (wide form: beyond the column's length -- beyond the last finite row of any of the wave's columns: L.dend -- there are
+    // only +inf rows: c_d = +inf there ends a window whose minima are +inf themselves, rows without any boundary, which no
+    // finite c_d ever reaches; as a scalar select, not as the loop's bound: a variable bound tips the kernel into scratch)
+    if constexpr (W) return d > L.dend ? kInfW : X::cval((uint64_t)a * (uint32_t)(d * d));
     const uint32_t c = a * (uint32_t)(d * d);
     return pk_both(c < kInf ? c : kInf);
   }
@@ -459,7 +490,18 @@ struct Steps {
         rhi[s % R] = w[K + B - 1 + s];
       }
       const uint32_t *slo = L.img, *shi = L.img;
-      for (int d0 = K + 1; d0 < 4096; d0 += R) {
+      int dstart = K + 1;
+      if constexpr (W) {
+        // the wave's blocks lie inside stretches of +inf rows: every step up to L.dskip would look at +inf rows on both sides
+        // in every lane -- the window starts at the last ring phase before the stretch ends, its rings holding what those
+        // steps would have left there: +inf (wave-uniform branch)
+        if (L.dskip > K + R) {
+          dstart = K + 1 + ((L.dskip - K) & ~(R - 1));
+          EDT_Q16_UNROLL
+          for (int i = 0; i < R; ++i) rlo[i] = rhi[i] = kInfW;
+        }
+      }
+      for (int d0 = dstart; d0 < 4096; d0 += R) {
         bool done = false;
         EDT_Q16_UNROLL
         for (int e = 0; e < R; e += 2) {  // steps d, d + 1 with d = d0 + e;  d mod R == (1 + e) mod R
@@ -614,6 +656,26 @@ EDT_LANE void block_eval(const Block &L, pk (&best)[kB]) {
         if (!EDT_Q16_ANY(X::subs(bmax, X::cval((uint64_t)L.a * D2 * D2)) != 0u)) return;
       }
     }
+  }
+  L.dskip = 0;
+  L.dend = L.n;
+  if constexpr (W) {
+    // Windows over +inf rows (round 6).  A block without a break whose first row is +inf holds +inf rows only, and so do the
+    // rows within its flat reach (a finite neighbour of a +inf row is always a break): the steps up to the smallest such
+    // reach of the wave are skipped.  And no window needs to look further than the finite rows of its column reach.
+    const int r1 = L.reach;
+    const bool own_inf = r1 > 0 && w[K] >= kInfW;
+    L.dskip = q16_wave_min(own_inf ? (r1 < 4096 ? r1 : 4096) : 0);
+    int jf, jl;
+    finite_extent(L.bmw, L.img[kPad * RW + L.cp], L.img[(L.n - 1 + kPad) * RW + L.cp], L.n, jf, jl);
+    int lane_end = 0;
+    if (jf <= jl) {
+      const int e1 = L.p0 + NR - 1 - jf, e2 = jl - L.p0;
+      lane_end = e1 > e2 ? e1 : e2;
+      lane_end = lane_end > 0 ? lane_end : 0;
+    }
+    const int de = q16_wave_max(lane_end);
+    L.dend = de < L.n ? de : L.n;
   }
   Steps<BB, S, W> steps{L, w, best, PB, bmax, L.a};
   steps.template run<1>();

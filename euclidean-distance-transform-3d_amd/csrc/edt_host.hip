@@ -237,8 +237,8 @@ static int run_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
 
 
 // sdf / sdfsq on host buffers in ONE round trip (reference: src/edt.pyx:121-202, two transforms and a
-// subtraction on the host): labels up once, edt(labels), the background mask and edt(mask) on the device, the
-// difference down once.
+// subtraction on the host): labels up once, the SIGNED transform on the device (one transform: EDT_FLAG_SIGNED; shapes it does
+// not serve: edt(labels), the background mask, edt(mask) and the subtraction), the difference down once.
 static int sdf_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, float wx,
                     float wy, float wz, int flags, float *output) {
   int rc = check_shape(dtype, ndim, sx, sy, sz);
@@ -261,6 +261,16 @@ static int sdf_host(const void *labels, int dtype, int ndim, int64_t sx, int64_t
   if ((rc = d_labels.alloc(lbytes, pooled ? 0 : -1)) != EDT_OK) return rc;
   if ((rc = d_a.alloc(obytes, pooled ? 1 : -1)) != EDT_OK) return rc;
   if ((rc = d_ws.alloc(wbytes, pooled ? 2 : -1)) != EDT_OK) return rc;
+  if (signed_transform_supported(dtype, ndim, sx, sy, sz, flags)) {
+    // ONE transform (EDT_FLAG_SIGNED, edt_api.hip): label 0 measured like every label, its voxels negated at the end
+    Prefault touch(output, obytes);
+    EDT_HIP_TRY(hipMemcpy(d_labels.p, labels, lbytes, hipMemcpyHostToDevice));
+    rc = run_device(d_labels.p, dtype, ndim, sx, sy, sz, wx, wy, wz, flags | EDT_FLAG_SIGNED, (float *)d_a.p, d_ws.p, wbytes, nullptr);
+    if (rc != EDT_OK) return rc;
+    touch.join();
+    EDT_HIP_TRY(hipMemcpy(output, d_a.p, obytes, hipMemcpyDeviceToHost));
+    return EDT_OK;
+  }
   if ((rc = d_mask.alloc((size_t)voxels, pooled ? 3 : -1)) != EDT_OK) return rc;
   if ((rc = d_b.alloc(obytes, pooled ? 4 : -1)) != EDT_OK) return rc;
   Prefault touch(output, obytes);

@@ -56,6 +56,7 @@ int launch_column_pass_serial(const float *fin, float *fout, const uint32_t *nz,
 int launch_subtract(const float *a, const float *b, float *out, int64_t count, hipStream_t stream);
 int launch_is_background(int dtype, const void *labels, uint8_t *mask, int64_t count,
                          hipStream_t stream);
+int launch_negate_background(int dtype, const void *labels, float *f, int64_t count, hipStream_t stream);  // f = labels == 0 ? -f : f
 int launch_select_label(int dtype, const void *labels, const float *dt, float *out, const void *key,
                         int64_t count, hipStream_t stream);
 
@@ -174,7 +175,8 @@ bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz);
 // codes != nullptr: 16-bit distance indices are written there INSTEAD of `out` (see XFuse)
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                         int to_finite, hipStream_t stream, const void *halo = nullptr, uint16_t *codes = nullptr);
+                         int to_finite, hipStream_t stream, const void *halo = nullptr, uint16_t *codes = nullptr,
+                         int zero_label = 0);  // zero_label: label 0 is measured like every label (the signed transform)
 // k * w exact for every k of a row of sx voxels: the 16-bit index form (codes) is bit-identical
 bool row_codes_exact(float w, int64_t sx);
 

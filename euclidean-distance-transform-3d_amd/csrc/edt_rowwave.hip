@@ -97,7 +97,7 @@ template <typename T, int NC, bool HAS_Z, bool FULL, bool C16, int H = 1>
 __global__ void __launch_bounds__((H >= 2 ? H : kRowWaves) * 64)
 k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t *__restrict__ nz_y,
                 uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, float w,
-                int bb, int to_finite, int nby, int ngroups, int xcd_sched, const T *__restrict__ halo) {
+                int bb, int to_finite, int nby, int ngroups, int xcd_sched, const T *__restrict__ halo, int zero_label) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *Ttab = reinterpret_cast<float *>(smem);  // [sx + 3]: T[0..sx+1], then +inf
   int *xchg = reinterpret_cast<int *>(smem) + ((sx + 3 + 3) & ~3);  // H >= 2: [row parity][part][last, first] boundary positions
@@ -192,7 +192,9 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         M[c] = __ballot(lab[c] != left[c]);
-        const unsigned long long fg = __ballot(lab[c] != T(0));
+        // (zero_label: the SIGNED transform -- label 0 is a label like any other, its runs are measured like every run, and
+        // the foreground plane says "everything": edt_api.hip, EDT_FLAG_SIGNED)
+        const unsigned long long fg = zero_label ? ~0ull : __ballot(lab[c] != T(0));
         shift_in(nzw[c], fg);
         shift_in(ysw[c], __ballot(lab[c] != above[c]));
         if (HAS_Z) shift_in(zsw[c], __ballot(lab[c] != below[c]));
@@ -368,7 +370,7 @@ bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
 template <typename T, int NC, int H = 1>
 static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                               uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                              int to_finite, hipStream_t stream, const void *halo, bool codes) {
+                              int to_finite, hipStream_t stream, const void *halo, bool codes, int zero_label) {
   const int64_t nby = ceil_div(sy, kBandRows);
   const int64_t ngroups = nby * sz;
   if (ngroups <= 0) return EDT_OK;
@@ -382,7 +384,7 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
 #define LAUNCH(Z, F, C)                                                                                   \
   hipLaunchKernelGGL((k_row_pass_wave<T, NC, Z, F, C, H>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream,  \
                      (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb, to_finite, \
-                     (int)nby, (int)ngroups, xcd_sched, (const T *)halo)
+                     (int)nby, (int)ngroups, xcd_sched, (const T *)halo, zero_label)
 #define LAUNCH_C(Z, F) do { if (codes) LAUNCH(Z, F, true); else LAUNCH(Z, F, false); } while (0)
   const bool full = sx == 64 * NC * H;
   if (zs_y != nullptr) { if (full) LAUNCH_C(true, true); else LAUNCH_C(true, false); }
@@ -396,9 +398,9 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
 template <typename T>
 static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                              uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                             int to_finite, hipStream_t stream, const void *halo, bool codes) {
+                             int to_finite, hipStream_t stream, const void *halo, bool codes, int zero_label) {
   const int64_t nc = ceil_div(sx, 64);
-#define GO(N) return launch_row_wave_tn<T, N>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes)
+#define GO(N) return launch_row_wave_tn<T, N>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes, zero_label)
   if (nc <= 1) GO(1);
   if (nc <= 2) GO(2);
   if (nc <= 4) GO(4);
@@ -406,14 +408,14 @@ static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uin
   if (nc <= 16) GO(16);
 #undef GO
   // rows of 1025..2048 voxels: two waves per row (H = 2), halves of 10, 12, 14 or 16 chunks
-#define GO2(N) return launch_row_wave_tn<T, N, 2>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes)
+#define GO2(N) return launch_row_wave_tn<T, N, 2>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes, zero_label)
   if (nc <= 20) GO2(10);
   if (nc <= 24) GO2(12);
   if (nc <= 28) GO2(14);
   if (nc <= 32) GO2(16);
 #undef GO2
   // rows of 2049..4096 voxels: four waves per row (H = 4), parts of 12 or 16 chunks
-#define GO4(N) return launch_row_wave_tn<T, N, 4>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes)
+#define GO4(N) return launch_row_wave_tn<T, N, 4>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes, zero_label)
   if (nc <= 48) GO4(12);
   GO4(16);
 #undef GO4
@@ -421,11 +423,11 @@ static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uin
 
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                         int to_finite, hipStream_t stream, const void *halo, uint16_t *codes) {
+                         int to_finite, hipStream_t stream, const void *halo, uint16_t *codes, int zero_label) {
   // codes != nullptr: the 16-bit distance indices go there and `out` is not touched
   if (codes != nullptr) out = reinterpret_cast<float *>(codes);
 #define ROW_WAVE(T) \
-  return launch_row_wave_t<T>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes != nullptr)
+  return launch_row_wave_t<T>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes != nullptr, zero_label)
   switch (dtype) {
     case EDT_U8: case EDT_BOOL: ROW_WAVE(uint8_t);
     case EDT_U16: ROW_WAVE(uint16_t);

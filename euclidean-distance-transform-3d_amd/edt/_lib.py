@@ -23,6 +23,7 @@ FLAG_FORCE_GENERIC = 4
 FLAG_BATCH_2D = 8
 FLAG_SMALL_WORKSPACE = 16
 FLAG_BINARY_YZ = 32
+FLAG_SIGNED = 64
 
 OK = 0
 ERR_NO_DEVICE = -1
@@ -57,6 +58,7 @@ SIGNATURES = {
     "edt_hip_set_devices": (_i, [_vp, _i]),
     "edt_hip_multi_supported": (_i, [_i, _i64, _i64, _i64, _i]),
     "edt_hip_sdf": (_i, [_vp, _i, _i, _i64, _i64, _i64, _f, _f, _f, _i, _i, _vp]),
+    "edt_hip_signed_supported": (_i, [_i, _i, _i64, _i64, _i64, _i]),
     "edt_hip_workspace_bytes": (_sz, [_i, _i, _i64, _i64, _i64]),
     "edt_hip_workspace_bytes_flags": (_sz, [_i, _i, _i64, _i64, _i64, _i]),
     "edt_hip_index_form_exact": (_i, [_f, _i64]),

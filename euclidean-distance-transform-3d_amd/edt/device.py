@@ -87,9 +87,11 @@ class Plan:
         return self._generic_ws
 
     def run(self, labels: torch.Tensor, weights_xyz, black_border=False, sqrt=False,
-            out: torch.Tensor | None = None, force_generic=False, batch2d=False, binary=False) -> torch.Tensor:
+            out: torch.Tensor | None = None, force_generic=False, batch2d=False, binary=False,
+            signed=False) -> torch.Tensor:
         """Enqueue the transform of ``labels`` (device, contiguous, ``voxels`` elements).  binary: the reference's
-        binary route for multi-valued labels (EDT_FLAG_BINARY_YZ: labels split runs along x only)."""
+        binary route for multi-valued labels (EDT_FLAG_BINARY_YZ: labels split runs along x only).  signed: the signed
+        transform (EDT_FLAG_SIGNED: sdf / sdfsq as ONE transform; :meth:`signed_supported` says whether the shape is served)."""
         if not labels.is_cuda or not labels.is_contiguous():
             raise ValueError("labels must be a contiguous device tensor")
         if labels.numel() != self.voxels:
@@ -103,13 +105,18 @@ class Plan:
         w = tuple(float(np.float32(v)) for v in weights_xyz) + (1.0,) * (3 - self.ndim)
         flags = ((_lib.FLAG_BLACK_BORDER if black_border else 0) | (_lib.FLAG_SQRT if sqrt else 0)
                  | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
-                 | (_lib.FLAG_BATCH_2D if batch2d else 0) | (_lib.FLAG_BINARY_YZ if binary else 0) | self.base_flags)
+                 | (_lib.FLAG_BATCH_2D if batch2d else 0) | (_lib.FLAG_BINARY_YZ if binary else 0)
+                 | (_lib.FLAG_SIGNED if signed else 0) | self.base_flags)
         ws = self._workspace_for(flags)
         rc = self.lib.edt_hip_edtsq_device(
             ctypes.c_void_p(labels.data_ptr()), self.code, self.ndim, *self.ext, w[0], w[1], w[2],
             flags, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr())
         _lib.check(rc)
         return out
+
+
+    def signed_supported(self) -> bool:
+        return bool(self.lib.edt_hip_signed_supported(self.code, self.ndim, *self.ext, self.base_flags))
 
 
 _plans: dict = {}
@@ -126,7 +133,8 @@ def _plan_for(ext, code, device) -> Plan:
     return _plans[key]
 
 
-def _transform(labels, anisotropy, black_border, sqrt, force_generic=False, binary=False):
+def _transform(labels, anisotropy, black_border, sqrt, force_generic=False, binary=False, signed=False):
+    """signed: the signed transform where the shape is served (one transform), None returned where it is not"""
     labels = as_device_tensor(labels)
     if labels.numel() == 0:
         return torch.zeros(labels.shape, dtype=torch.float32, device=labels.device)
@@ -140,7 +148,9 @@ def _transform(labels, anisotropy, black_border, sqrt, force_generic=False, bina
     ext = tuple(labels.shape[::-1])
     w = an[::-1]
     plan = _plan_for(ext, dtype_code(labels.dtype), labels.device)
-    return plan.run(labels, w, black_border, sqrt, force_generic=force_generic, binary=binary)
+    if signed and not plan.signed_supported():
+        return None
+    return plan.run(labels, w, black_border, sqrt, force_generic=force_generic, binary=binary, signed=signed)
 
 
 def binary_edtsq(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
@@ -188,15 +198,32 @@ def edt_stack(images: torch.Tensor, anisotropy=None, black_border=False) -> torc
 
 
 def sdf(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
-    """``edt(x) - edt(x == 0)`` without leaving the device (reference: src/edt.pyx:148-158)."""
+    """``edt(x) - edt(x == 0)`` without leaving the device (reference: src/edt.pyx:148-158) -- as ONE transform where the
+    shape allows (EDT_FLAG_SIGNED: label 0 measured like every label, its voxels negated; bit-identical to the definition,
+    whose two fields have disjoint supports), else as the two transforms and the subtraction."""
+    return _signed(labels, anisotropy, black_border, sqrt=True)
+
+
+def sdfsq(labels: torch.Tensor, anisotropy=None, black_border=False) -> torch.Tensor:
+    """``edtsq(x) - edtsq(x == 0)`` without leaving the device (reference: src/edt.pyx:161-202)."""
+    return _signed(labels, anisotropy, black_border, sqrt=False)
+
+
+def _signed(labels, anisotropy, black_border, sqrt, one_transform=True):
     lib = _lib.load()
     labels = as_device_tensor(labels).contiguous()
-    dt = _transform(labels, anisotropy, black_border, sqrt=True)
+    if labels.numel() == 0:
+        return torch.zeros(labels.shape, dtype=torch.float32, device=labels.device)
+    if one_transform and 2 <= labels.dim() <= 3:
+        dt = _transform(labels, anisotropy, black_border, sqrt=sqrt, signed=True)
+        if dt is not None:
+            return dt
+    dt = _transform(labels, anisotropy, black_border, sqrt=sqrt)
     mask = torch.empty(labels.shape, dtype=torch.bool, device=labels.device)
     _lib.check(lib.edt_hip_is_background_device(
         ctypes.c_void_p(labels.data_ptr()), dtype_code(labels.dtype),
         ctypes.c_void_p(mask.data_ptr()), labels.numel(), _stream_ptr()))
-    bg = _transform(mask, anisotropy, black_border, sqrt=True)
+    bg = _transform(mask, anisotropy, black_border, sqrt=sqrt)
     _lib.check(lib.edt_hip_subtract_device(
         ctypes.c_void_p(dt.data_ptr()), ctypes.c_void_p(bg.data_ptr()),
         ctypes.c_void_p(dt.data_ptr()), dt.numel(), _stream_ptr()))

@@ -67,6 +67,11 @@ enum {
                                 src/edt.hpp:487-576, :681-755): labels split runs in pass X only; passes Y and Z treat every
                                 column as one envelope from its first non-zero value on, background voxels as height-0
                                 sites.  Identical to the ordinary transform on 0/1 input. */
+  EDT_FLAG_SIGNED = 64,      /* edt_hip_edtsq_device: the SIGNED transform -- sdf / sdfsq of the reference's Python layer
+                                (src/edt.pyx:121-202: edt(x) - edt(x == 0)) as ONE transform: label 0 is measured like every
+                                other label and its voxels come out negated.  Bit-identical to the two-transform definition
+                                (the two fields have disjoint supports, and a voxel's value depends only on the voxels of its
+                                own label runs).  Shapes: edt_hip_signed_supported; others: EDT_ERR_UNSUPPORTED. */
   EDT_FLAG_SMALL_WORKSPACE = 16 /* scratch = the four bit planes only (1/2 byte per voxel): passes X and Y then
                                 exchange fp32 values instead of 16-bit distance indices (no 256 MiB index slab,
                                 about 7 % slower at 512^3); pass it to edt_hip_workspace_bytes_flags as well */
@@ -78,6 +83,8 @@ int edt_hip_device_count(void);         /* number of visible HIP devices (0 if n
  * of the voxel size (src/edt.hpp:97, :113) then ARE the multiples, and pass X may hand pass Y 16-bit distance indices
  * instead of fp32 values (needs no device; exported so that tests can hold the criterion against its property). */
 int edt_hip_index_form_exact(float wx, int64_t sx);
+/* 1 if edt_hip_edtsq_device serves EDT_FLAG_SIGNED for this shape and these flags (needs no device) */
+int edt_hip_signed_supported(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags);
 const char *edt_hip_last_error(void);   /* thread-local, never NULL                   */
 const char *edt_hip_version(void);
 

@@ -104,6 +104,7 @@ void tile_pass_wide(const float *Fin, const uint16_t *codes, const uint32_t *rsb
           const uint32_t hi = (uint32_t)((((uint64_t)e2 << 32) | e1) >> sh);
           L.win = ((uint64_t)hi << 32) | lo;
           L.reach = flat_reach_full(bm.data() + cw * 6, gi);
+          L.bmw = bm.data() + cw * 6;
         }
         pk best[kB];
         block_eval<BB, 1, true>(L, best);

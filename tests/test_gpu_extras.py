@@ -100,6 +100,40 @@ def test_negative_voxel_size_along_y_or_z_is_its_magnitude(edt_gpu, oracle_port)
         edt_gpu.edtsq(lab, anisotropy=(-2.0, 3.0, 5.0))
 
 
+def test_signed_transform_is_the_two_transform_definition(edt_gpu, oracle_port):
+    """sdf / sdfsq as ONE transform (EDT_FLAG_SIGNED, round 6): label 0 measured like every other label, its voxels negated --
+    against the definition edt(x) - edt(x == 0) computed by the oracle, and against this library's own two-transform
+    composition, over label types, orders, border modes, voxel sizes with and without a quantum, 2-D and 3-D."""
+    import torch
+    from edt import _lib, device
+
+    rng = np.random.default_rng(79)
+    cases = [((48, 140, 132), (6.0, 6.0, 30.0)), ((40, 100, 36), (1.0, 1.0, 1.0)), ((33, 70, 41), (0.7, 1.3, 2.0)),
+             ((64, 200), (1.0, 2.0)), ((130, 37), (3.58, 4.0)), ((512, 40, 40), (4.0, 4.0, 40.0))]
+    dtypes = [np.uint8, np.uint16, np.uint32, np.uint64, np.float32, bool]
+    for i, (shape, an) in enumerate(cases):
+        lab = blocky_labels(shape, nlabels=4, zero_frac=0.45, block=int(rng.integers(3, 12)), rng=rng).astype(dtypes[i % len(dtypes)])
+        code = {1: _lib.U8, 2: _lib.U16, 4: _lib.U32, 8: _lib.U64}[lab.dtype.itemsize] if lab.dtype.kind in "ub" else _lib.F32
+        ext = tuple(shape[::-1]) + (1,) * (3 - len(shape))   # C order: x is the last axis
+        assert _lib.load().edt_hip_signed_supported(code, len(shape), *ext, 0) == 1
+        for bb in (True, False):
+            for arr in (lab, np.asfortranarray(lab)):
+                want, wantsq = oracle_port.sdf(arr, an, bb), oracle_port.sdfsq(arr, an, bb)
+                assert (want < 0).any() and (want > 0).any()
+                assert np.array_equal(edt_gpu.sdf(arr, anisotropy=an, black_border=bb), want, equal_nan=True), (shape, an, bb)
+                assert np.array_equal(edt_gpu.sdfsq(arr, anisotropy=an, black_border=bb), wantsq, equal_nan=True), (shape, an, bb)
+            t = torch.from_numpy(np.ascontiguousarray(lab)).cuda()
+            one = device.sdf(t, anisotropy=an, black_border=bb)
+            two = device._signed(t, an, bb, sqrt=True, one_transform=False)
+            assert torch.equal(one, two) and np.array_equal(one.cpu().numpy(), oracle_port.sdf(lab, an, bb), equal_nan=True)
+            assert torch.equal(device.sdfsq(t, anisotropy=an, black_border=bb), device._signed(t, an, bb, sqrt=False, one_transform=False))
+    # a volume without any background, without a black border: +inf everywhere, as the definition says (inf - 0)
+    ones = np.ones((36, 100, 100), dtype=np.uint8)
+    assert np.array_equal(edt_gpu.sdf(ones, black_border=False), oracle_port.sdf(ones, None, False))
+    # all background: -inf
+    assert np.array_equal(edt_gpu.sdf(np.zeros_like(ones), black_border=False), oracle_port.sdf(np.zeros_like(ones), None, False))
+
+
 def test_sdf_single_round_trip(edt_gpu, oracle_port):
     rng = np.random.default_rng(77)
     for shape in ((200,), (70, 45), (40, 52, 36)):

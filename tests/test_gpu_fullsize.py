@@ -63,7 +63,9 @@ def test_cfg5_512_sdf_against_compiled_reference(edt_gpu, oracle_ref, an, bb):
     want = oracle_ref.sdf(lab, an, bb, parallel=p)
     assert float(want.min()) < 0.0 < float(want.max())
     t = torch.from_numpy(np.ascontiguousarray(lab.T)).cuda()
-    got = device.sdf(t, anisotropy=an[::-1], black_border=bb).cpu().numpy().T
+    got = device.sdf(t, anisotropy=an[::-1], black_border=bb).cpu().numpy().T      # ONE transform (EDT_FLAG_SIGNED)
+    assert np.array_equal(got, want)
+    got = device._signed(t, an[::-1], bb, sqrt=True, one_transform=False).cpu().numpy().T   # the two-transform composition
     assert np.array_equal(got, want)
     del got
     assert np.array_equal(edt_gpu.sdf(lab, anisotropy=an, black_border=bb), want)

@@ -271,6 +271,62 @@ def test_q16_rows_without_boundary(q16, oracle_port, n, sx):
     assert carried and (refused or n < 280)
 
 
+@pytest.mark.parametrize("n,sx,kind", [(512, 64, "one_row"), (700, 32, "one_voxel"), (512, 96, "stretches"), (1000, 64, "stretches"),
+                                       (333, 64, "top_and_bottom"), (512, 32, "two_rows"), (200, 96, "stretches"), (97, 32, "one_voxel")])
+def test_q16_windows_over_rows_without_boundary(q16, oracle_port, n, sx, kind):
+    """Round 6 (the window of a +inf row): without a black border a column may hold ONE finite row, or finite
+    stretches between long stretches of rows that saw no boundary along x.  The wide form starts such a window where the
+    stretch of +inf rows ends (Block::dskip) and ends it where the column's finite rows end (Block::dend, finite_extent)
+    instead of walking hundreds of steps over +inf -- the results must stay the oracle's for every structure: one finite row,
+    one finite voxel, finite rows at the column's ends (no break there), alternating stretches, every voxel-size pair."""
+    rng = np.random.default_rng(7 * n + sx)
+    lab = np.ones((n, sx), dtype=np.uint32)   # (rows, x): the column pass runs along axis 0
+    if kind == "one_row":
+        lab[n // 2, sx // 3] = 0
+    elif kind == "one_voxel":
+        lab[n // 2, sx // 3] = 0
+        lab[: n // 5] = 2                       # and a label border along the column, far from most rows
+    elif kind == "two_rows":
+        lab[n // 6, 5] = 0
+        lab[n - 1 - n // 7, sx - 3] = 0
+    elif kind == "top_and_bottom":
+        lab[0, sx // 2] = 0                     # finite rows that touch the column's ends: no break marks their outer side
+        lab[n - 1, 3] = 0
+        lab[n // 2, sx - 1] = 5
+    else:                                       # alternating stretches of rows with and without a boundary
+        r = 0
+        while r < n:
+            ln = int(rng.integers(3, max(4, n // 4)))
+            if rng.random() < 0.5:
+                lab[r:r + ln, int(rng.integers(0, sx))] = int(rng.integers(2, 6))   # a second label somewhere in these rows
+            r += ln + int(rng.integers(0, max(2, n // 3)))
+        lab[int(rng.integers(0, n)), :] = 7     # a whole row of another label: +inf along x, a border along the column
+    seen_inf = False
+    for (wx, wy) in ((1.0, 1.0), (6.0, 30.0), (30.0, 6.0), (0.5, 1.0), (2.0, 1.0)):
+        ok, q, a = quantum(q16, (wx, wy))
+        assert ok
+        f1, codes = x_pass(oracle_port, lab, wx, False)
+        assert (codes == 0xFFFF).any()
+        want = oracle_port.raw2d(lab, 2, sx, n, (wx, wy), False).reshape(n, sx)
+        for form in ("f32", "codes"):
+            for epi, full in ((1, 0), (3, 1), (0, 0)):
+                q16.q16_emul_set_full_wide(full)
+                got, tiles = column_pass(q16, lab, f1 if form == "f32" else None, codes if form == "codes" else None,
+                                         q, a[1], a[0], False, epi)
+                q16.q16_emul_set_full_wide(0)
+                exp = np.sqrt(want) if epi & 2 else want
+                if not epi & 1:
+                    exp = np.where(np.isinf(exp), np.finfo(np.float32).max, exp)
+                for i, t_ok in enumerate(tiles):
+                    sl = slice(32 * i, min(sx, 32 * i + 32))
+                    if t_ok:
+                        assert np.array_equal(got[:, sl], exp[:, sl]), (n, sx, kind, wx, wy, form, epi, full, i, int(t_ok))
+                        seen_inf |= bool((codes[:, sl] == 0xFFFF).any())
+                    else:
+                        assert (got[:, sl] == -1.0).all()
+    assert seen_inf or n > 280
+
+
 @pytest.mark.parametrize("n,sx,kind", [(1024, 32, "cells"), (512, 64, "blocky"), (500, 36, "membrane"), (300, 40, "cells"),
                                        (130, 96, "noise"), (257, 40, "blocky"), (64, 32, "cells"), (33, 8, "ones"), (16, 8, "blocky")])
 def test_q16_output_stride_two(q16, oracle_port, n, sx, kind):

@@ -40,7 +40,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
-PROFILE_TAG = "r05"    # profiles/<tag>_traffic.json holds the PMC-derived HBM bytes per launch
+PROFILE_TAG = "r06"    # profiles/<tag>_traffic.json holds the PMC-derived HBM bytes per launch
 HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming kernel reaches on this part (MI355X_MICROARCH.md)
 VG_NATIVE_MODEL_BPV = 42  # bytes per voxel the native voxel-graph form has to move (voxel_graph_secondary)
 WARM_MS = 60.0         # untimed steps run for at least this long before the `--warmup` ones (steady clocks)

@@ -38,6 +38,25 @@ def test_cfg3_512_against_compiled_reference(edt_gpu, oracle_ref, name):
     assert np.array_equal(edt_gpu.edtsq(lab, anisotropy=an, black_border=bb), want)
 
 
+@pytest.mark.parametrize("name", ["sw256", "sphere250", "onesF", "onebg", "diagF", "sphere_slab"])
+def test_object_sweep_against_compiled_reference(edt_gpu, oracle_ref, name):
+    """The object-size sweep of bench.py (tests/synth.py: SWEEP) as parity cases at full size: LARGE objects -- cells ~256 voxels
+    across, one ball of radius 250, a box without any boundary (+inf everywhere), a box with ONE background voxel (every
+    z-column one finite row: the windows of +inf rows, round 6), half spaces cut diagonally without a border (values beyond 16
+    bits AND rows without a boundary in every tile: the wide form throughout), the ball on the 8-GPU slab shape -- against the
+    compiled reference with every host thread, bit for bit; with and without the fused sqrt."""
+    import torch
+    from edt import device
+
+    lab, an, bb = config_volume(name, 512)
+    want = _ref_edtsq(oracle_ref, lab, an, bb)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).cuda()
+    got = device.edtsq(t, anisotropy=an[::-1], black_border=bb).cpu().numpy().T
+    assert np.array_equal(got, want)
+    got = device.edt(t, anisotropy=an[::-1], black_border=bb).cpu().numpy().T
+    assert np.array_equal(got, np.sqrt(want))
+
+
 def test_cfg4_1024_single_gpu_against_compiled_reference(edt_gpu, oracle_ref):
     import torch
     from edt import device

@@ -85,3 +85,49 @@ def test_traffic_table_names_kernels_of_this_build():
     assert named, "the table names no kernel"
     missing = sorted(k for k in named if k not in have)
     assert not missing, f"{table} names kernels this build does not have (profile again): {missing}"
+
+
+def test_traffic_table_names_no_launch_the_build_does_not_make():
+    """round 5's committed kernel statistics of cfg3 / cfg3L still listed the list-mode launches of the
+    fp32 kernel and the memset of the hand-over counters, which that round's final build no longer made there.  Where the
+    library's own host proof (edt_hip_q16_no_refusals: host arithmetic, no device) says a configuration's column passes can
+    refuse no tile, the build launches neither -- so the committed table of this round must not name them for that
+    configuration: the fp32 column kernel (`k_column_pass_wave`) under y_pass / z_pass, or the runtime's fill kernel
+    ("other": the memset)."""
+    import ctypes
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    from edt import _lib
+    from synth import SWEEP
+    table = os.path.join(ROOT, "profiles", f"{bench.PROFILE_TAG}_traffic.json")
+    lib_path = os.path.join(ROOT, "euclidean-distance-transform-3d_amd", "lib", "libedt_hip.so")
+    if not os.path.exists(table) or not os.path.exists(lib_path):
+        pytest.skip("this round's profile has not been taken yet / library not built")
+    lib = _lib.load()
+    # what the profiled configurations are: extents, voxel sizes, border rule (tests/synth.py: config_volume, SWEEP)
+    cfgs = {"cfg1": ((512,) * 3, (1.0, 1.0, 1.0), True), "cfg2": ((512,) * 3, (6.0, 6.0, 30.0), True),
+            "cfg3": ((512,) * 3, (1.0, 1.0, 1.0), False), "cfg3m": ((512,) * 3, (6.0, 6.0, 30.0), False),
+            "cfg3L": ((512,) * 3, (1.0, 1.0, 1.0), False), "cfg3M": ((512,) * 3, (1.0, 1.0, 1.0), False),
+            "cfg3La": ((512,) * 3, (6.0, 6.0, 30.0), False), "cfg3Ma": ((512,) * 3, (6.0, 6.0, 30.0), False),
+            "cfg4": ((1024,) * 3, (1.0, 1.0, 1.0), False)}
+    for name, (kind, par, an, bb) in SWEEP.items():
+        cfgs[name] = ((1024, 1024, 128) if kind == "sphere_slab" else (512,) * 3, an, bb)
+    blob = json.load(open(table))
+    checked = 0
+    for cfg, passes in blob.items():
+        if cfg not in cfgs or not isinstance(passes, dict):
+            continue
+        (sx, sy, sz), w, bb = cfgs[cfg]
+        y, z = ctypes.c_int(-1), ctypes.c_int(-1)
+        rc = lib.edt_hip_q16_no_refusals(sx, sy, sz, w[0], w[1], w[2], 3, int(bb), ctypes.addressof(y), ctypes.addressof(z))
+        if rc != 1:
+            continue
+        for p, sure in (("y_pass", bool(y.value)), ("z_pass", bool(z.value))):
+            kernels = passes.get(p, {}).get("kernels", [])
+            if sure:
+                assert not [k for k in kernels if "k_column_pass_wave" in k], (cfg, p, kernels)
+            checked += 1
+        if y.value and z.value:
+            assert "other" not in passes or passes["other"]["total"] == 0, (cfg, "a memset / fill the build does not launch", passes["other"])
+    assert checked > 0

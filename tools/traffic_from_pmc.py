@@ -25,6 +25,8 @@ def pass_of(name):
         return "x_pass"
     if "k_bits_transpose_yz" in n:
         return "z_bits"
+    if "k_negate_background" in n:
+        return "sign"
     m = re.match(r"k_column_pass_q16<(true|false), (\d)", n)
     if m:
         return "y_pass" if m.group(2) == "1" else "z_pass"

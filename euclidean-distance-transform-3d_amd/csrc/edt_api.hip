@@ -368,7 +368,9 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     }
     uint32_t *count = p.q16_counts + q16_slot++;
     const int r = launch_column_pass_q16(F, codes, rs, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, p.q16_ids, stream,
-                                         nullptr, plane, p.q16_map + map_words_off, p.q16_map_words);
+                                         nullptr, plane, p.q16_map + map_words_off, p.q16_map_words, nullptr, 0, 0,
+                                         // (pass Y into the plane: may a tile of nothing but +inf stay there for pass Z?)
+                                         (axis == 1 && plane != nullptr && codes != nullptr && q16_value_limit(q16_q, q16_a[2], sz, bb) != 0u) ? 1 : 0);
     if (r != EDT_OK) return r;
     launched = true;
     list.count = count;

@@ -74,6 +74,7 @@ struct Q16Args {
   uint32_t nlimw, dmaxw, kmaxw;
   uint32_t fwmax_bits;    // bit pattern of (float)nlimw * q (exact)
   uint32_t inf_ok;        // the wide form carries +inf (no black border, short enough columns: edt_colq16_lane.h, q16_wide_range)
+  uint32_t plane_inf_ok;  // O16: the pass that reads the 16-bit plane carries +inf too -- a tile of nothing but +inf may stay there as 0xFFFF
   uint32_t *count;        // tiles handed to the fp32 kernel: *count of them ...
   uint32_t *ids;          // ... their tile ids (outer index * x-tiles + x-tile) in the fp32 kernel's geometry:
   int list_cols;          // its tiles are 32 columns wide, or 16 (axes of more than 512 rows: two ids per refused tile)
@@ -159,6 +160,10 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   const bool col_ok = 4 * cg < cols_left;
   bool bad = false;   // the tile has no integer form at all: handed to the fp32 kernel
   bool over = false;  // ... no 16-bit form (a value beyond nlim): the wide form if `bad` stays false
+  // Round 6: a tile of NOTHING BUT +inf whose columns hold no run start behind row 0 (no black border: a tile inside one object that
+  // spans the volume along the earlier axes) comes out as +inf, row for row -- no border, no finite site.  It is answered from the
+  // fill (notinf: a value that is not +inf, or a run start) instead of going through two 32-bit passes that find nothing to do.
+  uint32_t notinf = BB ? 1u : 0u;
   // which of the thread's columns (4 cg .. 4 cg + 3) hold such a value: the two halves of ov01 / ov23 (index, plane rows), the
   // low bits of ovq (fp32 rows)
   pk ov01 = 0u, ov23 = 0u;
@@ -172,7 +177,9 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   }
   for (int u = t; u < NB * 32; u += T) {
     const int band = u >> 5, col = u & 31;
-    rsp[u] = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
+    const uint32_t w = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
+    rsp[u] = w;
+    notinf |= band == 0 ? (w & ~1u) : w;  // (row 0 starts a run in every column)
   }
   // (index form: the whole tile in ONE sweep of sixteen loads per thread -- nb32 <= 16 RPS: 512 rows at 256 threads, 1024 at
   // 512: launch_q16_k)
@@ -192,6 +199,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = i0 + RPS * j + r_in;
+        if (!BB && row < n && col_ok) notinf |= ~(kk[j][0] & kk[j][1]);
         if (row < nb32) {
           // k > kmax: the tile has no 16-bit form (k^2 may have wrapped: never used); kmaxw < k < 0xFFFF: no wide form either
           ov01 |= pk_subs(kk[j][0], kmaxpk);
@@ -243,6 +251,11 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const int row = i0 + RPS * j + r_in;
+        if (!BB && row < n && col_ok) {
+          // (+inf: 0xFFFF in a row of the plane, FLT_MAX in a row of fp32 values)
+          if ((in16 >> j) & 1u) notinf |= ~(raw[j][0] & raw[j][1]);
+          else notinf |= (raw[j][0] ^ 0x7F7FFFFFu) | (raw[j][1] ^ 0x7F7FFFFFu) | (raw[j][2] ^ 0x7F7FFFFFu) | (raw[j][3] ^ 0x7F7FFFFFu);
+        }
         if (row < nb32 && ((in16 >> j) & 1u)) {
           // (pass Y's limit may be the larger one; a 16-bit value is always within the wide form's range)
           ov01 |= pk_subs(raw[j][0], nlimpk);
@@ -292,13 +305,36 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   over |= ovq != 0u;
   if ((t & 63) == 0) flags[t >> 6] = 0u;
   {
-    const uint32_t v = (__ballot(bad) != 0ull ? 1u : 0u) | (__ballot(over) != 0ull ? 2u : 0u);
+    const uint32_t v = (__ballot(bad) != 0ull ? 1u : 0u) | (__ballot(over) != 0ull ? 2u : 0u) | (__ballot(notinf != 0u) != 0ull ? 4u : 0u);
     if (v != 0u && (t & 63) == 0) flags[t >> 6] = v;
   }
   __syncthreads();
   uint32_t verdict = 0;
 #pragma unroll
   for (int i = 0; i < T / 64; ++i) verdict |= flags[i];
+  if constexpr (!BB && S == 1 && !SC) {
+    // nothing but +inf and no run start: the tile's results are +inf (the wide form must be able to carry it: the same condition as
+    // for going through that form; debug bit 0x80: no short cut)
+    if (!(verdict & 5u) && qa.inf_ok && !(dbg & 0x80)) {
+      if constexpr (O16) {
+        const bool stays = qa.plane_inf_ok != 0u;  // (the indices of pass X, 0xFFFF, ARE the plane's +inf)
+        if (t == 0) {
+          if (stays) atomicOr(qa.map + xt * qa.map_words + (int)(o >> 5), 1u << (o & 31));
+          else atomicAnd(qa.map + xt * qa.map_words + (int)(o >> 5), ~(1u << (o & 31)));
+        }
+        if (stays) return;
+      }
+      const float finf = (epi & kEpiToInf) ? INFINITY : FLT_MAX;  // (sqrt of either is itself)
+      float *dstF = F + x0 + o * g.outer_stride + 4 * cg;
+      if (col_ok)
+        for (int row = r_in; row < n; row += RPS) {
+          if (epi & kEpiStream) __builtin_nontemporal_store((v4f){finf, finf, finf, finf}, reinterpret_cast<v4f *>(dstF + (int64_t)row * st));
+          else *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) = (v4f){finf, finf, finf, finf};
+        }
+      return;
+    }
+  }
+  verdict &= 3u;
   // the wide form: every row of every column, fp32 results (16-bit slab records cannot carry them; the stride-2 form keeps
   // the hand-over)
   constexpr bool kWide = S == 1 && !(O16 && SC);
@@ -774,8 +810,9 @@ static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q
 int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
                            uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
                            const BandScatter *scatter, uint16_t *plane, uint32_t *map, int map_words, const ColumnOut *out,
-                           int64_t plane_stride, int64_t plane_outer) {
+                           int64_t plane_stride, int64_t plane_outer, int plane_inf_ok) {
   Q16Args qa;
+  qa.plane_inf_ok = plane_inf_ok ? 1u : 0u;
   qa.codes = codes;
   qa.q = q;
   qa.rq = 1.0f / q;

@@ -131,6 +131,45 @@ def test_q16_rows_without_boundary_and_far_borders(edt_gpu, oracle_port, shape):
                               np.sqrt(oracle_port.edtsq(lab, (1.0, 10.0, 10.0), False))), (shape, "sqrt")
 
 
+@pytest.mark.parametrize("shape", [(128, 300, 200), (96, 512, 130), (64, 130, 1000), (36, 100, 100), (128, 128, 128)])
+def test_q16_tiles_of_nothing_but_inf(edt_gpu, oracle_port, shape):
+    """Round 6: without a black border a tile inside one object that spans the volume along the earlier axes holds nothing but
+    +inf and no run start -- it is answered from the fill (+inf row for row; in pass Y it may stay in the 16-bit plane as the 0xFFFF
+    pass X left there) instead of going through the 32-bit form.  Volumes made of such tiles, of tiles that just are not (one
+    finite voxel, one label change behind row 0), and of both: the oracle's results under the default form selection, without
+    the short cut (0x80), with fp32 between the passes (0x10000000) and on the fp32 kernels (0x8000000); edt and edtsq."""
+    from edt import _lib
+    lib = _lib.load()
+    sx, sy, sz = shape
+    vols = []
+    ones = np.ones(shape, dtype=np.uint32, order="F")
+    vols.append(("ones", ones))
+    v = ones.copy(order="F"); v[sx // 2, sy // 2, sz // 2] = 0
+    vols.append(("one background voxel", v))
+    v = ones.copy(order="F"); v[:, : sy // 3, :] = 2                      # run starts along y in every column, nothing along x
+    vols.append(("two slabs along y", v))
+    v = ones.copy(order="F"); v[:, :, sz // 2:] = 3                      # run starts along z only
+    vols.append(("two slabs along z", v))
+    v = ones.copy(order="F"); v[: sx // 2, : sy // 2, : sz // 2] = 4     # a corner: finite rows in an eighth of the volume
+    vols.append(("a corner block", v))
+    for name, lab in vols:
+        for an in ((1.0, 1.0, 1.0), (6.0, 6.0, 30.0), (0.5, 1.0, 2.0)):
+            want = oracle_port.edtsq(lab, an, False)
+            try:
+                for mode in (0, 0x80, 0x10000000, 0x8000000):
+                    lib.edt_hip_set_debug_mode(mode)
+                    assert np.array_equal(edt_gpu.edtsq(lab, anisotropy=an, black_border=False), want), (shape, name, an, hex(mode))
+                    if mode in (0, 0x80):
+                        assert np.array_equal(edt_gpu.edt(lab, anisotropy=an, black_border=False), np.sqrt(want)), (shape, name, an, hex(mode), "sqrt")
+            finally:
+                lib.edt_hip_set_debug_mode(0)
+    # two dimensions: pass Y is the last pass
+    img = np.ones((sx, sy), dtype=np.uint8, order="F")
+    assert np.array_equal(edt_gpu.edtsq(img, black_border=False), oracle_port.edtsq(img, (1.0, 1.0), False))
+    img[:, sy // 2:] = 2
+    assert np.array_equal(edt_gpu.edtsq(img, black_border=False), oracle_port.edtsq(img, (1.0, 1.0), False))
+
+
 def test_q16_two_dimensional_and_stacks(edt_gpu, oracle_port):
     rng = np.random.default_rng(3)
     for shape in ((300, 260), (1000, 200), (128, 1024)):

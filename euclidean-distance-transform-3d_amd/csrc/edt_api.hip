@@ -350,9 +350,15 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
   };
   // F in place (codes == nullptr) or from the 16-bit indices of pass X; returns the list for the fp32 launch that follows
   // (launched: the integer kernel ran; sure: the caller vouches for what the pass reads -- see above)
+  // will q16_pass launch the integer kernel for this axis?  (the shape and mode part of its test; buffers: column_pass_q16_aligned)
+  auto q16_applies = [&](const AxisGeom &g) {
+    return q16 && column_pass_q16_supported(g) && column_pass_wave_supported(g) && !(g_debug_mode & kQ16Off) &&
+           ceil_div(g.sx, 16) * (ceil_div(g.nouter, 8) * 8) <= p.q16_id_capacity;
+  };
   // map_words_off: the slab's first word in every x-tile's row of the plane's map (pass Y of the slabs after the first)
   auto q16_pass = [&](float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, int axis, int epi,
-                      TileList &list, uint16_t *plane, bool sure, bool &launched, int64_t map_words_off = 0) -> int {
+                      TileList &list, uint16_t *plane, bool sure, bool &launched, int64_t map_words_off = 0,
+                      const uint32_t *signbits = nullptr) -> int {
     list = TileList();
     launched = false;
     // (the bits that force one form of the fp32 kernel on every tile -- the test tiers' way to cover them -- keep the call there)
@@ -370,7 +376,8 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     const int r = launch_column_pass_q16(F, codes, rs, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, p.q16_ids, stream,
                                          nullptr, plane, p.q16_map + map_words_off, p.q16_map_words, nullptr, 0, 0,
                                          // (pass Y into the plane: may a tile of nothing but +inf stay there for pass Z?)
-                                         (axis == 1 && plane != nullptr && codes != nullptr && q16_value_limit(q16_q, q16_a[2], sz, bb) != 0u) ? 1 : 0);
+                                         (axis == 1 && plane != nullptr && codes != nullptr && q16_value_limit(q16_q, q16_a[2], sz, bb) != 0u) ? 1 : 0,
+                                         signbits);
     if (r != EDT_OK) return r;
     launched = true;
     list.count = count;
@@ -407,6 +414,14 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
                        column_pass_q16_supported(p.gy) && column_pass_q16_supported(p.gz) &&
                        column_pass_wave_supported(p.gy) && column_pass_wave_supported(p.gz);
   bool y_sure = true;  // every tile of pass Y was served by the integer kernel, provably (q16_cannot_refuse)
+  // The signed transform's sign as the EPILOGUE of pass Z (round 6): where both column passes provably run on the integer kernel
+  // alone -- it never reads the foreground plane -- pass X keeps the TRUE label != 0 bits there (zero_label = 2), the transposer
+  // carries them to the z axis, and the last pass negates the voxels whose bit is clear (kEpiSign): no pass of its own over
+  // labels and field (1.2 GB at 512^3).  Anywhere else: all-ones planes and k_negate_background.  (debug bit 0x400: never.)
+  const bool fuse_sign = signed_tf && zpass && index_form && tiled_z && !(g_debug_mode & 0x400) && q16_applies(p.gy) && q16_applies(p.gz) &&
+                         q16_cannot_refuse(1, p.gy) && q16_cannot_refuse(2, p.gz) && column_pass_q16_aligned(cur, p.codes, p.codes) &&
+                         ceil_div(sz, p.xy_slab > 0 ? p.xy_slab : sz) + 1 <= kQ16Slots;
+  const int zero_label = fuse_sign ? 2 : signed_tf;
   if (index_form) {
     const int64_t sxy = sx * sy, wpl = p.gy.sx * p.gy.nbands;  // voxels / bit words per slice
     const size_t lsz = dtype_size(dtype);
@@ -422,7 +437,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
         ScopedPass t(one ? "x_pass" : nullptr, stream);
         rc = launch_row_pass_wave(dtype, lab, nullptr, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl,
                                   zpass ? p.zs_y + z0 * wpl : nullptr, sx, sy, zc, wx, bb, bb ? 0 : 1, stream,
-                                  z0 > 0 ? lab - (size_t)sxy * lsz : nullptr, slab_codes, signed_tf);
+                                  z0 > 0 ? lab - (size_t)sxy * lsz : nullptr, slab_codes, zero_label);
         if (rc != EDT_OK) return rc;
         if (binary_yz) {
           AxisGeom gb = p.gy;
@@ -442,6 +457,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
         if (rc != EDT_OK) return rc;
         if (!launched) plane16 = false;  // (nothing wrote the plane or said where the rows are: pass Z reads fp32 values)
         y_sure = y_sure && list.none;
+        if (fuse_sign && (!launched || !list.none)) { set_error("internal: signed transform, pass Y left the integer kernel"); return EDT_ERR_HIP; }
         if (!list.none)
           rc = launch_column_pass_wave_codes(cur + z0 * sxy, slab_codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
                                              zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream, nullptr, list);
@@ -511,8 +527,10 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     if (tiled_z) {
       TileList list;
       bool launched = false;
-      rc = q16_pass(cur, nullptr, p.rs_z, p.gz, 2, last_epi, list, plane16 ? p.codes : nullptr, index_form && y_sure, launched);
+      rc = q16_pass(cur, nullptr, p.rs_z, p.gz, 2, last_epi | (fuse_sign ? kEpiSign : 0), list, plane16 ? p.codes : nullptr,
+                    index_form && y_sure, launched, 0, fuse_sign ? p.nz_z : nullptr);
       if (rc != EDT_OK) return rc;
+      if (fuse_sign && (!launched || !list.none)) { set_error("internal: signed transform, pass Z left the integer kernel"); return EDT_ERR_HIP; }
       if (!list.none) rc = launch_column_inplace(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream, list);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_z, p.rs_z, p.stack, p.gz, wz, bb, last_epi,
@@ -522,7 +540,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
     if (rc != EDT_OK) return rc;
   }
   if (cur != d_out) { set_error("internal: result buffer mismatch"); return EDT_ERR_HIP; }
-  if (signed_tf) {
+  if (signed_tf && !fuse_sign) {
     ScopedPass t("sign", stream);
     rc = launch_negate_background(dtype, d_labels, d_out, p.voxels, stream);
     if (rc != EDT_OK) return rc;

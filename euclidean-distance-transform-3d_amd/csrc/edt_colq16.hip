@@ -74,6 +74,7 @@ struct Q16Args {
   uint32_t nlimw, dmaxw, kmaxw;
   uint32_t fwmax_bits;    // bit pattern of (float)nlimw * q (exact)
   uint32_t inf_ok;        // the wide form carries +inf (no black border, short enough columns: edt_colq16_lane.h, q16_wide_range)
+  const uint32_t *signbits;  // kEpiSign: the true foreground plane of this axis ([outer][band][x] words, like the run starts)
   uint32_t plane_inf_ok;  // O16: the pass that reads the 16-bit plane carries +inf too -- a tile of nothing but +inf may stay there as 0xFFFF
   uint32_t *count;        // tiles handed to the fp32 kernel: *count of them ...
   uint32_t *ids;          // ... their tile ids (outer index * x-tiles + x-tile) in the fp32 kernel's geometry:
@@ -315,7 +316,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   if constexpr (!BB && S == 1 && !SC) {
     // nothing but +inf and no run start: the tile's results are +inf (the wide form must be able to carry it: the same condition as
     // for going through that form; debug bit 0x80: no short cut)
-    if (!(verdict & 5u) && qa.inf_ok && !(dbg & 0x80)) {
+    if (!(verdict & 5u) && qa.inf_ok && !(dbg & 0x80) && !(epi & kEpiSign)) {
       if constexpr (O16) {
         const bool stays = qa.plane_inf_ok != 0u;  // (the indices of pass X, 0xFFFF, ARE the plane's +inf)
         if (t == 0) {
@@ -500,6 +501,17 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       if (epi & kEpiSqrt) {
   #pragma unroll
         for (int j = 0; j < kB; ++j) out[j] = (v2f){sqrtf(out[j].x), sqrtf(out[j].y)};
+      }
+      if (epi & kEpiSign) {
+        // the signed transform: a voxel of label 0 gets the negated value (bit k0 + j of the band's foreground words)
+        const int k0 = L.p0 & 31;
+        v2u fgw = (v2u){~0u, ~0u};
+        if (store_ok) fgw = *reinterpret_cast<const v2u *>(qa.signbits + (o * g.nbands + s) * g.sx + x0 + 2 * cp);
+        const uint32_t sa = ~fgw[0] >> k0, sb = ~fgw[1] >> k0;
+  #pragma unroll
+        for (int j = 0; j < kB; ++j)
+          out[j] = (v2f){__uint_as_float(__float_as_uint(out[j].x) ^ (((sa >> j) & 1u) << 31)),
+                         __uint_as_float(__float_as_uint(out[j].y) ^ (((sb >> j) & 1u) << 31))};
       }
       if (redo == 0u && (epi & kEpiStream)) {
         // (the call's results: streamed -- edt_common.h: kEpiStream)
@@ -724,6 +736,13 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
 #pragma unroll
             for (int j = 0; j < kB; ++j) out[j] = sqrtf(out[j]);
           }
+          if (epi & kEpiSign) {
+            uint32_t fgw1 = ~0u;
+            if (store_ok) fgw1 = qa.signbits[(o * g.nbands + s) * g.sx + x0 + colc];
+            const uint32_t sw = ~fgw1 >> (L.p0 & 31);
+#pragma unroll
+            for (int j = 0; j < kB; ++j) out[j] = __uint_as_float(__float_as_uint(out[j]) ^ (((sw >> j) & 1u) << 31));
+          }
 #pragma unroll
           for (int j = 0; j < kB; ++j) {
             const int row = L.p0 + j;
@@ -810,9 +829,15 @@ static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q
 int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
                            uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
                            const BandScatter *scatter, uint16_t *plane, uint32_t *map, int map_words, const ColumnOut *out,
-                           int64_t plane_stride, int64_t plane_outer, int plane_inf_ok) {
+                           int64_t plane_stride, int64_t plane_outer, int plane_inf_ok, const uint32_t *signbits) {
   Q16Args qa;
   qa.plane_inf_ok = plane_inf_ok ? 1u : 0u;
+  qa.signbits = signbits;
+  if ((epi & kEpiSign) && (signbits == nullptr || scatter != nullptr || (out && (out->stride == 2 || out->compact != nullptr)) ||
+                           (codes != nullptr && plane != nullptr))) {
+    set_error("internal: the sign epilogue belongs to a last pass with fp32 results in place");
+    return EDT_ERR_BAD_ARG;
+  }
   qa.codes = codes;
   qa.q = q;
   qa.rq = 1.0f / q;

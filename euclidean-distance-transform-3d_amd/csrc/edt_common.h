@@ -43,7 +43,8 @@ void set_error(const std::string &msg);
 //                 the fp32 launch over the hand-over list is never skipped
 //   0x40000000    integer column kernels: a tile beyond 16 bits always as two wide passes over all its columns (no column subset)
 //   0x80          integer column kernels: a tile of nothing but +inf goes through the wide form like any other (no short cut from the fill)
-constexpr int kDiagFormBits = 16 | 32 | 64 | 0x80 | 256 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |
+//   0x400         signed transform: the background's sign as a pass of its own, not as the epilogue of the last column pass
+constexpr int kDiagFormBits = 16 | 32 | 64 | 0x80 | 256 | 0x400 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |
                               0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000 | 0x2000000 | 0x4000000 | 0x8000000 | 0x10000000 |
                               0x20000000 | 0x40000000;
 #ifdef EDT_DIAG
@@ -127,6 +128,8 @@ struct BandScatter {
 // kEpiStream: the pass's results are the CALL's results -- nothing of this call reads them again: the integer column kernel
 // writes them with non-temporal stores (round 5: the 512 MiB a 512^3 pass Z leaves in the caches otherwise drain under the next
 // call's pass X -- 0.5896 -> 0.573 ms per cfg2 step, 0.5725 -> 0.5583 with two volumes taken in turn)
-enum : int { kEpiToInf = 1, kEpiSqrt = 2, kEpiStream = 4 };
+// kEpiSign: the signed transform (EDT_FLAG_SIGNED) -- the integer column kernel of the call's last pass negates the results of the
+// voxels whose foreground bit (Q16Args::signbits: the true label != 0 plane of that axis) is clear, instead of a pass of its own
+enum : int { kEpiToInf = 1, kEpiSqrt = 2, kEpiStream = 4, kEpiSign = 8 };
 
 }  // namespace edt_amd

@@ -166,7 +166,8 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
                            uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
                            const BandScatter *scatter = nullptr, uint16_t *plane = nullptr, uint32_t *map = nullptr,
                            int map_words = 0, const ColumnOut *out = nullptr, int64_t plane_stride = 0, int64_t plane_outer = 0,
-                           int plane_inf_ok = 0);  // plane_inf_ok: the pass that reads the 16-bit plane this one writes carries +inf
+                           int plane_inf_ok = 0,   // the pass that reads the 16-bit plane this one writes carries +inf
+                           const uint32_t *signbits = nullptr);  // kEpiSign: the true foreground plane of this axis
 }  // namespace edt_amd
 
 namespace edt_amd {

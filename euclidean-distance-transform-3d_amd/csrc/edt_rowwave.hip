@@ -192,15 +192,16 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         M[c] = __ballot(lab[c] != left[c]);
-        // (zero_label: the SIGNED transform -- label 0 is a label like any other, its runs are measured like every run, and
-        // the foreground plane says "everything": edt_api.hip, EDT_FLAG_SIGNED)
-        const unsigned long long fg = zero_label ? ~0ull : __ballot(lab[c] != T(0));
+        // (zero_label: the SIGNED transform -- label 0 is a label like any other, its runs are measured like every run.  1: the
+        // foreground plane says "everything" (the fp32 column kernels read it); 2: it keeps the truth -- the call's column passes
+        // are integer passes that never read it, and the last of them takes the background's sign from it: edt_api.hip)
+        const unsigned long long fg = zero_label == 1 ? ~0ull : __ballot(lab[c] != T(0));
         shift_in(nzw[c], fg);
         shift_in(ysw[c], __ballot(lab[c] != above[c]));
         if (HAS_Z) shift_in(zsw[c], __ballot(lab[c] != below[c]));
         above[c] = lab[c];
         any_start |= M[c];
-        all_fg |= (fg == ~0ull ? 1u : 0u) << c;
+        all_fg |= ((zero_label != 0 || fg == ~0ull) ? 1u : 0u) << c;
       }
       // ---- the previous row's results leave now: issued after this row's loads have been waited
       //      for and a whole distance stage before the next wait, they retire off the critical path

@@ -126,6 +126,13 @@ def test_signed_transform_is_the_two_transform_definition(edt_gpu, oracle_port):
             one = device.sdf(t, anisotropy=an, black_border=bb)
             two = device._signed(t, an, bb, sqrt=True, one_transform=False)
             assert torch.equal(one, two) and np.array_equal(one.cpu().numpy(), oracle_port.sdf(lab, an, bb), equal_nan=True)
+            # (the sign as the epilogue of the last integer pass where the host can prove both passes stay on that kernel -- the
+            # default -- and as a pass of its own: debug bit 0x400)
+            try:
+                _lib.load().edt_hip_set_debug_mode(0x400)
+                assert torch.equal(device.sdf(t, anisotropy=an, black_border=bb), one), (shape, an, bb, "sign as a pass of its own")
+            finally:
+                _lib.load().edt_hip_set_debug_mode(0)
             assert torch.equal(device.sdfsq(t, anisotropy=an, black_border=bb), device._signed(t, an, bb, sqrt=False, one_transform=False))
     # a volume without any background, without a black border: +inf everywhere, as the definition says (inf - 0)
     ones = np.ones((36, 100, 100), dtype=np.uint8)

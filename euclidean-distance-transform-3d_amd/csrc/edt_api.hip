@@ -418,10 +418,17 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
   // alone -- it never reads the foreground plane -- pass X keeps the TRUE label != 0 bits there (zero_label = 2), the transposer
   // carries them to the z axis, and the last pass negates the voxels whose bit is clear (kEpiSign): no pass of its own over
   // labels and field (1.2 GB at 512^3).  Anywhere else: all-ones planes and k_negate_background.  (debug bit 0x400: never.)
-  const bool fuse_sign = signed_tf && zpass && index_form && tiled_z && !(g_debug_mode & 0x400) && q16_applies(p.gy) && q16_applies(p.gz) &&
-                         q16_cannot_refuse(1, p.gy) && q16_cannot_refuse(2, p.gz) && column_pass_q16_aligned(cur, p.codes, p.codes) &&
-                         ceil_div(sz, p.xy_slab > 0 ? p.xy_slab : sz) + 1 <= kQ16Slots;
+  // q16_only: both column passes of the call provably run on the integer kernel alone (what q16_pass will decide, decided here
+  // for the whole call; a pass that left that kernel after all is an internal error below)
+  const bool q16_only = zpass && index_form && tiled_z && q16_applies(p.gy) && q16_applies(p.gz) && q16_cannot_refuse(1, p.gy) &&
+                        q16_cannot_refuse(2, p.gz) && column_pass_q16_aligned(cur, p.codes, p.codes) &&
+                        ceil_div(sz, p.xy_slab > 0 ? p.xy_slab : sz) + 1 <= kQ16Slots;
+  const bool fuse_sign = signed_tf && q16_only && !(g_debug_mode & 0x400);
   const int zero_label = fuse_sign ? 2 : signed_tf;
+  // ... and then nobody reads a foreground plane (the integer kernel knows background as N = 0): pass X does not write one, the
+  // transposer carries the run starts alone -- 48 MiB less per 512^3 step (debug bit 0x400 keeps the planes)
+  const bool skip_nz = q16_only && !signed_tf && !binary_yz && !(g_debug_mode & 0x400);
+  uint32_t *const nzy = skip_nz ? nullptr : p.nz_y, *const nzz = skip_nz ? nullptr : p.nz_z;
   if (index_form) {
     const int64_t sxy = sx * sy, wpl = p.gy.sx * p.gy.nbands;  // voxels / bit words per slice
     const size_t lsz = dtype_size(dtype);
@@ -435,7 +442,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
       {
         // (slice 0 of a later slab compares against the slice below it through the halo pointer of the sharded path)
         ScopedPass t(one ? "x_pass" : nullptr, stream);
-        rc = launch_row_pass_wave(dtype, lab, nullptr, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl,
+        rc = launch_row_pass_wave(dtype, lab, nullptr, nzy ? nzy + z0 * wpl : nullptr, p.rs_y + z0 * wpl,
                                   zpass ? p.zs_y + z0 * wpl : nullptr, sx, sy, zc, wx, bb, bb ? 0 : 1, stream,
                                   z0 > 0 ? lab - (size_t)sxy * lsz : nullptr, slab_codes, zero_label);
         if (rc != EDT_OK) return rc;
@@ -457,7 +464,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
         if (rc != EDT_OK) return rc;
         if (!launched) plane16 = false;  // (nothing wrote the plane or said where the rows are: pass Z reads fp32 values)
         y_sure = y_sure && list.none;
-        if (fuse_sign && (!launched || !list.none)) { set_error("internal: signed transform, pass Y left the integer kernel"); return EDT_ERR_HIP; }
+        if (q16_only && (!launched || !list.none)) { set_error("internal: pass Y left the integer kernel"); return EDT_ERR_HIP; }
         if (!list.none)
           rc = launch_column_pass_wave_codes(cur + z0 * sxy, slab_codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
                                              zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream, nullptr, list);
@@ -515,7 +522,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
   if (zpass) {
     // z-packed planes (after the y pass: rs_z may live in the y pass's run-start plane)
     ScopedPass t("z_bits", stream);
-    if (tiled_x) rc = launch_bits_transpose_yz(p.nz_y, p.zs_y, p.nz_z, p.rs_z, sx, sy, sz, stream);
+    if (tiled_x) rc = launch_bits_transpose_yz(nzy, p.zs_y, nzz, p.rs_z, sx, sy, sz, stream);
     else {
       rc = launch_axis_bits(dtype, d_labels, nullptr, p.nz_z, p.rs_z, p.gz, stream);
       if (rc == EDT_OK && binary_yz) rc = launch_planes_one_run(p.nz_z, p.rs_z, nullptr, p.gz, 0, stream);
@@ -530,7 +537,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
       rc = q16_pass(cur, nullptr, p.rs_z, p.gz, 2, last_epi | (fuse_sign ? kEpiSign : 0), list, plane16 ? p.codes : nullptr,
                     index_form && y_sure, launched, 0, fuse_sign ? p.nz_z : nullptr);
       if (rc != EDT_OK) return rc;
-      if (fuse_sign && (!launched || !list.none)) { set_error("internal: signed transform, pass Z left the integer kernel"); return EDT_ERR_HIP; }
+      if (q16_only && (!launched || !list.none)) { set_error("internal: pass Z left the integer kernel"); return EDT_ERR_HIP; }
       if (!list.none) rc = launch_column_inplace(cur, p.nz_z, p.rs_z, p.gz, wz, bb, last_epi, stream, list);
     } else {
       rc = launch_column_pass_serial(cur, other, p.nz_z, p.rs_z, p.stack, p.gz, wz, bb, last_epi,

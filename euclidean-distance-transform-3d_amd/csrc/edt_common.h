@@ -43,7 +43,8 @@ void set_error(const std::string &msg);
 //                 the fp32 launch over the hand-over list is never skipped
 //   0x40000000    integer column kernels: a tile beyond 16 bits always as two wide passes over all its columns (no column subset)
 //   0x80          integer column kernels: a tile of nothing but +inf goes through the wide form like any other (no short cut from the fill)
-//   0x400         signed transform: the background's sign as a pass of its own, not as the epilogue of the last column pass
+//   0x400         no short cuts from "both column passes provably on the integer kernel": the foreground planes are written and
+//                 transposed although nobody reads them; the signed transform's sign is a pass of its own, not the last pass's epilogue
 constexpr int kDiagFormBits = 16 | 32 | 64 | 0x80 | 256 | 0x400 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |
                               0x100000 | 0x200000 | 0x400000 | 0x800000 | 0x1000000 | 0x2000000 | 0x4000000 | 0x8000000 | 0x10000000 |
                               0x20000000 | 0x40000000;

@@ -254,6 +254,9 @@ __device__ __forceinline__ void transpose32(uint32_t (&a)[32]) {
   transpose32_stage<1, 0x55555555u>(a);
 }
 
+// NZ = false: the run starts alone (round 6: a call whose column passes provably run on the integer kernel never reads a
+// foreground plane -- it is neither written by pass X nor transposed)
+template <bool NZ>
 __global__ void k_bits_transpose_yz(const uint32_t *__restrict__ nz_y,
                                     const uint32_t *__restrict__ zs_y,
                                     uint32_t *__restrict__ nz_z, uint32_t *__restrict__ rs_z,
@@ -272,20 +275,20 @@ __global__ void k_bits_transpose_yz(const uint32_t *__restrict__ nz_y,
     a[t] = 0; b[t] = 0;
     if (z < sz) {
       const int64_t w = z * in_zstride + yb * sx + x;
-      a[t] = nz_y[w];
+      if constexpr (NZ) a[t] = nz_y[w];
       b[t] = zs_y[w];
     }
   }
   // 32x32 bit-matrix transposes in registers: five butterfly stages of 16 masked swaps each
   // (word t bit r  <->  word r bit t), ~500 operations per plane instead of 32*32 bit extractions
-  transpose32(a);
+  if constexpr (NZ) transpose32(a);
   transpose32(b);
 #pragma unroll
   for (int r = 0; r < 32; ++r) {
     const int64_t y = yb * 32 + r;
     if (y >= sy) break;
     const int64_t w = (y * nbz + zb) * sx + x;
-    nz_z[w] = a[r];
+    if constexpr (NZ) nz_z[w] = a[r];
     rs_z[w] = b[r];
   }
 }
@@ -297,9 +300,14 @@ int launch_bits_transpose_yz(const uint32_t *nz_y, const uint32_t *zs_y, uint32_
   const int64_t total = sx * nby * nbz;
   if (total <= 0) return EDT_OK;
   const int threads = 256;
-  hipLaunchKernelGGL(k_bits_transpose_yz, dim3((unsigned)ceil_div(total, threads)), dim3(threads), 0,
-                     stream, nz_y, zs_y, nz_z, rs_z, sx, sy, sz, nby, nbz,
-                     in_zstride > 0 ? in_zstride : nby * sx);
+  if (nz_y != nullptr && nz_z != nullptr)
+    hipLaunchKernelGGL(k_bits_transpose_yz<true>, dim3((unsigned)ceil_div(total, threads)), dim3(threads), 0,
+                       stream, nz_y, zs_y, nz_z, rs_z, sx, sy, sz, nby, nbz,
+                       in_zstride > 0 ? in_zstride : nby * sx);
+  else
+    hipLaunchKernelGGL(k_bits_transpose_yz<false>, dim3((unsigned)ceil_div(total, threads)), dim3(threads), 0,
+                       stream, nz_y, zs_y, nz_z, rs_z, sx, sy, sz, nby, nbz,
+                       in_zstride > 0 ? in_zstride : nby * sx);
   EDT_HIP_TRY(hipGetLastError());
   return EDT_OK;
 }

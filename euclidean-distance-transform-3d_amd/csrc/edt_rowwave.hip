@@ -338,7 +338,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
         // row 0 of the volume starts a run along y, slice 0 starts every run along z
         const uint32_t ys = (__brev(ysw[c]) >> sh) | (y0 == 0 ? 1u : 0u);
         const uint32_t zs = (z == 0 && halo == nullptr) ? (0xFFFFFFFFu >> sh) : (__brev(zsw[c]) >> sh);
-        nz_y[wbase + x] = __brev(nzw[c]) >> sh;
+        if (nz_y != nullptr) nz_y[wbase + x] = __brev(nzw[c]) >> sh;  // (nullptr: nobody will read a foreground plane, edt_api.hip)
         ys_y[wbase + x] = ys;
         if (HAS_Z) zs_y[wbase + x] = zs;
       }

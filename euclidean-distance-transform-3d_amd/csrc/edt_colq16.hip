@@ -352,8 +352,13 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       for (int row = r_in; row < n; row += RPS) {
         if (((mapw[row >> 5] >> (row & 31)) & 1u) != 0u && col_ok) {
           const v2u v = *reinterpret_cast<const v2u *>(img + (row + kPad) * kRowWords + 2 * cg);
-          *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) =
-              (v4f){(float)(v[0] & 0xFFFFu) * qa.q, (float)(v[0] >> 16) * qa.q, (float)(v[1] & 0xFFFFu) * qa.q, (float)(v[1] >> 16) * qa.q};
+          // (0xFFFF: +inf -- a tile of nothing but +inf that pass Y left in the plane as the indices it was, round 6: FLT_MAX between
+          // the passes, as tofinite leaves it, src/edt.hpp:39-45)
+          const uint32_t h[4] = {v[0] & 0xFFFFu, v[0] >> 16, v[1] & 0xFFFFu, v[1] >> 16};
+          v4f f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) f[c] = h[c] == 0xFFFFu ? FLT_MAX : (float)h[c] * qa.q;
+          *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) = f;
         }
       }
     }

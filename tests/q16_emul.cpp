@@ -203,7 +203,8 @@ int tile_pass(const float *Fin, const uint16_t *codes, const uint32_t *rsbits, f
       for (int row = 0; row < n; ++row)
         if (row_in_plane[row])
           for (int col = 0; col < 32 && col < cols_left; ++col)
-            out[(int64_t)row * sx + x0 + col] = (float)plane_in[(int64_t)row * sx + x0 + col] * q;
+            out[(int64_t)row * sx + x0 + col] = plane_in[(int64_t)row * sx + x0 + col] == 0xFFFFu
+                                                    ? 3.402823466e+38f : (float)plane_in[(int64_t)row * sx + x0 + col] * q;  // (0xFFFF: +inf)
     return 0;
   }
   // ---- scans + breaks (phase 1) ----

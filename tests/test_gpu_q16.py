@@ -170,6 +170,22 @@ def test_q16_tiles_of_nothing_but_inf(edt_gpu, oracle_port, shape):
     assert np.array_equal(edt_gpu.edtsq(img, black_border=False), oracle_port.edtsq(img, (1.0, 1.0), False))
 
 
+def test_q16_refused_tile_with_inf_rows_in_the_plane(edt_gpu, oracle_port):
+    """Found by the round-6 fuzz on the first build with the short cut above (1 of 600 cases): slices of nothing but +inf that pass Y
+    left in the 16-bit plane (0xFFFF) next to a slice whose values pass Z's integer form cannot hold (x-distances of up to 211
+    voxels at a voxel size of 40: N = k^2 * 1600 beyond 2^24) -- pass Z REFUSES such a tile and first turns its plane rows into fp32
+    values for the fp32 kernel: 0xFFFF must become FLT_MAX there, not 65535 quanta."""
+    shape = (212, 189, 253)
+    lab = np.ones(shape, dtype=bool, order="F")
+    lab[0, :, 10] = False                       # one slice with a boundary at x = 0: indices up to 211 along x
+    lab[5:9, 100:140, 200:203] = False          # and some ordinary structure elsewhere
+    for an in ((40.0, 2.0, 3.0), (40.0, 40.0, 2.0)):
+        want = oracle_port.edtsq(lab, an, False)
+        assert np.isfinite(want).all() and want.max() > 2 ** 24
+        got = edt_gpu.edtsq(lab, anisotropy=an, black_border=False)
+        assert np.array_equal(got, want), (an, int((got != want).sum()))
+
+
 def test_q16_two_dimensional_and_stacks(edt_gpu, oracle_port):
     rng = np.random.default_rng(3)
     for shape in ((300, 260), (1000, 200), (128, 1024)):

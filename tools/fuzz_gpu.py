@@ -76,5 +76,19 @@ for i in range(ncases):
     if not np.array_equal(got, want, equal_nan=True):
         bad += 1
         print("MISMATCH", shape, dt.__name__, an, bb, int((got != want).sum()))
+        if os.environ.get("FUZZ_DUMP") == "1" and not vg:
+            # which form selection answers this case correctly, and where the wrong voxels are; the case itself for the CPU tier
+            from edt import _lib
+            lib = _lib.load()
+            for mode in (0x80, 0x400, 0x480, 0x20000000, 0x10000000, 0x8000000):
+                lib.edt_hip_set_debug_mode(mode)
+                g2 = edt.edtsq(lab, anisotropy=an, black_border=bb)
+                print("   mode", hex(mode), "mismatches", int((g2 != want).sum()))
+            lib.edt_hip_set_debug_mode(0)
+            w = np.argwhere(got != want)
+            print("   order", "F" if lab.flags.f_contiguous else "C", "labels", np.unique(lab)[:8], "first wrong", w[:3].tolist(), "last", w[-3:].tolist(),
+                  "got", got[tuple(w[0])], "want", want[tuple(w[0])], "box", w.min(0).tolist(), w.max(0).tolist())
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{i}.npz"), lab=lab, an=np.array(an), bb=bb)
 print(f"{ncases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)

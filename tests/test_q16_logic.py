@@ -403,6 +403,35 @@ def test_q16_plane_between_passes(q16, oracle_port):
             assert np.array_equal(out[rows == 1, :32], f1[rows == 1, :32]) and (out[rows == 0, :32] == -1.0).all()
 
 
+def test_q16_refused_tile_turns_inf_rows_of_the_plane_into_flt_max(q16, oracle_port):
+    """Round 6 (found by the closing fuzz on the GPU): a row of the 16-bit plane may be +inf (0xFFFF: a tile of nothing but +inf
+    that the pass before left there); a tile that is REFUSED hands its plane rows to the fp32 kernel as fp32 values -- +inf as
+    FLT_MAX (tofinite, src/edt.hpp:39-45), not as 65535 quanta.  And a tile that is not refused carries those rows as +inf."""
+    n, sx = 200, 32
+    lab = np.ones((n, sx), dtype=np.uint32)
+    labc = np.ascontiguousarray(lab)
+    ok, q, a = quantum(q16, (1.0, 1.0))
+    rows = np.ones(n, dtype=np.uint8)
+    rows[50] = 0                                           # one row arrives as fp32 values ...
+    pin = np.full((n, sx), 0xFFFF, dtype=np.uint16)        # ... every other row is +inf in the plane
+    fin = np.full((n, sx), -7.0, dtype=np.float32)
+    fin[50] = np.float32(9.0)                              # a finite row: 9 quanta
+    tiles = np.zeros(1, dtype=np.uint8)
+    out = np.full((n, sx), -1.0, dtype=np.float32)
+    args = lambda: (labc.ctypes.data_as(ctypes.c_void_p), fin.ctypes.data_as(ctypes.c_void_p), None, out.ctypes.data_as(ctypes.c_void_p),
+                    ctypes.c_int64(sx), ctypes.c_int64(n), ctypes.c_float(q), ctypes.c_uint32(a[1]), ctypes.c_uint32(a[0]), 0, 1,
+                    tiles.ctypes.data_as(ctypes.c_void_p), pin.ctypes.data_as(ctypes.c_void_p), rows.ctypes.data_as(ctypes.c_void_p), None)
+    q16.q16_emul_column_pass_plane(*args())
+    assert tiles[0]                                        # carried: every row finds the finite one, (p - 50)^2 + 9
+    p = np.arange(n, dtype=np.float32)[:, None]
+    assert np.array_equal(out, np.broadcast_to((p - 50) ** 2 + 9, (n, sx)))
+    fin[50, 3] = np.float32(2.5)                           # off the quantum grid: the tile is refused
+    out[:] = -1.0
+    q16.q16_emul_column_pass_plane(*args())
+    assert not tiles[0]
+    assert (out[rows == 1] == FLT_MAX).all() and (out[50] == -1.0).all()
+
+
 def test_quantum_of_voxel_sizes(q16):
     assert quantum(q16, (1.0, 1.0, 1.0)) == (True, 1.0, [1, 1, 1])
     assert quantum(q16, (6.0, 6.0, 30.0)) == (True, 36.0, [1, 1, 25])

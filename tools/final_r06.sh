@@ -11,6 +11,8 @@ f() { echo "$1:"; shift; env "$@" 2>&1 | grep "MISMATCH\|cases\|Traceback\|Error
   f "general, 1500 cases" python tools/fuzz_gpu.py 1500 6101
   f "general, axes up to 2100, 300 cases" FUZZ_MAX_AXIS=2100 python tools/fuzz_gpu.py 300 6102
   f "integer kernel's shapes (FUZZ_Q16=1), 600 cases" FUZZ_Q16=1 python tools/fuzz_gpu.py 600 6103
+  f "the same shapes, volumes of +inf (FUZZ_INF=1: sparse structure, no border), 400 cases" FUZZ_Q16=1 FUZZ_INF=1 python tools/fuzz_gpu.py 400 6115
+  f "the same, without the short cut for tiles of nothing but +inf (0x80), 150 cases" FUZZ_Q16=1 FUZZ_INF=1 EDT_HIP_DEBUG_MODE=0x80 python tools/fuzz_gpu.py 150 6116
   f "the same, tiles beyond 16 bits as two wide passes (0x40000000), 200 cases" FUZZ_Q16=1 EDT_HIP_DEBUG_MODE=0x40000000 python tools/fuzz_gpu.py 200 6104
   f "the same, no wide form (0x20000000), 200 cases" FUZZ_Q16=1 EDT_HIP_DEBUG_MODE=0x20000000 python tools/fuzz_gpu.py 200 6105
   f "the same, fp32 between passes Y and Z (0x10000000), 200 cases" FUZZ_Q16=1 EDT_HIP_DEBUG_MODE=0x10000000 python tools/fuzz_gpu.py 200 6106

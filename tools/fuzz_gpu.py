@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle fuzz over shapes / dtypes / label structures (diagnostics; the regular
-parity tests live in tests/).  usage: [FUZZ_Q16=1 | FUZZ_VG=1] python tools/fuzz_gpu.py [ncases] [seed]"""
+parity tests live in tests/).  usage: [FUZZ_Q16=1 [FUZZ_INF=1] | FUZZ_VG=1] python tools/fuzz_gpu.py [ncases] [seed]      (FUZZ_DUMP=1: triage a mismatch under the
+form-selection bits and save the case to gpurun_out/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "euclidean-distance-transform-3d_amd"), os.path.join(ROOT, "tests")):
@@ -46,10 +47,34 @@ for i in range(ncases):
         shape = [int(rng.integers(1, 40)) * (4 if rng.random() < 0.6 else 1) + int(rng.integers(0, 2)) * int(rng.random() < 0.3)]
         shape += [int(rng.integers(4, 600 if rng.random() < 0.2 else 120)) for _ in range(dims - 1)]
         shape = tuple(shape)
+    finf = os.environ.get("FUZZ_INF") == "1"
     if np.prod(shape) > (3e7 if q16 else 4e5 if vg else 6e6):
         continue
     kind = rng.integers(0, 3)
-    if kind == 0:
+    if finf:
+        # Volumes of +inf (round 6): one object with SPARSE structure and no black border -- most x-rows see no boundary at all,
+        # whole tiles are nothing but +inf, every column holds a few finite rows at most; sometimes a large voxel size along x, so
+        # that the few finite values leave the integer form and their tiles are refused.  Targets: tiles answered from the fill, the
+        # +inf rows pass Y leaves in the 16-bit plane, windows that start / stop at the finite rows, refused tiles with such rows.
+        lab = np.ones(shape, dtype=np.uint32)
+        for _ in range(int(rng.integers(0, 6))):
+            c = [int(rng.integers(0, s)) for s in shape]
+            how = rng.integers(0, 5)
+            val = 0 if rng.random() < 0.6 else int(rng.integers(2, 5))
+            if how == 0:
+                lab[c[0], c[1], c[2]] = val                                   # one voxel
+            elif how == 1:
+                lab[c[0], :, c[2]] = val                                      # a line along y
+            elif how == 2:
+                lab[c[0], c[1], :] = val                                      # a line along z
+            elif how == 3:
+                lab[:, :, c[2]:c[2] + int(rng.integers(1, 4))] = val          # whole slices of another label: +inf along x AND y
+            else:
+                lab[:, c[1]:, :] = val                                        # a half space along y
+        kind = -1
+    if kind == -1:
+        pass
+    elif kind == 0:
         lab = np.ones(shape, dtype=np.uint32)
     else:
         lab = blocky_labels(shape, nlabels=int(rng.integers(1, 6)) if not q16 or rng.random() < 0.5 else int(rng.integers(20, 400)),
@@ -65,6 +90,8 @@ for i in range(ncases):
         g = np.asfortranarray(g)
     an = tuple(float(a) for a in rng.choice([1, 2, 6, 30, 0.5, 4, 40, 3] if q16 else [1, 2, 6, 30, 0.5, 1.3, 7.25], size=dims))
     bb = bool(rng.integers(0, 2))
+    if finf:
+        bb = rng.random() < 0.1
     if vg:
         if rng.random() < 0.7:
             an = tuple(float(a) for a in rng.choice([1, 2, 6, 30, 4], size=dims))  # (sizes that share a quantum: integer kernel)

@@ -161,16 +161,12 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   const bool col_ok = 4 * cg < cols_left;
   bool bad = false;   // the tile has no integer form at all: handed to the fp32 kernel
   bool over = false;  // ... no 16-bit form (a value beyond nlim): the wide form if `bad` stays false
-  // Round 6: a tile of NOTHING BUT +inf whose columns hold no run start behind row 0 (no black border: a tile inside one object that
-  // spans the volume along the earlier axes) comes out as +inf, row for row -- no border, no finite site.  It is answered from the
-  // fill (notinf: a value that is not +inf, or a run start) instead of going through two 32-bit passes that find nothing to do.
-  uint32_t notinf = BB ? 1u : 0u;
   // which of the thread's columns (4 cg .. 4 cg + 3) hold such a value: the two halves of ov01 / ov23 (index, plane rows), the
   // low bits of ovq (fp32 rows)
   pk ov01 = 0u, ov23 = 0u;
   uint32_t ovq = 0u;
   if (t < 64) bm[t] = 0u, bm[t + 32] = 0u;  // (96 words)
-  if (t == 0) ovm[0] = 0u;
+  if (t == 0) ovm[0] = 0u, ovm[1] = 0u;
   if (t < 8 * kPad) {
     // +inf around the column: 2 x kPad rows x 16 words, one 16-byte store per thread
     const int row = t < 4 * kPad ? -kPad + (t >> 2) : nb32 + ((t - 4 * kPad) >> 2);
@@ -178,9 +174,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   }
   for (int u = t; u < NB * 32; u += T) {
     const int band = u >> 5, col = u & 31;
-    const uint32_t w = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
-    rsp[u] = w;
-    notinf |= band == 0 ? (w & ~1u) : w;  // (row 0 starts a run in every column)
+    rsp[u] = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
   }
   // (index form: the whole tile in ONE sweep of sixteen loads per thread -- nb32 <= 16 RPS: 512 rows at 256 threads, 1024 at
   // 512: launch_q16_k)
@@ -200,7 +194,6 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = i0 + RPS * j + r_in;
-        if (!BB && row < n && col_ok) notinf |= ~(kk[j][0] & kk[j][1]);
         if (row < nb32) {
           // k > kmax: the tile has no 16-bit form (k^2 may have wrapped: never used); kmaxw < k < 0xFFFF: no wide form either
           ov01 |= pk_subs(kk[j][0], kmaxpk);
@@ -252,11 +245,6 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const int row = i0 + RPS * j + r_in;
-        if (!BB && row < n && col_ok) {
-          // (+inf: 0xFFFF in a row of the plane, FLT_MAX in a row of fp32 values)
-          if ((in16 >> j) & 1u) notinf |= ~(raw[j][0] & raw[j][1]);
-          else notinf |= (raw[j][0] ^ 0x7F7FFFFFu) | (raw[j][1] ^ 0x7F7FFFFFu) | (raw[j][2] ^ 0x7F7FFFFFu) | (raw[j][3] ^ 0x7F7FFFFFu);
-        }
         if (row < nb32 && ((in16 >> j) & 1u)) {
           // (pass Y's limit may be the larger one; a 16-bit value is always within the wide form's range)
           ov01 |= pk_subs(raw[j][0], nlimpk);
@@ -306,7 +294,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   over |= ovq != 0u;
   if ((t & 63) == 0) flags[t >> 6] = 0u;
   {
-    const uint32_t v = (__ballot(bad) != 0ull ? 1u : 0u) | (__ballot(over) != 0ull ? 2u : 0u) | (__ballot(notinf != 0u) != 0ull ? 4u : 0u);
+    const uint32_t v = (__ballot(bad) != 0ull ? 1u : 0u) | (__ballot(over) != 0ull ? 2u : 0u);
     if (v != 0u && (t & 63) == 0) flags[t >> 6] = v;
   }
   __syncthreads();
@@ -314,25 +302,58 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
 #pragma unroll
   for (int i = 0; i < T / 64; ++i) verdict |= flags[i];
   if constexpr (!BB && S == 1 && !SC) {
-    // nothing but +inf and no run start: the tile's results are +inf (the wide form must be able to carry it: the same condition as
-    // for going through that form; debug bit 0x80: no short cut)
-    if (!(verdict & 5u) && qa.inf_ok && !(dbg & 0x80) && !(epi & kEpiSign)) {
-      if constexpr (O16) {
-        const bool stays = qa.plane_inf_ok != 0u;  // (the indices of pass X, 0xFFFF, ARE the plane's +inf)
-        if (t == 0) {
-          if (stays) atomicOr(qa.map + xt * qa.map_words + (int)(o >> 5), 1u << (o & 31));
-          else atomicAnd(qa.map + xt * qa.map_words + (int)(o >> 5), ~(1u << (o & 31)));
+    // Round 6: a tile of NOTHING BUT +inf whose columns hold no run start behind row 0 (no black border: a tile inside one object
+    // that spans the volume along the earlier axes) has neither a border nor a finite site -- its results are +inf row for row.
+    // Such a tile arrives here as "over" (+inf is beyond every 16-bit limit); before it goes through two 32-bit passes that
+    // find nothing to do it is looked at once more -- its inputs again (they are in the L2), its run-start words -- and answered
+    // from here.  Only tiles that are over pay for the look (the multi-label configurations: a few per cent of the tiles;
+    // tracking it in the fill itself cost every tile of a border-less call 3 %).  debug bit 0x80: no short cut.
+    if (verdict == 2u && qa.inf_ok && !(dbg & 0x80) && !(epi & kEpiSign)) {
+      uint32_t notinf = 0u;
+      for (int u = t; u < NB * 32; u += T) notinf |= (u >> 5) == 0 ? (rsp[u] & ~1u) : rsp[u];  // (row 0 starts a run in every column)
+      if (col_ok) {
+        if constexpr (IN == kQ16InCodes) {
+          const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
+          for (int row = r_in; row < n && notinf == 0u; row += RPS) {
+            const v2u kk = *reinterpret_cast<const v2u *>(src + (int64_t)row * st);
+            notinf |= ~(kk[0] & kk[1]);
+          }
+        } else {
+          const float *src = F + x0 + o * g.outer_stride + 4 * cg;
+          const uint16_t *src16 = qa.plane + x0 + o * qa.p_outer + 4 * cg;
+          for (int row = r_in; row < n && notinf == 0u; row += RPS) {
+            bool p16 = false;
+            if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
+            if (p16) {
+              const v2u v = *reinterpret_cast<const v2u *>(src16 + (int64_t)row * qa.pst);
+              notinf |= ~(v[0] & v[1]);  // (+inf: 0xFFFF in a row of the plane)
+            } else {
+              const v4u v = *reinterpret_cast<const v4u *>(src + (int64_t)row * st);
+              notinf |= (v[0] ^ 0x7F7FFFFFu) | (v[1] ^ 0x7F7FFFFFu) | (v[2] ^ 0x7F7FFFFFu) | (v[3] ^ 0x7F7FFFFFu);  // (FLT_MAX in fp32 rows)
+            }
+          }
         }
-        if (stays) return;
       }
-      const float finf = (epi & kEpiToInf) ? INFINITY : FLT_MAX;  // (sqrt of either is itself)
-      float *dstF = F + x0 + o * g.outer_stride + 4 * cg;
-      if (col_ok)
-        for (int row = r_in; row < n; row += RPS) {
-          if (epi & kEpiStream) __builtin_nontemporal_store((v4f){finf, finf, finf, finf}, reinterpret_cast<v4f *>(dstF + (int64_t)row * st));
-          else *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) = (v4f){finf, finf, finf, finf};
+      if (notinf != 0u) atomicOr(ovm + 1, 1u);
+      __syncthreads();
+      if (ovm[1] == 0u) {
+        if constexpr (O16) {
+          const bool stays = qa.plane_inf_ok != 0u;  // (the indices of pass X, 0xFFFF, ARE the plane's +inf)
+          if (t == 0) {
+            if (stays) atomicOr(qa.map + xt * qa.map_words + (int)(o >> 5), 1u << (o & 31));
+            else atomicAnd(qa.map + xt * qa.map_words + (int)(o >> 5), ~(1u << (o & 31)));
+          }
+          if (stays) return;
         }
-      return;
+        const float finf = (epi & kEpiToInf) ? INFINITY : FLT_MAX;  // (sqrt of either is itself)
+        float *dstF = F + x0 + o * g.outer_stride + 4 * cg;
+        if (col_ok)
+          for (int row = r_in; row < n; row += RPS) {
+            if (epi & kEpiStream) __builtin_nontemporal_store((v4f){finf, finf, finf, finf}, reinterpret_cast<v4f *>(dstF + (int64_t)row * st));
+            else *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) = (v4f){finf, finf, finf, finf};
+          }
+        return;
+      }
     }
   }
   verdict &= 3u;

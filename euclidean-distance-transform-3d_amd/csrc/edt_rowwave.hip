@@ -128,6 +128,8 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
   // (voxel 0 never marks itself -- it is its own left neighbour); end of the row likewise
   const int pre0 = bb ? 0 : -(1 << 20);
   const int suf0 = bb ? sx : (1 << 20);
+  const unsigned long long force_fg = zero_label == 1 ? ~0ull : 0ull;  // (see the row loop)
+  const uint32_t keep_all = zero_label != 0 ? ~0u : 0u;
 
   // Work distribution.  The `zs` bits need the labels of slice z-1, which some other wave reads as
   // ITS slice: when both run on the same XCD at about the same time the second read hits in that
@@ -194,15 +196,17 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
         M[c] = __ballot(lab[c] != left[c]);
         // (zero_label: the SIGNED transform -- label 0 is a label like any other, its runs are measured like every run.  1: the
         // foreground plane says "everything" (the fp32 column kernels read it); 2: it keeps the truth -- the call's column passes
-        // are integer passes that never read it, and the last of them takes the background's sign from it: edt_api.hip)
-        const unsigned long long fg = zero_label == 1 ? ~0ull : __ballot(lab[c] != T(0));
+        // are integer passes that never read it, and the last of them takes the background's sign from it: edt_api.hip.  As two
+        // masks made once per kernel: this loop is bound by its scalar instructions)
+        const unsigned long long fg = __ballot(lab[c] != T(0)) | force_fg;
         shift_in(nzw[c], fg);
         shift_in(ysw[c], __ballot(lab[c] != above[c]));
         if (HAS_Z) shift_in(zsw[c], __ballot(lab[c] != below[c]));
         above[c] = lab[c];
         any_start |= M[c];
-        all_fg |= ((zero_label != 0 || fg == ~0ull) ? 1u : 0u) << c;
+        all_fg |= (fg == ~0ull ? 1u : 0u) << c;
       }
+      all_fg |= keep_all;  // (zero_label: no voxel is zeroed)
       // ---- the previous row's results leave now: issued after this row's loads have been waited
       //      for and a whole distance stage before the next wait, they retire off the critical path
       if (r > 0) {

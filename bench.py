@@ -937,6 +937,9 @@ def main():
         "bound": "hbm", "kernel": "whole step (x_pass + y_pass + z_bits + z_pass)", "dominant_kernel": dom,
         "achieved": summary["whole_job_algorithmic_GBs"], "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": summary["whole_job_frac"], "traffic": whole_step_traffic(args.config),
+        "frac_note": "algorithmic bytes (SURVEY 8(d): 32 B/voxel, the reference's data movement) over the step's time, against the 8 TB/s "
+                     "spec; the kernels really move ~18.4 B/voxel (traffic), so on a fast box this model fraction can pass 1 without "
+                     "any kernel exceeding the memory system: real_* price the bytes that moved",
         "dominant_kernel_traffic": measured_traffic(dom, args.config), "dominant_kernel_model_GBs": round(achieved, 1),
         "kernel_ms": summary["kernel_ms"],
         # every pass against its own model (the `kernel` above is simply the longest one: X and Z are within 2 % of each other

@@ -150,6 +150,15 @@ def sweep_volume(name: str, n: int = 512):
     raise KeyError(name)
 
 
+def several_slabs_volume(shape):
+    """Multi-label volume of more than 2^27 voxels for the slab-wise passes X / Y (tests/test_gpu_fullsize.py): blocks of a
+    seeded size, 5 % background, one whole slice of a single label (rows without a boundary under black_border=False)."""
+    rng = np.random.default_rng(sum(shape))
+    lab = np.asfortranarray(blocky_labels(shape, nlabels=40, zero_frac=0.05, block=int(rng.integers(16, 70)), rng=rng).astype(np.uint32))
+    lab[:, :, shape[2] // 2] = 77
+    return lab
+
+
 def config_volume(name: str, n: int = 512):
     """The BASELINE.json configurations at edge length `n` (Fortran order, x fastest).
 

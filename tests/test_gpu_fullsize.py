@@ -15,7 +15,7 @@ import threading
 import numpy as np
 import pytest
 
-from synth import blocky_labels, config_volume, voronoi_labels
+from synth import blocky_labels, config_volume, several_slabs_volume, voronoi_labels
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +55,41 @@ def test_object_sweep_against_compiled_reference(edt_gpu, oracle_ref, name):
     assert np.array_equal(got, want)
     got = device.edt(t, anisotropy=an[::-1], black_border=bb).cpu().numpy().T
     assert np.array_equal(got, np.sqrt(want))
+
+
+@pytest.mark.parametrize("shape,an,bb", [((1024, 1024, 200), (1.0, 1.0, 1.0), False), ((2048, 512, 300), (6.0, 6.0, 30.0), True),
+                                         ((1024, 1024, 130), (4.0, 4.0, 40.0), False)])
+def test_volumes_of_several_index_slabs_against_compiled_reference(edt_gpu, oracle_ref, shape, an, bb):
+    """Round 6: volumes of more than 2^27 voxels run passes X and Y slab by slab (128 slices of 1024 x 1024) but keep EVERY slab's
+    16-bit indices, so that the 16-bit plane between passes Y and Z exists there too (csrc/edt_api.hip: codes_whole).  Uneven
+    last slabs (200 = 128 + 72, 300 = 128 + 128 + 44, 130 = 128 + 2), rows of 2048 voxels (two waves per row in pass X), both
+    border rules, large cells next to small ones -- against the compiled reference, and against the same library with the
+    single index slab of round 5 (EDT_HIP_WHOLE_INDEX_BYTES=0 in a subprocess: fp32 between Y and Z)."""
+    import subprocess
+    import sys
+    import torch
+    from edt import device
+
+    lab = several_slabs_volume(shape)
+    want = _ref_edtsq(oracle_ref, lab, an, bb)
+    t = torch.from_numpy(np.ascontiguousarray(lab.T).view(np.int32)).cuda()
+    got = device.edtsq(t, anisotropy=an[::-1], black_border=bb).cpu().numpy().T
+    assert np.array_equal(got, want)
+    del t, got, lab
+    torch.cuda.empty_cache()
+    # the same volume with one index slab (a fresh process: the limit is read once); compared through a digest of the result
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, hashlib, numpy as np\n"
+            f"sys.path[:0] = [{os.path.join(os.path.dirname(here), 'euclidean-distance-transform-3d_amd')!r}, {here!r}]\n"
+            "import edt\n"
+            "from synth import several_slabs_volume\n"
+            f"out = edt.edtsq(several_slabs_volume({shape!r}), anisotropy={an!r}, black_border={bb!r})\n"
+            "print('DIGEST', hashlib.sha256(np.ascontiguousarray(out.T).tobytes()).hexdigest())\n")
+    env = dict(os.environ, EDT_HIP_WHOLE_INDEX_BYTES="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "DIGEST " + hashlib.sha256(np.ascontiguousarray(want.T).tobytes()).hexdigest() in res.stdout, res.stdout[-300:]
 
 
 def test_cfg4_1024_single_gpu_against_compiled_reference(edt_gpu, oracle_ref):

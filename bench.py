@@ -1001,7 +1001,11 @@ def main():
                  "diag": "two half spaces cut by the plane x + y + z = const", "diagF": "the same two half spaces without a black border",
                  "sphere_slab": "the ball of radius 250 on the 8-GPU slab shape"}
         what.update(sweep)
-        todo = [("cfg1", n), ("cfg3", n), ("cfg3f", n), ("cfg3m", n), ("cfg3L", n), ("cfg3La", n), ("cfg3M", n), ("cfg3Ma", n), ("cfg4", 2 * n)]
+        # the headline's volume WITHOUT the short cut for tiles that have no structure along the scan axis (debug bit 0x80: every
+        # tile through scans, break bits and blocks): a single-label box is made of nothing but such tiles, so the headline is
+        # also stated as what the same kernels take when they do their whole work on it
+        what["cfg2_scans"] = "the headline's volume with the flat-tile short cut switched off (debug bit 0x80)"
+        todo = [("cfg2_scans", n), ("cfg1", n), ("cfg3", n), ("cfg3f", n), ("cfg3m", n), ("cfg3L", n), ("cfg3La", n), ("cfg3M", n), ("cfg3Ma", n), ("cfg4", 2 * n)]
         todo += [(k, n) for k in sweep]
         only = [c for c in args.secondary.split(",") if c]
         verify = os.environ.get("EDT_BENCH_VERIFY", "1") != "0"
@@ -1009,13 +1013,16 @@ def main():
             if only and name not in only:
                 continue
             try:
-                run = DeviceRun(name, size, dev)
+                if name == "cfg2_scans":
+                    from edt import _lib as _edt_lib
+                    _edt_lib.load().edt_hip_set_debug_mode(0x80)
+                run = DeviceRun("cfg2" if name == "cfg2_scans" else name, size, dev)
                 s, kern, _ = run.measure(max(5, min(args.steps, 200) // 2) if size > n else min(args.steps, 100 if name in sweep else 400),
                                          args.warmup)
                 entry = {"config": name,
-                         "workload": f"{'x'.join(str(v) for v in run.shape)} uint32 {'single-label' if name == 'cfg1' else 'multi-label'}: {what[name]}, "
+                         "workload": f"{'x'.join(str(v) for v in run.shape)} uint32 {'single-label' if name in ('cfg1', 'cfg2_scans') else 'multi-label'}: {what[name]}, "
                                      f"anisotropy {tuple(run.an)}, black_border={run.bb}, device-resident in/out, 1 GPU", **s}
-                entry.update(real_traffic_fields(s["ms_per_step"], kern, None, name))
+                entry.update(real_traffic_fields(s["ms_per_step"], kern, None, run.name))
                 entry["output_verified"] = None
                 if lib is not None and verify:
                     # the timed output, bit for bit against the CPU reference on the same volume (all threads), timed as well
@@ -1031,6 +1038,9 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # pragma: no cover  (a secondary must never take the headline down)
                 secondary.append({"config": name, "error": repr(e)})
+            finally:
+                if name == "cfg2_scans":
+                    _edt_lib.load().edt_hip_set_debug_mode(int(os.environ.get("EDT_HIP_DEBUG_MODE", "0"), 0))
         if not only or "cfg5" in only:
             try:
                 secondary.append(voxel_graph_secondary(n, dev, max(5, min(args.steps, 200) // 4), args.warmup,

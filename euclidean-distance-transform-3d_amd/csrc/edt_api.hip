@@ -76,6 +76,7 @@ struct Plan {
   int64_t xy_slab = 0;        // slices per slab of the slab-wise X/Y passes (0: no index form for this shape)
   bool codes_whole = false;   // the index buffer holds every slice (volumes of several slabs: round 6) -- the 16-bit plane between
                               // passes Y and Z then exists there too
+  int64_t code_pitch = 0;     // elements between the slices of the index buffer: sx * sy, or padded (plane_pad_elems)
   // the tiles the 16-bit integer column kernel hands to the fp32 kernel (edt_colq16.hip): kQ16Slots counters, one per
   // column-pass launch of a call, and one array of tile ids (launches are stream-ordered: the array is reused)
   uint32_t *q16_counts = nullptr, *q16_ids = nullptr;
@@ -121,6 +122,25 @@ static int64_t whole_index_limit() {
   }();
   return v;
 }
+// The pitch of the index buffer = of the 16-bit plane between passes Y and Z (round 6).  Pass Z walks columns whose rows are one
+// slice apart: 2 * sx * sy bytes in the plane it reads, 4 * sx * sy in the caller's array it writes.  Where the plane's slice is a
+// whole multiple of 1 MiB both streams of a tile fall onto the same few channels at once and the pass loses a third of its rate
+// (tools/zorder_probe.hip, profiles/r06_zorder_probe.txt: the bare access pattern at 1024^3 2.10 ms, 1.36 with the plane's slices 8 KiB
+// further apart; the caller's 4 MiB stride alone -- stores only -- costs nothing).  The caller's array is not ours; the plane is:
+// slices that are a multiple of 2 MiB lie 8 KiB further apart, slices that are a multiple of 1 MiB 4 KiB (8 KiB is the one bad
+// choice there), every other shape is left alone (512^3: 512 KiB slices are best as they are).  EDT_HIP_PLANE_PAD_BYTES overrides
+// (0: never; a multiple of 8).
+static int64_t plane_pad_elems(int64_t sx, int64_t sy) {
+  // (read per plan, not once: the test tiers force a pad onto small shapes; a workspace sized under another value is refused
+  // by the size check of the call, never overrun)
+  const char *e = std::getenv("EDT_HIP_PLANE_PAD_BYTES");
+  const int64_t forced = (e && *e) ? (int64_t)std::strtoll(e, nullptr, 0) : (int64_t)-1;
+  if (forced >= 0) return (forced & ~(int64_t)7) / 2;
+  const int64_t slice = sx * sy * (int64_t)sizeof(uint16_t);
+  if (slice % ((int64_t)2 << 20) == 0) return 8192 / 2;
+  if (slice % ((int64_t)1 << 20) == 0) return 4096 / 2;
+  return 0;
+}
 constexpr int kQ16Slots = 256;  // counters of the 16-bit integer column kernel's hand-over lists (one per launch)
 constexpr int EDT_FLAG_NO_INDEX_FORM = 0x8000;  // internal: plan without the index buffer
 static int64_t plan_code_slab(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, int flags) {
@@ -163,7 +183,9 @@ static Plan make_plan(int dtype, int ndim, int64_t sx, int64_t sy, int64_t sz, v
     p.xy_slab = plan_code_slab(dtype, ndim, sx, sy, sz, flags);
     p.codes_whole = p.xy_slab >= sz || (p.xy_slab > 0 && p.xy_slab % 32 == 0 && ndim == 3 && !(flags & EDT_FLAG_BATCH_2D) &&
                                         sx * sy * sz * (int64_t)sizeof(uint16_t) <= whole_index_limit());
-    if (p.xy_slab > 0) p.codes = c.take<uint16_t>((size_t)((p.codes_whole ? sz : p.xy_slab) * sx * sy));
+    // (a padded pitch only where the plane exists -- a whole-volume buffer of a 3-D call; a single slice needs none)
+    p.code_pitch = sx * sy + ((p.codes_whole && ndim == 3 && sz > 1 && !(flags & EDT_FLAG_BATCH_2D)) ? plane_pad_elems(sx, sy) : 0);
+    if (p.xy_slab > 0) p.codes = c.take<uint16_t>((size_t)((p.codes_whole ? sz : p.xy_slab) * p.code_pitch));
   }
   if (ndim >= 2 && !(flags & EDT_FLAG_FORCE_GENERIC) && !env_force_generic()) {
     // (ids in the fp32 kernel's geometry: 16-column tiles for axes of more than 512 rows)
@@ -373,11 +395,15 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
       q16_counts_zeroed = true;
     }
     uint32_t *count = p.q16_counts + q16_slot++;
+    // (the index buffer's own pitch: the outer stride of codes -- and of the plane written over them -- in pass Y, the row stride
+    // of the plane pass Z reads)
+    const bool reads_plane = codes == nullptr && plane != nullptr;
     const int r = launch_column_pass_q16(F, codes, rs, g, q16_q, q16_a[axis], q16_a[0], bb, epi, count, p.q16_ids, stream,
-                                         nullptr, plane, p.q16_map + map_words_off, p.q16_map_words, nullptr, 0, 0,
+                                         nullptr, plane, p.q16_map + map_words_off, p.q16_map_words, nullptr,
+                                         reads_plane ? p.code_pitch : 0, reads_plane ? sx : 0,
                                          // (pass Y into the plane: may a tile of nothing but +inf stay there for pass Z?)
                                          (axis == 1 && plane != nullptr && codes != nullptr && q16_value_limit(q16_q, q16_a[2], sz, bb) != 0u) ? 1 : 0,
-                                         signbits);
+                                         signbits, (codes != nullptr && axis == 1) ? p.code_pitch : 0);
     if (r != EDT_OK) return r;
     launched = true;
     list.count = count;
@@ -438,13 +464,13 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
       const int64_t zc = std::min<int64_t>(p.xy_slab, sz - z0);
       const char *lab = static_cast<const char *>(d_labels) + (size_t)(z0 * sxy) * lsz;
       // (one slab of indices taken in turn, or -- codes_whole -- every slab's own part of a whole-volume buffer: the 16-bit plane)
-      uint16_t *slab_codes = p.codes + ((p.codes_whole && !one) ? z0 * sxy : 0);
+      uint16_t *slab_codes = p.codes + ((p.codes_whole && !one) ? z0 * p.code_pitch : 0);
       {
         // (slice 0 of a later slab compares against the slice below it through the halo pointer of the sharded path)
         ScopedPass t(one ? "x_pass" : nullptr, stream);
         rc = launch_row_pass_wave(dtype, lab, nullptr, nzy ? nzy + z0 * wpl : nullptr, p.rs_y + z0 * wpl,
                                   zpass ? p.zs_y + z0 * wpl : nullptr, sx, sy, zc, wx, bb, bb ? 0 : 1, stream,
-                                  z0 > 0 ? lab - (size_t)sxy * lsz : nullptr, slab_codes, zero_label);
+                                  z0 > 0 ? lab - (size_t)sxy * lsz : nullptr, slab_codes, zero_label, p.code_pitch);
         if (rc != EDT_OK) return rc;
         if (binary_yz) {
           AxisGeom gb = p.gy;
@@ -467,7 +493,7 @@ int run_device(const void *d_labels, int dtype, int ndim, int64_t sx, int64_t sy
         if (q16_only && (!launched || !list.none)) { set_error("internal: pass Y left the integer kernel"); return EDT_ERR_HIP; }
         if (!list.none)
           rc = launch_column_pass_wave_codes(cur + z0 * sxy, slab_codes, p.nz_y + z0 * wpl, p.rs_y + z0 * wpl, g, wy, bb,
-                                             zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream, nullptr, list);
+                                             zpass ? 0 : last_epi, wx, bb ? 0 : 1, stream, nullptr, list, ColumnOut(), p.code_pitch);
         if (rc != EDT_OK) return rc;
       }
     }

@@ -85,7 +85,9 @@ struct Q16Args {
   uint16_t *plane;
   uint32_t *map;          // (slab records: all ones where every row is read from the plane; nullptr where a plane is written and no map kept)
   int map_words;          // words per x-tile
-  int64_t pst, p_outer;   // the plane's own row / outer strides in 16-bit elements (slab records: edt_shard_api.hip), else g's
+  int64_t pst, p_outer;   // the plane's own row / outer strides in 16-bit elements (slab records: edt_shard_api.hip; the padded
+                          // pitch of the index buffer: edt_api.hip, code_pitch), else g's
+  int64_t cd_outer;       // outer stride of codes, and of the plane a pass writes over them (g.outer_stride, or the padded pitch)
   // output stride 2 (S = 2: the doubled grids of the voxel-graph transform) only: nullptr = the even rows go to their places
   // in F; else row r of column (x, outer o) goes to compact[x + o * c_outer + (r / 2) * c_row2]   (edt_kernels.h: ColumnOut)
   float *compact;
@@ -159,6 +161,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   constexpr int RPS = T / 8;            // rows per sweep of the workgroup: 8 threads x 4 columns per row
   const int r_in = t >> 3, cg = t & 7;
   const bool col_ok = 4 * cg < cols_left;
+  uint32_t rsany = 0u;  // a run start behind row 0 somewhere in the tile (the words this thread loads)
   bool bad = false;   // the tile has no integer form at all: handed to the fp32 kernel
   bool over = false;  // ... no 16-bit form (a value beyond nlim): the wide form if `bad` stays false
   // which of the thread's columns (4 cg .. 4 cg + 3) hold such a value: the two halves of ov01 / ov23 (index, plane rows), the
@@ -166,7 +169,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   pk ov01 = 0u, ov23 = 0u;
   uint32_t ovq = 0u;
   if (t < 64) bm[t] = 0u, bm[t + 32] = 0u;  // (96 words)
-  if (t == 0) ovm[0] = 0u, ovm[1] = 0u;
+  if (t == 0) ovm[0] = 0u, ovm[1] = 0u, ovm[2] = 0u;
   if (t < 8 * kPad) {
     // +inf around the column: 2 x kPad rows x 16 words, one 16-byte store per thread
     const int row = t < 4 * kPad ? -kPad + (t >> 2) : nb32 + ((t - 4 * kPad) >> 2);
@@ -174,13 +177,15 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   }
   for (int u = t; u < NB * 32; u += T) {
     const int band = u >> 5, col = u & 31;
-    rsp[u] = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
+    const uint32_t w = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
+    rsp[u] = w;
+    rsany |= band == 0 ? (w & ~1u) : w;  // (row 0 starts a run in every column)
   }
   // (index form: the whole tile in ONE sweep of sixteen loads per thread -- nb32 <= 16 RPS: 512 rows at 256 threads, 1024 at
   // 512: launch_q16_k)
   if constexpr (IN == kQ16InCodes) {
     v2u kk[16];
-    const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
+    const uint16_t *src = qa.codes + x0 + o * qa.cd_outer + 4 * cg;
     const pk kmaxpk = pk_both(qa.kmax), kmaxw1pk = pk_both(qa.kmaxw + qa.inf_ok), ainpk = pk_both(qa.ain);
     const pk infadd = qa.inf_ok ? 0x00010001u : 0u;
     {
@@ -294,13 +299,62 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
   over |= ovq != 0u;
   if ((t & 63) == 0) flags[t >> 6] = 0u;
   {
-    const uint32_t v = (__ballot(bad) != 0ull ? 1u : 0u) | (__ballot(over) != 0ull ? 2u : 0u);
+    const uint32_t v = (__ballot(bad) != 0ull ? 1u : 0u) | (__ballot(over) != 0ull ? 2u : 0u) | (__ballot(rsany != 0u) != 0ull ? 4u : 0u);
     if (v != 0u && (t & 63) == 0) flags[t >> 6] = v;
   }
   __syncthreads();
   uint32_t verdict = 0;
 #pragma unroll
   for (int i = 0; i < T / 64; ++i) verdict |= flags[i];
+  const bool has_run_start = (verdict & 4u) != 0u;
+  verdict &= 3u;
+  if constexpr (S == 1 && !SC) {
+    // Round 6: a tile WITHOUT STRUCTURE along the scan axis -- no run start behind row 0 in any of its columns and every row equal
+    // to row 0 (the inside of a box: the headline's single-label volume, large objects) -- has nothing for a window to find: every
+    // candidate a * d^2 + N[j] carries the column's own value, so result = min(N, the border parabola of the column's ends) (with a
+    // black border; without one: N).  Such a tile is answered from its image, row by row by the threads that filled it: no scans,
+    // no break bits, no blocks.  The test costs a tile with run starts one OR per run-start word; a tile without any compares its
+    // rows once (a cold branch, one more barrier).  debug bit 0x80: no short cut.
+    if (verdict == 0u && !has_run_start && !(dbg & 0x80) && !(epi & kEpiSign)) {
+      const v2u ref = *reinterpret_cast<const v2u *>(img + kPad * kRowWords + 2 * cg);
+      uint32_t diff = 0u;
+      for (int row = r_in; row < n; row += RPS) {
+        const v2u v = *reinterpret_cast<const v2u *>(img + (row + kPad) * kRowWords + 2 * cg);
+        diff |= (v[0] ^ ref[0]) | (v[1] ^ ref[1]);
+      }
+      if (diff != 0u) atomicOr(ovm + 2, 1u);
+      __syncthreads();
+      if (ovm[2] == 0u) {
+        if constexpr (O16) {
+          if (t == 0) atomicOr(qa.map + xt * qa.map_words + (int)(o >> 5), 1u << (o & 31));
+        }
+        if (col_ok) {
+          float *dstF = F + x0 + o * g.outer_stride + 4 * cg;
+          uint16_t *dst16 = qa.plane + x0 + o * qa.cd_outer + 4 * cg;
+          for (int row = r_in; row < n; row += RPS) {
+            pk b = ~0u;
+            if constexpr (BB) {
+              // (a * min(d, dmax + 1)^2: beyond dmax it is above every value of the tile, as the clamp of the general form)
+              uint32_t d = (uint32_t)(row + 1 < n - row ? row + 1 : n - row);
+              d = d < qa.dmax + 1u ? d : qa.dmax + 1u;
+              const uint32_t c = qa.a * d * d;
+              b = pk_both(c < kInf ? c : kInf);
+            }
+            const v2u r = {pk_min(ref[0], b), pk_min(ref[1], b)};
+            if constexpr (O16) {
+              *reinterpret_cast<v2u *>(dst16 + (int64_t)row * st) = r;
+            } else {
+              v4f f = {(float)(r[0] & 0xFFFFu) * qa.q, (float)(r[0] >> 16) * qa.q, (float)(r[1] & 0xFFFFu) * qa.q, (float)(r[1] >> 16) * qa.q};
+              if (epi & kEpiSqrt) f = (v4f){sqrtf(f[0]), sqrtf(f[1]), sqrtf(f[2]), sqrtf(f[3])};
+              if (epi & kEpiStream) __builtin_nontemporal_store(f, reinterpret_cast<v4f *>(dstF + (int64_t)row * st));
+              else *reinterpret_cast<v4f *>(dstF + (int64_t)row * st) = f;
+            }
+          }
+        }
+        return;
+      }
+    }
+  }
   if constexpr (!BB && S == 1 && !SC) {
     // Round 6: a tile of NOTHING BUT +inf whose columns hold no run start behind row 0 (no black border: a tile inside one object
     // that spans the volume along the earlier axes) has neither a border nor a finite site -- its results are +inf row for row.
@@ -313,7 +367,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       for (int u = t; u < NB * 32; u += T) notinf |= (u >> 5) == 0 ? (rsp[u] & ~1u) : rsp[u];  // (row 0 starts a run in every column)
       if (col_ok) {
         if constexpr (IN == kQ16InCodes) {
-          const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
+          const uint16_t *src = qa.codes + x0 + o * qa.cd_outer + 4 * cg;
           for (int row = r_in; row < n && notinf == 0u; row += RPS) {
             const v2u kk = *reinterpret_cast<const v2u *>(src + (int64_t)row * st);
             notinf |= ~(kk[0] & kk[1]);
@@ -356,7 +410,6 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       }
     }
   }
-  verdict &= 3u;
   // the wide form: every row of every column, fp32 results (16-bit slab records cannot carry them; the stride-2 form keeps
   // the hand-over)
   constexpr bool kWide = S == 1 && !(O16 && SC);
@@ -511,7 +564,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
       if (O16 && !to_f32) {
         // (SC: the record's rows are 16-bit here -- the table's pointers and strides count 4-byte words, a row is st / 2 of them)
         auto *ndst = SC ? (__attribute__((address_space(1))) uint32_t *)dst - ((x0 + 2 * cp) >> 1) + (((int64_t)s * 32 * st) >> 1)
-                        : (__attribute__((address_space(1))) uint32_t *)(qa.plane + x0 + o * g.outer_stride + 2 * cp);
+                        : (__attribute__((address_space(1))) uint32_t *)(qa.plane + x0 + o * qa.cd_outer + 2 * cp);
   #pragma unroll
         for (int j = 0; j < kB; ++j) {
           const int row = L.p0 + j;
@@ -616,7 +669,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
             // the first fill's mapping (whole 64-byte row pieces), by the threads that hold this half's columns (keeping the
             // first fill's registers alive across the verdict instead spills: 46 scratch instructions)
             if ((cg >> 2) == h) {
-              const uint16_t *src = qa.codes + x0 + o * g.outer_stride + 4 * cg;
+              const uint16_t *src = qa.codes + x0 + o * qa.cd_outer + 4 * cg;
   #pragma unroll 1
               for (int jb = 0; jb < 16; jb += 8) {  // (eight loads in flight: sixteen tip this cold path into scratch)
                 v2u kk[8];
@@ -685,7 +738,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
               bool p16 = false;
               if constexpr (IN == kQ16InMixed) p16 = ((qa.map[xt * qa.map_words + (row >> 5)] >> (row & 31)) & 1u) != 0u;
               if constexpr (IN == kQ16InCodes) {
-                v = q16_index_value(qa.codes[x0 + o * g.outer_stride + c + (int64_t)row * st], qa.ain);
+                v = q16_index_value(qa.codes[x0 + o * qa.cd_outer + c + (int64_t)row * st], qa.ain);
               } else if (p16) {
                 v = q16_plane_value(qa.plane[x0 + o * qa.p_outer + c + (int64_t)row * qa.pst]);
               } else {
@@ -855,8 +908,10 @@ static int launch_q16_b(float *F, const uint32_t *rs, const AxisGeom &g, const Q
 int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, const AxisGeom &g, float q, uint32_t a,
                            uint32_t ain, int bb, int epi, uint32_t *count, uint32_t *ids, hipStream_t stream,
                            const BandScatter *scatter, uint16_t *plane, uint32_t *map, int map_words, const ColumnOut *out,
-                           int64_t plane_stride, int64_t plane_outer, int plane_inf_ok, const uint32_t *signbits) {
+                           int64_t plane_stride, int64_t plane_outer, int plane_inf_ok, const uint32_t *signbits,
+                           int64_t codes_outer) {
   Q16Args qa;
+  qa.cd_outer = codes_outer > 0 ? codes_outer : g.outer_stride;
   qa.plane_inf_ok = plane_inf_ok ? 1u : 0u;
   qa.signbits = signbits;
   if ((epi & kEpiSign) && (signbits == nullptr || scatter != nullptr || (out && (out->stride == 2 || out->compact != nullptr)) ||

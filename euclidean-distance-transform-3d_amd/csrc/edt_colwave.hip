@@ -65,9 +65,11 @@ int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, co
 // First column pass reading pass 1 as 16-bit distance indices (edt_rowwave.hip, C16): F is only written.
 int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_t *nz, const uint32_t *rs,
                                   const AxisGeom &g, float w, int bb, int epi, float wx, int to_finite,
-                                  hipStream_t stream, const BandScatter *scatter, const TileList &list, const ColumnOut &out_stride) {
+                                  hipStream_t stream, const BandScatter *scatter, const TileList &list, const ColumnOut &out_stride,
+                                  int64_t codes_outer) {
   XFuse xf;
   xf.codes = codes;
+  xf.c_outer = codes_outer > 0 ? codes_outer : g.outer_stride;
   xf.w = wx;
   xf.flim = to_finite ? 0x7f7fffff : 0x7f800000;
   return launch_wave_any(F, nz, rs, g, w, bb, epi, &xf, stream, scatter, scatter != nullptr, out_stride, list);

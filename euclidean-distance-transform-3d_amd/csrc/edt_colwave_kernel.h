@@ -384,7 +384,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
     // scan, which only waits for the bit words
     load_bits();
     if (IO::kGran == 4 && aligned16) {
-      const uint16_t *Ctile = xf.codes + x0 + o * g.outer_stride;
+      const uint16_t *Ctile = xf.codes + x0 + o * xf.c_outer;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int i = wave + j * W;
@@ -401,7 +401,7 @@ k_column_pass_wave(float *__restrict__ F, const uint32_t *__restrict__ nzbits,
   scan_runs<CW>(L, lane);
   if constexpr (XF) {
     // ---- phase 0, second half: indices -> fp32 tile (edt_colwave_lane.h: code_value, four at a time) ----
-    const uint16_t *Ctile = xf.codes + x0 + o * g.outer_stride;
+    const uint16_t *Ctile = xf.codes + x0 + o * xf.c_outer;
     if (IO::kGran == 4 && aligned16) {
       typedef float v2f __attribute__((ext_vector_type(2)));
       const v2f ww = {xf.w, xf.w};
@@ -653,7 +653,7 @@ int launch_wave_c(float *F, const uint32_t *nz, const uint32_t *rs, const AxisGe
                          int bb, int epi, const XFuse *xf, hipStream_t stream, const BandScatter *scatter,
                          bool sc_al, const ColumnOut &out_stride, const TileList &list) {
   // the border rule and the index form of pass 1 are compile-time variants, the epilogue a run-time one
-  const XFuse none = {nullptr, 0.0f, 0};
+  const XFuse none = {nullptr, 0, 0.0f, 0};
   if (xf)
     return bb ? launch_wave_cbx<CW, true, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride, list)
               : launch_wave_cbx<CW, false, true>(F, nz, rs, g, w, epi, *xf, stream, scatter, sc_al, out_stride, list);

@@ -42,7 +42,8 @@ void set_error(const std::string &msg);
 //   0x20000000    integer column kernels: no wide form (tiles beyond 16 bits go to the fp32 kernel, as in round 4); with it
 //                 the fp32 launch over the hand-over list is never skipped
 //   0x40000000    integer column kernels: a tile beyond 16 bits always as two wide passes over all its columns (no column subset)
-//   0x80          integer column kernels: a tile of nothing but +inf goes through the wide form like any other (no short cut from the fill)
+//   0x80          integer column kernels: no short cuts for whole tiles -- a tile of nothing but +inf goes through the wide form like any
+//                 other, a tile without structure along the scan axis through scans, break bits and blocks
 //   0x400         no short cuts from "both column passes provably on the integer kernel": the foreground planes are written and
 //                 transposed although nobody reads them; the signed transform's sign is a pass of its own, not the last pass's epilogue
 constexpr int kDiagFormBits = 16 | 32 | 64 | 0x80 | 256 | 0x400 | 0x800 | 0x1000 | 0x2000 | 0x4000 | 0x8000 | 0x10000 | 0x20000 |

@@ -108,7 +108,8 @@ namespace edt_amd {
 // indices k (edt_rowwave.hip, C16) instead of F; the first column pass rebuilds F = fl32(fl32(k * w)^2) while it fills
 // its tile.  codes = nullptr: the ordinary in-place pass.
 struct XFuse {
-  const uint16_t *codes;  // [outer][row][x], same strides (in elements) as F
+  const uint16_t *codes;  // [outer][row][x], same strides (in elements) as F ...
+  int64_t c_outer;        // ... but for the outer stride where the index buffer has a padded pitch (0: g.outer_stride)
   float w;                // voxel size of pass 1 (k * w exact: row_codes_exact)
   int flim;               // bit pattern of FLT_MAX (tofinite) or +inf
 };
@@ -140,7 +141,7 @@ int launch_column_pass_wave(float *F, const uint32_t *nz, const uint32_t *rs, co
 int launch_column_pass_wave_codes(float *F, const uint16_t *codes, const uint32_t *nz, const uint32_t *rs,
                                   const AxisGeom &g, float w, int bb, int epi, float wx, int to_finite,
                                   hipStream_t stream, const BandScatter *scatter = nullptr, const TileList &list = TileList(),
-                                  const ColumnOut &out = ColumnOut());
+                                  const ColumnOut &out = ColumnOut(), int64_t codes_outer = 0);
 // ---- 16-bit integer column pass: edt_colq16.hip ---------------------------------------------------
 // the quantum of a call: w_i^2 = a[i] * q (false: the voxel sizes share none, the fp32 kernels keep the call)
 bool q16_quantum(const float *w, int naxes, float *q, uint32_t *a);
@@ -167,7 +168,8 @@ int launch_column_pass_q16(float *F, const uint16_t *codes, const uint32_t *rs, 
                            const BandScatter *scatter = nullptr, uint16_t *plane = nullptr, uint32_t *map = nullptr,
                            int map_words = 0, const ColumnOut *out = nullptr, int64_t plane_stride = 0, int64_t plane_outer = 0,
                            int plane_inf_ok = 0,   // the pass that reads the 16-bit plane this one writes carries +inf
-                           const uint32_t *signbits = nullptr);  // kEpiSign: the true foreground plane of this axis
+                           const uint32_t *signbits = nullptr,  // kEpiSign: the true foreground plane of this axis
+                           int64_t codes_outer = 0);  // outer stride of codes (and of the plane written over them), 0: g.outer_stride
 }  // namespace edt_amd
 
 namespace edt_amd {
@@ -178,7 +180,8 @@ bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz);
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
                          int to_finite, hipStream_t stream, const void *halo = nullptr, uint16_t *codes = nullptr,
-                         int zero_label = 0);  // zero_label: label 0 is measured like every label (the signed transform)
+                         int zero_label = 0,  // zero_label: label 0 is measured like every label (the signed transform)
+                         int64_t codes_pitch = 0);  // elements between the slices of codes (0: sx * sy)
 // k * w exact for every k of a row of sx voxels: the 16-bit index form (codes) is bit-identical
 bool row_codes_exact(float w, int64_t sx);
 

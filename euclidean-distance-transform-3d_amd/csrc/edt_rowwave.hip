@@ -97,7 +97,9 @@ template <typename T, int NC, bool HAS_Z, bool FULL, bool C16, int H = 1>
 __global__ void __launch_bounds__((H >= 2 ? H : kRowWaves) * 64)
 k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t *__restrict__ nz_y,
                 uint32_t *__restrict__ ys_y, uint32_t *__restrict__ zs_y, int sx, int sy, int sz, float w,
-                int bb, int to_finite, int nby, int ngroups, int xcd_sched, const T *__restrict__ halo, int zero_label) {
+                int bb, int to_finite, int nby, int ngroups, int xcd_sched, const T *__restrict__ halo, int zero_label,
+                int64_t opitch) {
+  // (opitch: elements between the slices of `out` -- sx * sy, or the padded pitch of the index buffer: edt_api.hip, code_pitch)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *Ttab = reinterpret_cast<float *>(smem);  // [sx + 3]: T[0..sx+1], then +inf
   int *xchg = reinterpret_cast<int *>(smem) + ((sx + 3 + 3) & ~3);  // H >= 2: [row parity][part][last, first] boundary positions
@@ -149,7 +151,7 @@ k_row_pass_wave(const T *__restrict__ labels, float *__restrict__ out, uint32_t 
     const int nrows = (sy - y0) < 32 ? (sy - y0) : 32;
     const T *base = labels + ((int64_t)z * sy + y0) * sx;  // row y0 of this slice
     constexpr uint32_t OB = C16 ? 2u : 4u;  // bytes per stored voxel
-    char *obase = reinterpret_cast<char *>(out) + (size_t)(((int64_t)z * sy + y0) * sx) * OB;
+    char *obase = reinterpret_cast<char *>(out) + (size_t)((int64_t)z * opitch + (int64_t)y0 * sx) * OB;
     const rsrc_t rs_lab = make_rsrc(base);
     // the slice below: inside the volume, or -- for slice 0 of a Z-sharded slab -- the halo slice
     const rsrc_t rs_bel = make_rsrc((HAS_Z && z > 0) ? base - sxy
@@ -375,7 +377,7 @@ bool row_pass_wave_supported(int dtype, int64_t sx, int64_t sy, int64_t sz) {
 template <typename T, int NC, int H = 1>
 static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                               uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                              int to_finite, hipStream_t stream, const void *halo, bool codes, int zero_label) {
+                              int to_finite, hipStream_t stream, const void *halo, bool codes, int zero_label, int64_t opitch) {
   const int64_t nby = ceil_div(sy, kBandRows);
   const int64_t ngroups = nby * sz;
   if (ngroups <= 0) return EDT_OK;
@@ -389,7 +391,7 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
 #define LAUNCH(Z, F, C)                                                                                   \
   hipLaunchKernelGGL((k_row_pass_wave<T, NC, Z, F, C, H>), dim3((unsigned)blocks), dim3(WAVES * 64), lds, stream,  \
                      (const T *)labels, out, nz_y, ys_y, zs_y, (int)sx, (int)sy, (int)sz, w, bb, to_finite, \
-                     (int)nby, (int)ngroups, xcd_sched, (const T *)halo, zero_label)
+                     (int)nby, (int)ngroups, xcd_sched, (const T *)halo, zero_label, opitch)
 #define LAUNCH_C(Z, F) do { if (codes) LAUNCH(Z, F, true); else LAUNCH(Z, F, false); } while (0)
   const bool full = sx == 64 * NC * H;
   if (zs_y != nullptr) { if (full) LAUNCH_C(true, true); else LAUNCH_C(true, false); }
@@ -403,9 +405,9 @@ static int launch_row_wave_tn(const void *labels, float *out, uint32_t *nz_y, ui
 template <typename T>
 static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                              uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                             int to_finite, hipStream_t stream, const void *halo, bool codes, int zero_label) {
+                             int to_finite, hipStream_t stream, const void *halo, bool codes, int zero_label, int64_t opitch) {
   const int64_t nc = ceil_div(sx, 64);
-#define GO(N) return launch_row_wave_tn<T, N>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes, zero_label)
+#define GO(N) return launch_row_wave_tn<T, N>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes, zero_label, opitch)
   if (nc <= 1) GO(1);
   if (nc <= 2) GO(2);
   if (nc <= 4) GO(4);
@@ -413,14 +415,14 @@ static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uin
   if (nc <= 16) GO(16);
 #undef GO
   // rows of 1025..2048 voxels: two waves per row (H = 2), halves of 10, 12, 14 or 16 chunks
-#define GO2(N) return launch_row_wave_tn<T, N, 2>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes, zero_label)
+#define GO2(N) return launch_row_wave_tn<T, N, 2>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes, zero_label, opitch)
   if (nc <= 20) GO2(10);
   if (nc <= 24) GO2(12);
   if (nc <= 28) GO2(14);
   if (nc <= 32) GO2(16);
 #undef GO2
   // rows of 2049..4096 voxels: four waves per row (H = 4), parts of 12 or 16 chunks
-#define GO4(N) return launch_row_wave_tn<T, N, 4>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes, zero_label)
+#define GO4(N) return launch_row_wave_tn<T, N, 4>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes, zero_label, opitch)
   if (nc <= 48) GO4(12);
   GO4(16);
 #undef GO4
@@ -428,11 +430,13 @@ static int launch_row_wave_t(const void *labels, float *out, uint32_t *nz_y, uin
 
 int launch_row_pass_wave(int dtype, const void *labels, float *out, uint32_t *nz_y, uint32_t *ys_y,
                          uint32_t *zs_y, int64_t sx, int64_t sy, int64_t sz, float w, int bb,
-                         int to_finite, hipStream_t stream, const void *halo, uint16_t *codes, int zero_label) {
-  // codes != nullptr: the 16-bit distance indices go there and `out` is not touched
+                         int to_finite, hipStream_t stream, const void *halo, uint16_t *codes, int zero_label, int64_t codes_pitch) {
+  // codes != nullptr: the 16-bit distance indices go there and `out` is not touched; codes_pitch > 0: its slices lie that many
+  // elements apart (the padded pitch of the index buffer), else sx * sy like everything else
+  const int64_t opitch = (codes != nullptr && codes_pitch > 0) ? codes_pitch : sx * sy;
   if (codes != nullptr) out = reinterpret_cast<float *>(codes);
 #define ROW_WAVE(T) \
-  return launch_row_wave_t<T>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes != nullptr, zero_label)
+  return launch_row_wave_t<T>(labels, out, nz_y, ys_y, zs_y, sx, sy, sz, w, bb, to_finite, stream, halo, codes != nullptr, zero_label, opitch)
   switch (dtype) {
     case EDT_U8: case EDT_BOOL: ROW_WAVE(uint8_t);
     case EDT_U16: ROW_WAVE(uint16_t);

@@ -53,9 +53,10 @@ def test_argument_validation_needs_no_gpu(lib):
     # (+ the hand-over list of the 16-bit integer column kernel: 4 bytes per tile)
     # ... unless every slab's indices fit the whole-volume limit (8 GiB of them; round 6: the 16-bit plane between passes Y and Z
     # then exists on volumes of several slabs too) -- 1024^3: 0.5 GiB of bit planes + 2 GiB of indices; beyond the limit: one slab
-    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 1024, 1024, 1024) <= (1 << 29) + (1 << 31) + (1 << 19)
+    # (+ 8 KiB per slice: slices of a whole multiple of 2 MiB lie that much further apart in the index buffer -- plane_pad_elems)
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 1024, 1024, 1024) <= (1 << 29) + (1 << 31) + (1 << 19) + 1024 * 8192
     assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 2048, 2048, 2048) <= (1 << 32) + (1 << 28) + (1 << 21)
-    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 2048, 2048, 512) <= (1 << 32) + (1 << 30) + (1 << 21)   # (4 GiB of indices: within the limit)
+    assert lib.edt_hip_workspace_bytes(_lib.U32, 3, 2048, 2048, 512) <= (1 << 32) + (1 << 30) + (1 << 21) + 512 * 8192   # (4 GiB of indices: within the limit)
     # ... which a caller can decline (EDT_FLAG_SMALL_WORKSPACE: fp32 between passes X and Y): 0.5 GiB for 1024^3
     assert lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 1024, 1024, 1024, _lib.FLAG_SMALL_WORKSPACE) <= (1 << 29) + (1 << 19)
     assert lib.edt_hip_workspace_bytes_flags(_lib.U32, 3, 64, 64, 64, _lib.FLAG_SMALL_WORKSPACE) <= 4 * v // 8 + 8192

@@ -170,6 +170,46 @@ def test_q16_tiles_of_nothing_but_inf(edt_gpu, oracle_port, shape):
     assert np.array_equal(edt_gpu.edtsq(img, black_border=False), oracle_port.edtsq(img, (1.0, 1.0), False))
 
 
+@pytest.mark.parametrize("shape", [(128, 200, 160), (100, 512, 130), (64, 130, 1000), (36, 97, 100), (512, 128, 128)])
+def test_q16_tiles_without_structure(edt_gpu, oracle_port, shape):
+    """Round 6: a tile with no run start behind row 0 and every row equal to row 0 (the inside of a box) is answered from its
+    image -- min(N, the border parabola of the column's ends), or N without a black border -- without scans, break bits or
+    blocks.  Volumes made of such tiles and of tiles that JUST are not: one voxel of another label (a run start in one column, in
+    y and in z), one row whose x-profile differs (no run start along the scan axis, but rows that are not equal), partial tiles
+    (row lengths that are no multiple of 32), columns that end inside a band.  The oracle's results under the default selection,
+    without the short cut (0x80), with fp32 between the passes (0x10000000) and on the fp32 kernels (0x8000000); edt and edtsq;
+    both border rules; voxel sizes whose border parabolas leave 16 bits early (a = 25, 1600)."""
+    from edt import _lib
+    lib = _lib.load()
+    sx, sy, sz = shape
+    ones = np.ones(shape, dtype=np.uint16, order="F")
+    vols = [("one label", ones)]
+    v = ones.copy(order="F"); v[sx // 3, sy // 2, sz // 2] = 2
+    vols.append(("one voxel of another label", v))
+    v = ones.copy(order="F"); v[: sx // 2, sy // 4, :] = 3                 # one y-row of every slice with another x-profile ...
+    v[: sx // 2, sy // 4 + 1:, :] = 3                                       # ... continued upwards: rows differ, run starts along y too
+    vols.append(("a step along y", v))
+    v = ones.copy(order="F"); v[sx - 5:, :, :] = 0                           # background at the end of every row: flat along y and z
+    vols.append(("background slab along x", v))
+    v = ones.copy(order="F"); v[:, :, : sz // 3] = 4
+    vols.append(("two slabs along z", v))
+    for name, lab in vols:
+        for an in ((1.0, 1.0, 1.0), (6.0, 6.0, 30.0), (1.0, 40.0, 5.0)):
+            for bb in (True, False):
+                want = oracle_port.edtsq(lab, an, bb)
+                try:
+                    for mode in (0, 0x80, 0x10000000, 0x8000000):
+                        lib.edt_hip_set_debug_mode(mode)
+                        assert np.array_equal(edt_gpu.edtsq(lab, anisotropy=an, black_border=bb), want), (shape, name, an, bb, hex(mode))
+                        if mode == 0:
+                            assert np.array_equal(edt_gpu.edt(lab, anisotropy=an, black_border=bb), np.sqrt(want)), (shape, name, an, bb, "sqrt")
+                finally:
+                    lib.edt_hip_set_debug_mode(0)
+    img = np.ones((sx, sy), dtype=np.uint8, order="F")                      # two dimensions: pass Y is the last pass
+    for bb in (True, False):
+        assert np.array_equal(edt_gpu.edt(img, anisotropy=(2.0, 3.0), black_border=bb), np.sqrt(oracle_port.edtsq(img, (2.0, 3.0), bb)))
+
+
 def test_q16_refused_tile_with_inf_rows_in_the_plane(edt_gpu, oracle_port):
     """Found by the round-6 fuzz on the first build with the short cut above (1 of 600 cases): slices of nothing but +inf that pass Y
     left in the 16-bit plane (0xFFFF) next to a slice whose values pass Z's integer form cannot hold (x-distances of up to 211
@@ -230,3 +270,43 @@ def test_q16_voxel_graph_output_stride_two(edt_gpu, oracle_port, shape):
         finally:
             lib.edt_hip_set_debug_mode(0)
         assert np.array_equal(edt_gpu.edt(lab, anisotropy=an, black_border=bb, voxel_graph=g), np.sqrt(want), equal_nan=True)
+
+
+@pytest.mark.parametrize("pad", [8, 4096, 8192 + 24])
+def test_q16_padded_index_buffer(edt_gpu, oracle_port, pad, monkeypatch):
+    """Round 6: the index buffer of pass X -- which becomes the 16-bit plane between passes Y and Z -- may keep its slices further
+    apart than sx * sy elements (csrc/edt_api.hip: plane_pad_elems; slices that are a multiple of 1 MiB alias in pass Z, the
+    full-size shapes of tests/test_gpu_fullsize.py get their pad from that rule).  Forced here (EDT_HIP_PLANE_PAD_BYTES, read per
+    plan) onto small volumes whose tiles take every way through the passes: qualifying tiles (pass Y writes the plane over the
+    indices, pass Z reads it at its own row stride), tiles beyond 16 bits (the wide form re-reads the indices), refused tiles (the
+    fp32 kernel reads the indices of its tile through XFuse.c_outer), tiles of nothing but +inf and tiles without structure (both
+    short cuts leave / write plane rows), partial tiles; the signed transform (the sign in pass Z's epilogue); under the form bits
+    of MODES; edt and edtsq.  A pad of 8 bytes separates every stride that should be the pitch from sx * sy."""
+    monkeypatch.setenv("EDT_HIP_PLANE_PAD_BYTES", str(pad))
+    from edt import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(pad)
+    # (the plan of a 3-D call really takes the pad: sz slices of 16-bit elements more workspace than without)
+    with_pad = lib.edt_hip_workspace_bytes_flags(0, 3, 160, 300, 140, 0)
+    monkeypatch.setenv("EDT_HIP_PLANE_PAD_BYTES", "0")
+    assert with_pad - lib.edt_hip_workspace_bytes_flags(0, 3, 160, 300, 140, 0) >= 140 * (pad & ~7) - 4096
+    monkeypatch.setenv("EDT_HIP_PLANE_PAD_BYTES", str(pad))
+    for shape in ((160, 300, 140), (72, 136, 1024), (640, 130, 140), (36, 97, 100), (512, 64, 33)):
+        labs = [np.asfortranarray(voronoi_labels(shape, nseeds=30, seed=sum(shape), upsample=4, membrane=0.03)),
+                np.asfortranarray(blocky_labels(shape, nlabels=3, zero_frac=0.3, block=int(rng.integers(20, 300)), rng=rng).astype(np.uint16)),
+                np.ones(shape, dtype=np.uint8, order="F")]
+        for lab in labs:
+            for an, bb in (((1, 1, 1), False), ((6, 6, 30), True), ((1.0, 1.5, 0.5), False)):
+                want = oracle_port.edtsq(lab, an, bb)
+                for got, (_, name) in zip(run_modes(edt_gpu, lab, an, bb), MODES):
+                    assert np.array_equal(got, want), (pad, shape, an, bb, name)
+                for mode in (0x80, 0x400):
+                    try:
+                        lib.edt_hip_set_debug_mode(mode)
+                        assert np.array_equal(edt_gpu.edtsq(lab, anisotropy=an, black_border=bb), want), (pad, shape, an, bb, hex(mode))
+                    finally:
+                        lib.edt_hip_set_debug_mode(0)
+                assert np.array_equal(edt_gpu.edt(lab, anisotropy=an, black_border=bb), np.sqrt(want)), (pad, shape, an, bb, "sqrt")
+        lab = labs[1]
+        want = oracle_port.edtsq(lab, (6, 6, 30), True) - oracle_port.edtsq(lab == 0, (6, 6, 30), True)
+        assert np.array_equal(edt_gpu.sdfsq(lab, anisotropy=(6, 6, 30), black_border=True), want), (pad, shape, "sdfsq")

@@ -13,6 +13,11 @@ f() { echo "$1:"; shift; env "$@" 2>&1 | grep "MISMATCH\|cases\|Traceback\|Error
   f "integer kernel's shapes (FUZZ_Q16=1), 600 cases" FUZZ_Q16=1 python tools/fuzz_gpu.py 600 6103
   f "the same shapes, volumes of +inf (FUZZ_INF=1: sparse structure, no border), 400 cases" FUZZ_Q16=1 FUZZ_INF=1 python tools/fuzz_gpu.py 400 6115
   f "the same, without the short cut for tiles of nothing but +inf (0x80), 150 cases" FUZZ_Q16=1 FUZZ_INF=1 EDT_HIP_DEBUG_MODE=0x80 python tools/fuzz_gpu.py 150 6116
+  f "the same shapes, volumes of slabs and boxes (FUZZ_FLAT=1: tiles without structure), a random pitch of the index buffer per case (FUZZ_PAD=1), 500 cases" FUZZ_Q16=1 FUZZ_FLAT=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 500 6117
+  f "the same, without the short cuts for whole tiles (0x80), 150 cases" FUZZ_Q16=1 FUZZ_FLAT=1 FUZZ_PAD=1 EDT_HIP_DEBUG_MODE=0x80 python tools/fuzz_gpu.py 150 6118
+  f "the same, fp32 between passes Y and Z (0x10000000), 100 cases" FUZZ_Q16=1 FUZZ_FLAT=1 EDT_HIP_DEBUG_MODE=0x10000000 python tools/fuzz_gpu.py 100 6119
+  f "integer kernel's shapes, a random pitch per case (FUZZ_PAD=1), 400 cases" FUZZ_Q16=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 400 6120
+  f "volumes of +inf, a random pitch per case, 200 cases" FUZZ_Q16=1 FUZZ_INF=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 200 6121
   f "the same, tiles beyond 16 bits as two wide passes (0x40000000), 200 cases" FUZZ_Q16=1 EDT_HIP_DEBUG_MODE=0x40000000 python tools/fuzz_gpu.py 200 6104
   f "the same, no wide form (0x20000000), 200 cases" FUZZ_Q16=1 EDT_HIP_DEBUG_MODE=0x20000000 python tools/fuzz_gpu.py 200 6105
   f "the same, fp32 between passes Y and Z (0x10000000), 200 cases" FUZZ_Q16=1 EDT_HIP_DEBUG_MODE=0x10000000 python tools/fuzz_gpu.py 200 6106

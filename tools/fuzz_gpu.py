@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle fuzz over shapes / dtypes / label structures (diagnostics; the regular
-parity tests live in tests/).  usage: [FUZZ_Q16=1 [FUZZ_INF=1] | FUZZ_VG=1] python tools/fuzz_gpu.py [ncases] [seed]      (FUZZ_DUMP=1: triage a mismatch under the
+parity tests live in tests/).  usage: [FUZZ_Q16=1 [FUZZ_INF=1 | FUZZ_FLAT=1] [FUZZ_PAD=1] | FUZZ_VG=1] python tools/fuzz_gpu.py [ncases] [seed]      (FUZZ_DUMP=1: triage a mismatch under the
 form-selection bits and save the case to gpurun_out/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -72,6 +72,38 @@ for i in range(ncases):
             else:
                 lab[:, c[1]:, :] = val                                        # a half space along y
         kind = -1
+    fflat = os.environ.get("FUZZ_FLAT") == "1"
+    if fflat and not finf and dims == 3:
+        # Volumes of SLABS and BOXES (round 6): columns that are constant along whole axes -- tiles without a run start behind row 0
+        # whose rows all equal row 0 are answered from their image (csrc/edt_colq16.hip: "tiles without structure") -- next to
+        # tiles that just are not: a slab along one axis (flat along the other two), a box, single voxels, an x-range whose rows
+        # differ from their neighbours' but not along y or z.  Both border rules.
+        lab = np.ones(shape, dtype=np.uint32)
+        for _ in range(int(rng.integers(0, 5))):
+            c = [int(rng.integers(0, s)) for s in shape]
+            e = [int(rng.integers(1, max(2, s // 2))) for s in shape]
+            how = rng.integers(0, 6)
+            val = 0 if rng.random() < 0.4 else int(rng.integers(2, 5))
+            if how == 0:
+                lab[c[0]:c[0] + e[0], :, :] = val                              # an x-range of every row: flat along y and z
+            elif how == 1:
+                lab[:, c[1]:c[1] + e[1], :] = val                              # a slab along y
+            elif how == 2:
+                lab[:, :, c[2]:c[2] + e[2]] = val                              # a slab along z
+            elif how == 3:
+                lab[c[0]:c[0] + e[0], c[1]:c[1] + e[1], c[2]:c[2] + e[2]] = val  # a box
+            elif how == 4:
+                lab[c[0], c[1], c[2]] = val                                    # one voxel
+            else:
+                lab[c[0]:, c[1]:, :] = val                                     # a quadrant: flat along z only
+        kind = -1
+    if os.environ.get("FUZZ_PAD") == "1":
+        # the pitch of the index buffer / 16-bit plane (csrc/edt_api.hip: plane_pad_elems), read per plan
+        pad = rng.choice(["", "0", "8", "4096", "8200"])
+        if pad:
+            os.environ["EDT_HIP_PLANE_PAD_BYTES"] = str(pad)
+        else:
+            os.environ.pop("EDT_HIP_PLANE_PAD_BYTES", None)
     if kind == -1:
         pass
     elif kind == 0:

@@ -1,5 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_q16.py -m gpu -x -q -k "without_structure or nothing_but_inf" 2>&1 | tail -3
-python -m pytest tests/test_gpu_extras.py tests/test_gpu_reference_verbatim.py tests/test_gpu_voxel_graph.py tests/test_gpu_multiproc.py tests/test_gpu_multi_device.py -m gpu -x -q 2>&1 | tail -3
-python tools/fuzz_shard.py 150 9201 2>&1 | grep "MISMATCH\|cases"
-python tools/fuzz_driver.py 2 100 9202 2>&1 | grep "MISMATCH\|cases"
+export FUZZ_DUMP=1
+FUZZ_Q16=1 FUZZ_FLAT=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 400 7001 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
+FUZZ_Q16=1 FUZZ_FLAT=1 FUZZ_PAD=1 EDT_HIP_DEBUG_MODE=0x80 python tools/fuzz_gpu.py 100 7002 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
+FUZZ_Q16=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 300 7003 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
+FUZZ_Q16=1 FUZZ_INF=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 150 7004 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
+FUZZ_PAD=1 python tools/fuzz_gpu.py 300 7005 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"

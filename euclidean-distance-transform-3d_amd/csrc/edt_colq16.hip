@@ -175,12 +175,31 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     const int row = t < 4 * kPad ? -kPad + (t >> 2) : nb32 + ((t - 4 * kPad) >> 2);
     *reinterpret_cast<v4u *>(img + (row + kPad) * kRowWords + 4 * (t & 3)) = (v4u){~0u, ~0u, ~0u, ~0u};
   }
-  for (int u = t; u < NB * 32; u += T) {
-    const int band = u >> 5, col = u & 31;
-    const uint32_t w = col < cols_left ? rsbits[(o * g.nbands + band) * g.sx + x0 + col] : 0u;
-    rsp[u] = w;
-    rsany |= band == 0 ? (w & ~1u) : w;  // (row 0 starts a run in every column)
+  // The run-start words of the tile ([outer][band][x]: 32 words per band, NB * 32 <= 2 T of them -- launch_q16_k) as at most two
+  // loads per thread from addresses that are valid for every thread (a thread without a word reads word 0 of the tile and drops
+  // it), issued AHEAD of the fill's loads and put into LDS behind them: straight-line code, one trip to memory for all of it.
+  // (Round 6: as a loop of load -> LDS store the compiler waited for each word before the next load and before the fill's first
+  // load went out -- three dependent trips per tile, tools/yorder_probe.hip has the bare pattern at half the pass's time.)
+  uint32_t rsw[2];
+  bool rsw_ok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int u = t + k * T;
+    rsw_ok[k] = u < NB * 32 && (u & 31) < cols_left;
+    const int uc = rsw_ok[k] ? u : 0;
+    rsw[k] = rsbits[(o * g.nbands + (uc >> 5)) * g.sx + x0 + (uc & 31)];
   }
+  auto put_run_starts = [&]() {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int u = t + k * T;
+      if (u < NB * 32) {
+        const uint32_t w = rsw_ok[k] ? rsw[k] : 0u;
+        rsp[u] = w;
+        rsany |= u < 32 ? (w & ~1u) : w;  // (row 0 starts a run in every column)
+      }
+    }
+  };
   // (index form: the whole tile in ONE sweep of sixteen loads per thread -- nb32 <= 16 RPS: 512 rows at 256 threads, 1024 at
   // 512: launch_q16_k)
   if constexpr (IN == kQ16InCodes) {
@@ -190,15 +209,19 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     const pk infadd = qa.inf_ok ? 0x00010001u : 0u;
     {
       constexpr int i0 = 0;
+      // (every load from a valid address -- rows behind the column's end read its last row, columns behind the row's end the
+      // tile's first four -- and dropped afterwards: sixteen loads back to back, no branch between them)
+      const uint16_t *srcv = col_ok ? src : src - 4 * cg;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = i0 + RPS * j + r_in;
-        kk[j] = (v2u){0u, 0u};
-        if (row < n && col_ok) kk[j] = EDT_Q16_FILL_LOAD(reinterpret_cast<const v2u *>(src + (int64_t)row * st));
+        kk[j] = EDT_Q16_FILL_LOAD(reinterpret_cast<const v2u *>(srcv + (int64_t)(row < n ? row : n - 1) * st));
       }
+      put_run_starts();
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = i0 + RPS * j + r_in;
+        if (!(row < n && col_ok)) kk[j] = (v2u){0u, 0u};
         if (row < nb32) {
           // k > kmax: the tile has no 16-bit form (k^2 may have wrapped: never used); kmaxw < k < 0xFFFF: no wide form either
           ov01 |= pk_subs(kk[j][0], kmaxpk);
@@ -218,6 +241,49 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     const uint32_t *mapw = qa.map + xt * qa.map_words;  // (IN == kQ16InMixed: bit z = row z of this x-tile is in the plane)
     const pk nlimpk = pk_both(qa.nlim);
     const float flim = (float)qa.nlim + 1.0f;
+    // EVERY ROW FROM THE PLANE (round 6) -- the usual case: pass Y left all of this x-tile's slices there.  The tile's map words
+    // (NB <= T / 16 of them, the same for every tile of an x-tile) are read up front as scalar loads from clamped addresses, one
+    // wait for all of them; where they are all ones the fill is sixteen plane loads back to back from addresses valid for every
+    // thread, as the index form's above.  (Before: one scalar load AND its wait ahead of every single row load, and a branch
+    // around each -- sixteen dependent trips to the scalar cache in the fill of a tile.)
+    bool all16 = false;
+    if constexpr (IN == kQ16InMixed) {
+      uint32_t allw = ~0u;
+#pragma unroll
+      for (int k = 0; k < T / 16; ++k) {
+        const uint32_t w = mapw[k < NB ? k : NB - 1];
+        // (rows behind the column's end are nobody's)
+        const uint32_t beyond = 32 * k + 32 <= n ? 0u : (32 * k >= n ? ~0u : ~0u << (n - 32 * k));
+        allw &= w | beyond;
+      }
+      all16 = __builtin_amdgcn_readfirstlane(allw) == ~0u;
+    }
+    if (all16) {
+      v2u pv[16];
+      const uint16_t *srcv = col_ok ? src16 : src16 - 4 * cg;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = RPS * j + r_in;
+        pv[j] = EDT_Q16_FILL_LOAD(reinterpret_cast<const v2u *>(srcv + (int64_t)(row < n ? row : n - 1) * pst));
+      }
+      put_run_starts();
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = RPS * j + r_in;
+        if (row < nb32) {
+          v2u v = col_ok ? pv[j] : (v2u){0u, 0u};
+          if (row < n) {
+            ov01 |= pk_subs(v[0], nlimpk);
+            ov23 |= pk_subs(v[1], nlimpk);
+            bad |= !qa.inf_ok && (pk_subs(v[0], 0xFFFEFFFEu) | pk_subs(v[1], 0xFFFEFFFEu)) != 0u;
+          } else {
+            v = (v2u){~0u, ~0u};
+          }
+          *reinterpret_cast<v2u *>(img + (row + kPad) * kRowWords + 2 * cg) = v;
+        }
+      }
+    } else {
+    put_run_starts();
     // (eight loads per thread in flight; all sixteen of a 512-row tile at once measured no faster -- cfg2 Z 0.237 vs
     // 0.239 ms -- and cost 40-90 VGPRs)
     constexpr int NL = 8;
@@ -289,6 +355,7 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
         }
       }
     }
+    }  // (!all16)
   }
 #if EDT_Q16_PRIO
   __builtin_amdgcn_s_setprio(0);

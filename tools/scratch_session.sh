@@ -1,7 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export FUZZ_DUMP=1
-FUZZ_Q16=1 FUZZ_FLAT=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 400 7001 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
-FUZZ_Q16=1 FUZZ_FLAT=1 FUZZ_PAD=1 EDT_HIP_DEBUG_MODE=0x80 python tools/fuzz_gpu.py 100 7002 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
-FUZZ_Q16=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 300 7003 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
-FUZZ_Q16=1 FUZZ_INF=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 150 7004 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
-FUZZ_PAD=1 python tools/fuzz_gpu.py 300 7005 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
+python -m pytest tests/test_gpu_q16.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+for i in 1 2; do
+for c in cfg2 cfg3 cfg3m cfg3L; do
+./tools/gpu_session.sh ab new_${c}_$i $c
+./tools/gpu_session.sh ab old_${c}_$i $c EDT_HIP_LIB=euclidean-distance-transform-3d_amd/lib/prev/libedt_hip.so
+done
+done

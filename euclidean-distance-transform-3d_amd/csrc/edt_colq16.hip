@@ -242,21 +242,19 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     const pk nlimpk = pk_both(qa.nlim);
     const float flim = (float)qa.nlim + 1.0f;
     // EVERY ROW FROM THE PLANE (round 6) -- the usual case: pass Y left all of this x-tile's slices there.  The tile's map words
-    // (NB <= T / 16 of them, the same for every tile of an x-tile) are read up front as scalar loads from clamped addresses, one
-    // wait for all of them; where they are all ones the fill is sixteen plane loads back to back from addresses valid for every
-    // thread, as the index form's above.  (Before: one scalar load AND its wait ahead of every single row load, and a branch
-    // around each -- sixteen dependent trips to the scalar cache in the fill of a tile.)
+    // (NB of them, the same for every tile of an x-tile) are read up front, one wait for all of them; where they are all ones
+    // the fill is sixteen plane loads back to back from addresses valid for every thread, as the index form's above.  (Before:
+    // one scalar load AND its wait ahead of every single row load, and a branch around each -- sixteen dependent trips to the
+    // scalar cache in the fill of a tile.)
     bool all16 = false;
     if constexpr (IN == kQ16InMixed) {
-      uint32_t allw = ~0u;
-#pragma unroll
-      for (int k = 0; k < T / 16; ++k) {
-        const uint32_t w = mapw[k < NB ? k : NB - 1];
-        // (rows behind the column's end are nobody's)
-        const uint32_t beyond = 32 * k + 32 <= n ? 0u : (32 * k >= n ? ~0u : ~0u << (n - 32 * k));
-        allw &= w | beyond;
-      }
-      all16 = __builtin_amdgcn_readfirstlane(allw) == ~0u;
+      // (one vector load: lane l takes word min(l, NB - 1) -- NB <= 32 --, in flight together with the run-start words; as
+      // scalar loads the compiler waited for every word before it asked for the next)
+      const int k = (t & 63) < NB ? (t & 63) : NB - 1;
+      const uint32_t w = mapw[k];
+      // (rows behind the column's end are nobody's)
+      const uint32_t beyond = 32 * k + 32 <= n ? 0u : ~0u << (n - 32 * k);
+      all16 = __ballot((w | beyond) != ~0u) == 0ull;
     }
     if (all16) {
       v2u pv[16];

@@ -224,15 +224,25 @@ k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const
     uint32_t diff = 0;              // (wave-uniform) bit m: mask m differs from F somewhere in the row
 #pragma unroll
     for (int m = 0; m < 4; ++m) { prevv[m] = -kVgFar; run[m] = -kVgFar; }
-    for (int c = 0; c < NC; ++c) {
+    // (round 6: the row's voxels eight chunks at a time, every load from a valid address and all sixteen in flight together --
+    // as a load per chunk inside the loop each chunk waited for its own trip to memory, eight dependent trips per 512-voxel row)
+    for (int c0 = 0; c0 < NC; c0 += 8) {
+    T lv[8];
+    uint8_t gv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int x = (c0 + k) * 64 + lane, xc = x < sx ? x : sx - 1;
+      lv[k] = lrow[xc];
+      gv[k] = grow[xc];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = c0 + k;
+      if (c >= NC) break;
       const int x = c * 64 + lane;
       const bool valid = x < sx;
-      bool fg = false;
-      uint32_t g = 0;
-      if (valid) {
-        fg = vg_fg(lrow[x]);
-        g = grow[x];
-      }
+      const bool fg = valid && vg_fg(lv[k]);
+      const uint32_t g = valid ? gv[k] : 0u;
       bool in[4];
       in[0] = valid && !fg;
       in[1] = valid && !(fg && (g & 0x01u));
@@ -247,6 +257,7 @@ k_vg_rows(const T *__restrict__ labels, const uint8_t *__restrict__ graph, const
         if (M[m]) run[m] = c * 64 + 63 - __builtin_clzll(M[m]);
       }
       diff |= (M[1] != M[0] ? 1u : 0u) | (M[2] != M[0] ? 2u : 0u) | (M[3] != M[0] ? 4u : 0u);
+    }
     }
     // ---- phase B (backward): nearest members on either side, table look-up, square ----
     int nxt[4];  // (wave-uniform) first member of the mask in the chunks after the current one

@@ -170,7 +170,7 @@ def test_q16_tiles_of_nothing_but_inf(edt_gpu, oracle_port, shape):
     assert np.array_equal(edt_gpu.edtsq(img, black_border=False), oracle_port.edtsq(img, (1.0, 1.0), False))
 
 
-@pytest.mark.parametrize("shape", [(128, 200, 160), (100, 512, 130), (64, 130, 1000), (36, 97, 100), (512, 128, 128)])
+@pytest.mark.parametrize("shape", [(128, 200, 160), (100, 512, 130), (64, 130, 1000), (36, 97, 100), (512, 128, 128), (640, 130, 140), (528, 100, 600)])
 def test_q16_tiles_without_structure(edt_gpu, oracle_port, shape):
     """Round 6: a tile with no run start behind row 0 and every row equal to row 0 (the inside of a box) is answered from its
     image -- min(N, the border parabola of the column's ends), or N without a black border -- without scans, break bits or

@@ -246,21 +246,15 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     // the fill is sixteen plane loads back to back from addresses valid for every thread, as the index form's above.  (Before:
     // one scalar load AND its wait ahead of every single row load, and a branch around each -- sixteen dependent trips to the
     // scalar cache in the fill of a tile.)
-    // ... and NO ROW from the plane (the x-tile's slices all left pass Y as fp32 values: the middle x-tiles of a row of more than
-    // 510 voxels; every tile of a pass that reads fp32 values: IN == kQ16InF32): the fp32 rows, eight at a time, from addresses
-    // valid for every thread as well.  Only a tile with rows in both places keeps the per-row choice -- its map word now comes
-    // out of the vector register (v_readlane), not from memory.
-    bool all16 = false, none16 = true;
-    uint32_t mapword = 0u;  // lane l: word min(l, NB - 1) of the tile's map
+    bool all16 = false;
     if constexpr (IN == kQ16InMixed) {
       // (one vector load: lane l takes word min(l, NB - 1) -- NB <= 32 --, in flight together with the run-start words; as
       // scalar loads the compiler waited for every word before it asked for the next)
       const int k = (t & 63) < NB ? (t & 63) : NB - 1;
-      mapword = mapw[k];
+      const uint32_t w = mapw[k];
       // (rows behind the column's end are nobody's)
       const uint32_t beyond = 32 * k + 32 <= n ? 0u : ~0u << (n - 32 * k);
-      all16 = __ballot((mapword | beyond) != ~0u) == 0ull;
-      none16 = __ballot((mapword & ~beyond) != 0u) == 0ull;
+      all16 = __ballot((w | beyond) != ~0u) == 0ull;
     }
     if (all16) {
       v2u pv[16];
@@ -294,28 +288,16 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
     for (int i0 = 0; i0 < nb32; i0 += RPS * NL) {
       v4u raw[NL];
       uint32_t in16 = 0;  // bit j: row i0 + 32 j + r_in comes from the 16-bit plane
-      if (none16) {
-        const float *srcv = col_ok ? src : src - 4 * cg;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-          const int row = i0 + RPS * j + r_in;
-          raw[j] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(srcv + (int64_t)(row < n ? row : n - 1) * st));
-        }
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-          const int row = i0 + RPS * j + r_in;
-          if (!(row < n && col_ok)) raw[j] = (v4u){0u, 0u, 0u, 0u};
-        }
-      } else {
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const int row = i0 + RPS * j + r_in;
         raw[j] = (v4u){0u, 0u, 0u, 0u};
-        // (a wave covers 8 consecutive rows: the map word is wave-uniform)
+        // (a wave covers 8 consecutive rows: the map word is wave-uniform -- a scalar load, not a vector load the fill
+        // would have to wait for: cfg3's Z pass 0.276 -> 0.233 ms)
         bool p16 = false;
         if constexpr (IN == kQ16InMixed) {
           const int mrow = row < n ? row : 0;
-          const uint32_t mw = (uint32_t)__builtin_amdgcn_readlane((int)mapword, __builtin_amdgcn_readfirstlane(mrow >> 5));
+          const uint32_t mw = mapw[__builtin_amdgcn_readfirstlane(mrow >> 5)];
           p16 = row < n && ((mw >> (row & 31)) & 1u) != 0u;
         }
         if (p16) {
@@ -329,7 +311,6 @@ k_column_pass_q16(float *__restrict__ F, const uint32_t *__restrict__ rsbits, Ax
           raw[j] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src + (int64_t)row * st));
         }
       }
-      }  // (!none16)
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const int row = i0 + RPS * j + r_in;

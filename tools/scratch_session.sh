@@ -1,12 +1,13 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_q16.py tests/test_gpu_parity.py tests/test_gpu_paths.py -m gpu -x -q 2>&1 | tail -3
-FUZZ_Q16=1 FUZZ_FLAT=1 FUZZ_PAD=1 python tools/fuzz_gpu.py 200 7301 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
-FUZZ_Q16=1 EDT_HIP_DEBUG_MODE=0x10000000 python tools/fuzz_gpu.py 200 7302 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
-FUZZ_Q16=1 EDT_HIP_DEBUG_MODE=0x100000 python tools/fuzz_gpu.py 200 7303 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
-FUZZ_Q16=1 python tools/fuzz_gpu.py 300 7304 2>&1 | grep -A8 "MISMATCH\|cases\|Traceback\|Error"
-for i in 1 2 3; do
-for c in cfg2 cfg3; do
-./tools/gpu_session.sh ab new_${c}_$i $c
-./tools/gpu_session.sh ab old_${c}_$i $c EDT_HIP_LIB=euclidean-distance-transform-3d_amd/lib/prev/libedt_hip.so
-done
-done
+mkdir -p gpurun_out
+(time python -m pytest tests -m gpu -x -q 2>&1 | tail -8) 2>&1 | tee gpurun_out/r06_gpu_tier.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a gpurun_out/r06_gpu_tier.txt
+python bench.py > gpurun_out/r06_bench_line.json 2> gpurun_out/r06_bench.err
+tail -2 gpurun_out/r06_bench.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r06_bench_line.json"))
+print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["config"]["output_verified"], d["cpu_baseline"]["value"], d["roofline"]["traffic"]["total"])
+for s in d.get("secondary", []):
+    print(s["config"], s.get("ms_per_step", s.get("gpu_seconds_total")), s.get("whole_job_frac"), s.get("output_verified"), s.get("error"))
+PY

@@ -286,3 +286,43 @@ def test_import_probe_says_why_on_a_host_without_a_gpu():
     res = subprocess.run([sys.executable, "-c", "import edt; print(edt.edtsq.__name__)"], env=env, capture_output=True, text=True,
                          timeout=120, cwd="/tmp")
     assert res.returncode == 0 and "edtsq" in res.stdout, res.stderr[-1500:]
+
+
+def test_pitch_of_the_index_buffer_follows_the_slice_size(lib, monkeypatch):
+    """Round 6 (csrc/edt_api.hip: plane_pad_elems): the slices of the index buffer / 16-bit plane lie 8 KiB further apart where a slice
+    (2 bytes per voxel) is a whole multiple of 2 MiB, 4 KiB where of 1 MiB, and sx * sy elements apart everywhere else -- seen from
+    outside as workspace bytes (host arithmetic: no GPU).  EDT_HIP_PLANE_PAD_BYTES overrides per plan; a 2-D call and a stack of
+    images (EDT_FLAG_BATCH_2D) have no plane between passes Y and Z and no pad."""
+    from edt import _lib
+    monkeypatch.delenv("EDT_HIP_PLANE_PAD_BYTES", raising=False)
+
+    def ws(shape, flags=0, ndim=3):
+        return lib.edt_hip_workspace_bytes_flags(_lib.U32, ndim, *shape, flags)
+
+    def pad_per_slice(shape):
+        monkeypatch.setenv("EDT_HIP_PLANE_PAD_BYTES", "0")
+        without = ws(shape)
+        monkeypatch.delenv("EDT_HIP_PLANE_PAD_BYTES")
+        extra = ws(shape) - without
+        assert extra % shape[2] == 0 or extra < 4096, (shape, extra)   # (the carver rounds every buffer up to its alignment)
+        return round(extra / shape[2])
+
+    assert pad_per_slice((1024, 1024, 64)) == 8192      # 2 MiB slices
+    assert pad_per_slice((2048, 512, 40)) == 8192
+    assert pad_per_slice((2048, 2048, 8)) == 8192       # 8 MiB
+    assert pad_per_slice((1024, 512, 64)) == 4096       # 1 MiB
+    assert pad_per_slice((512, 1024, 64)) == 4096
+    assert pad_per_slice((512, 512, 512)) == 0          # 512 KiB: best as it is
+    assert pad_per_slice((1024, 1008, 64)) == 0
+    assert pad_per_slice((640, 512, 64)) == 0
+    monkeypatch.setenv("EDT_HIP_PLANE_PAD_BYTES", "4096")
+    forced = ws((160, 300, 140))
+    monkeypatch.setenv("EDT_HIP_PLANE_PAD_BYTES", "0")
+    assert 140 * 4096 <= forced - ws((160, 300, 140)) < 140 * 4096 + 4096
+    # no plane, no pad: two dimensions, a stack of images
+    monkeypatch.setenv("EDT_HIP_PLANE_PAD_BYTES", "8192")
+    with_pad_2d = ws((1024, 1024, 1), ndim=2)
+    with_pad_stack = ws((1024, 1024, 16), flags=_lib.FLAG_BATCH_2D)
+    monkeypatch.setenv("EDT_HIP_PLANE_PAD_BYTES", "0")
+    assert with_pad_2d == ws((1024, 1024, 1), ndim=2)
+    assert with_pad_stack == ws((1024, 1024, 16), flags=_lib.FLAG_BATCH_2D)

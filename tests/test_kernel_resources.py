@@ -53,6 +53,19 @@ def test_integer_column_kernels_have_no_scratch_and_four_waves_per_simd():
     for f in funcs:
         assert f["scratch_ops"] == 0, f
         assert f["vgprs"] <= 128 and (f["occupancy"] is None or f["occupancy"] >= 4), f
+    # Round 6: the fill of a tile is ONE trip to memory -- the sixteen 8-byte row loads of a thread (index form: IN = 1; the 16-bit
+    # plane: IN = 2) leave back to back, no `s_waitcnt vmcnt` between them.  The source cannot show this: the build before had the
+    # same sixteen loads in its text and a wait behind the second one in its ISA (a register copy of the allocator's), and in pass Z
+    # a scalar load and its wait ahead of each -- profiles/r06_fill_ab.txt.  Pinned here so that a compiler or a well-meant edit
+    # that brings a branch back between the loads shows up without a GPU.
+    import re
+    seen = 0
+    for f in funcs:
+        m = re.search(r"k_column_pass_q16<(?:true|false), (\d),", f["name"])
+        if m and m.group(1) in ("1", "2"):
+            seen += 1
+            assert f["loads_in_flight"] >= 16, f
+    assert seen >= 20
 
 
 def test_traffic_table_names_kernels_of_this_build():
